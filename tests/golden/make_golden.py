@@ -1,0 +1,159 @@
+"""Generate golden vectors from the REFERENCE implementation (build container only).
+
+Runs /root/reference's own `PerceiverResampler` and `GatedCrossAttentionBlock` (forward via the modules,
+backward via torch autograd) in float64 on deterministic inputs and writes `tests/golden/*.npz`.
+The reference never travels to the GPU box: only these data files do.
+
+    python tests/golden/make_golden.py            # needs /root/reference
+
+Import recipe: `einops_exts` is absent -> 6-line in-memory shim; the three hot-path
+files are loaded by path under a synthetic `flamingo_mini` package so `__init__.py` (which pulls in
+transformers-dependent modules) is bypassed.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from detgen import det, resampler_params, xattn_params  # noqa: E402
+
+REF = os.environ.get("FLAMINGO_REFERENCE", "/root/reference")
+
+
+def load_reference():
+    from einops import rearrange, repeat
+    shim = types.ModuleType("einops_exts")
+    shim.rearrange_many = lambda ts, pattern, **kw: tuple(rearrange(t, pattern, **kw) for t in ts)
+    shim.repeat_many = lambda ts, pattern, **kw: tuple(repeat(t, pattern, **kw) for t in ts)
+    sys.modules["einops_exts"] = shim
+    pkg = types.ModuleType("flamingo_mini")
+    pkg.__path__ = [os.path.join(REF, "flamingo_mini")]
+    sys.modules["flamingo_mini"] = pkg
+    mods = {}
+    for name in ("utils", "perceiver_resampler", "gated_cross_attention"):
+        spec = importlib.util.spec_from_file_location(f"flamingo_mini.{name}", os.path.join(REF, "flamingo_mini", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"flamingo_mini.{name}"] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods
+
+
+def t64(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float64))
+
+
+def load_sd(module, params):
+    sd = {k: t64(v) for k, v in params.items()}
+    missing, unexpected = module.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def grads_of(module):
+    return {k: p.grad.detach().numpy().copy() for k, p in module.named_parameters()}
+
+
+def resampler_case(mods, name, *, dim, depth, heads, dim_head, q, nte, ff_mult, act, xshape, store_params):
+    R = mods["perceiver_resampler"].PerceiverResampler
+    m = R(dim=dim, depth=depth, dim_head=dim_head, heads=heads, num_latents=q, num_time_embeds=nte,
+          ff_mult=ff_mult, act=act).double()
+    params = resampler_params(dim, depth, heads, dim_head, q, nte, ff_mult, tag=name)
+    load_sd(m, params)
+    x = t64(det(xshape, name + "x", 1.0)).requires_grad_(True)
+    y = m(x)
+    dy = t64(det(tuple(y.shape), name + "dy", 1.0))
+    y.backward(dy)
+    out = {"y": y.detach().numpy(), "dx": x.grad.numpy()}
+    out.update({"g." + k: v for k, v in grads_of(m).items()})
+    meta = dict(dim=dim, depth=depth, heads=heads, dim_head=dim_head, q=q, nte=nte, ff_mult=ff_mult)
+    if store_params:
+        out.update({"p." + k: v.astype(np.float64) for k, v in params.items()})
+        out["x"] = x.detach().numpy()
+        out["dy"] = dy.numpy()
+    else:  # large case: regenerate inputs with detgen, store float32 results + a digest of the inputs
+        out = {k: v.astype(np.float32) for k, v in out.items()}
+        out["digest"] = np.array([float(sum(np.abs(v.astype(np.float64)).sum() for v in params.values())),
+                                  float(np.abs(x.detach().numpy()).sum())])
+    out["meta"] = np.array([meta[k] for k in ("dim", "depth", "heads", "dim_head", "q", "nte", "ff_mult")])
+    out["xshape"] = np.array(xshape)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "y", tuple(y.shape), "|y|", float(y.abs().mean()))
+
+
+def xattn_case(mods, name, *, dim, dv, heads, dim_head, n_visual, ff_mult, act, b, L, N, ml, store_params):
+    G = mods["gated_cross_attention"].GatedCrossAttentionBlock
+    m = G(dim=dim, dim_visual=dv, dim_head=dim_head, heads=heads, ff_mult=ff_mult, act=act, n_visual=n_visual).double()
+    params = xattn_params(dim, dv, heads, dim_head, ff_mult, tag=name)
+    load_sd(m, params)
+    y = t64(det((b, L, dim), name + "y", 1.0)).requires_grad_(True)
+    vf = t64(det((b, N, n_visual, dv), name + "vf", 1.0)).requires_grad_(True)
+    mlt = torch.from_numpy(np.asarray(ml, dtype=np.int64))
+    out_y, kv = m(y, vf, mlt, previous_kv=None, output_kv=True)
+    dy = t64(det((b, L, dim), name + "dy", 1.0))
+    out_y.backward(dy)
+    out = {"y_out": out_y.detach().numpy(), "k": kv[0].detach().numpy(), "v": kv[1].detach().numpy(),
+           "dy_in": y.grad.numpy(), "dvf": vf.grad.numpy()}
+    out.update({"g." + k: v for k, v in grads_of(m).items()})
+    # cached-decode path (gated_cross_attention.py:88-92,102-104): last token only, K/V reused
+    with torch.no_grad():
+        y_last = y[:, -1:].detach()
+        out_c, _ = m(y_last, torch.zeros(b, 1, n_visual, dv, dtype=torch.float64), mlt,
+                     previous_kv=(kv[0].detach(), kv[1].detach()), output_kv=False)
+    out["y_out_cached_last"] = out_c.numpy()
+    out["ml"] = np.asarray(ml, dtype=np.int64)
+    meta = dict(dim=dim, dv=dv, heads=heads, dim_head=dim_head, n_visual=n_visual, ff_mult=ff_mult, b=b, L=L, N=N)
+    if store_params:
+        out.update({"p." + k: v.astype(np.float64) for k, v in params.items()})
+        out["y"] = y.detach().numpy()
+        out["vf"] = vf.detach().numpy()
+        out["dy"] = dy.numpy()
+    else:
+        keep = {"ml"}
+        out = {k: (v if k in keep else v.astype(np.float32)) for k, v in out.items()}
+        out["digest"] = np.array([float(sum(np.abs(v.astype(np.float64)).sum() for v in params.values())),
+                                  float(y.detach().abs().sum()), float(vf.detach().abs().sum())])
+    out["meta"] = np.array([meta[k] for k in ("dim", "dv", "heads", "dim_head", "n_visual", "ff_mult", "b", "L", "N")])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "y_out", tuple(out_y.shape), "|delta|", float((out_y - y).abs().mean()))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_grad_enabled(True)
+    mods = load_reference()
+    toy_rs = dict(dim=64, depth=2, heads=2, dim_head=16, q=8, nte=4, ff_mult=4, store_params=True)
+    resampler_case(mods, "rs_toy_gelu_T3", act="gelu", xshape=(2, 3, 10, 64), **toy_rs)
+    resampler_case(mods, "rs_toy_sqrelu_3d", act="sqrelu", xshape=(2, 10, 64), **toy_rs)
+    resampler_case(mods, "rs_toy_relu_T4", act="relu", xshape=(1, 4, 7, 64), **toy_rs)
+    # real head geometry (8 heads x 64, 64 latents), ViT-B/32-like 50 tokens, two frames
+    resampler_case(mods, "rs_geom_v50_T2", act="gelu", xshape=(2, 2, 50, 128), dim=128, depth=2, heads=8,
+                   dim_head=64, q=64, nte=4, ff_mult=4, store_params=False)
+    # ViT-L/14-like 257 tokens (ragged: 257+64 = 321 keys), single frame given 3-D
+    resampler_case(mods, "rs_geom_v257", act="gelu", xshape=(1, 257, 128), dim=128, depth=1, heads=8,
+                   dim_head=64, q=64, nte=4, ff_mult=4, store_params=False)
+
+    # media_locations rows: (0) tags at 0 and 3 -> t=1,1,1,2,2,..; (1) leading no-media tokens and a third tag
+    # with only N=2 images -> t=3 > N (fully masked row -> uniform softmax quirk); (2) no tags at all (t=0).
+    ml_toy = [[1, 0, 0, 1, 0, 0, 0, 0],
+              [0, 0, 1, 0, 0, 1, 0, 1],
+              [0, 0, 0, 0, 0, 0, 0, 0]]
+    toy_xa = dict(dim=32, dv=64, heads=2, dim_head=16, n_visual=8, ff_mult=4, b=3, L=8, N=2, ml=ml_toy, store_params=True)
+    for act in ("gelu", "sqrelu", "relu"):
+        xattn_case(mods, f"xa_toy_{act}", act=act, **toy_xa)
+    L = 40
+    ml_geom = np.zeros((2, L), dtype=np.int64)
+    ml_geom[0, [0, 17]] = 1           # two images, boundary inside a 16-token tile
+    ml_geom[1, [3, 20, 33]] = 1       # leading t=0 tokens, and a 3rd tag with only 2 images (quirk rows)
+    xattn_case(mods, "xa_geom_L40_N2", act="gelu", dim=192, dv=128, heads=8, dim_head=64, n_visual=64, ff_mult=4,
+               b=2, L=L, N=2, ml=ml_geom.tolist(), store_params=False)
+
+
+if __name__ == "__main__":
+    main()

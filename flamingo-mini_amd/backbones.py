@@ -1,0 +1,76 @@
+"""Frozen backbones (stock HF / PyTorch-ROCm, NOT part of the accelerated path).
+
+`from_pretrained` needs hub files; this container / the GPU box have no network, so benchmarks and tests build the
+same ARCHITECTURES with random weights from the tables below (public model cards: openai/clip-vit-*, gpt2*, facebook/opt-*).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+CLIP_VISION = {
+    # name: hidden, layers, heads, intermediate, patch, image
+    "openai/clip-vit-base-patch32": (768, 12, 12, 3072, 32, 224),
+    "openai/clip-vit-base-patch16": (768, 12, 12, 3072, 16, 224),
+    "openai/clip-vit-large-patch14": (1024, 24, 16, 4096, 14, 224),
+}
+GPT2 = {  # n_embd, n_layer, n_head
+    "gpt2": (768, 12, 12), "gpt2-medium": (1024, 24, 16), "gpt2-large": (1280, 36, 20), "gpt2-xl": (1600, 48, 25),
+}
+OPT = {  # hidden, layers, heads, ffn, word_embed_proj_dim, do_layer_norm_before
+    "facebook/opt-125m": (768, 12, 12, 3072, 768, True),
+    "facebook/opt-350m": (1024, 24, 16, 4096, 512, False),
+    "facebook/opt-1.3b": (2048, 24, 32, 8192, 2048, True),
+    "facebook/opt-2.7b": (2560, 32, 32, 10240, 2560, True),
+    "facebook/opt-6.7b": (4096, 32, 32, 16384, 4096, True),
+}
+
+
+def want_random_init(config) -> bool:
+    return bool(getattr(config, "random_init_backbones", False)) or os.environ.get("FLAMINGO_RANDOM_INIT_BACKBONES", "0") == "1"
+
+
+def _tiny_override(config, key):
+    """tests may shrink a backbone: config.backbone_overrides = {'lm': {...}, 'clip': {...}}"""
+    return dict(getattr(config, "backbone_overrides", None) or {}).get(key, {})
+
+
+def load_vision_encoder(config):
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    if not want_random_init(config):
+        return CLIPVisionModel.from_pretrained(config.clip_model_type)
+    if config.clip_model_type not in CLIP_VISION:
+        raise ValueError(f"no built-in architecture for {config.clip_model_type}; known: {sorted(CLIP_VISION)}")
+    hidden, layers, heads, inter, patch, image = CLIP_VISION[config.clip_model_type]
+    kw = dict(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter,
+              patch_size=patch, image_size=image)
+    kw.update(_tiny_override(config, "clip"))
+    return CLIPVisionModel(CLIPVisionConfig(**kw))
+
+
+def load_language_model(config):
+    """Returns the *ForCausalLM model (embedding + lm_head tied as in the released checkpoints)."""
+    name = config.lm
+    if not want_random_init(config):
+        if name.startswith("gpt2"):
+            from transformers import GPT2LMHeadModel
+            return GPT2LMHeadModel.from_pretrained(name)
+        from transformers import OPTForCausalLM
+        return OPTForCausalLM.from_pretrained(name)
+    if name.startswith("gpt2"):
+        from transformers import GPT2Config, GPT2LMHeadModel
+        if name not in GPT2:
+            raise ValueError(f"no built-in architecture for {name}; known: {sorted(GPT2)}")
+        n_embd, n_layer, n_head = GPT2[name]
+        kw = dict(n_embd=n_embd, n_layer=n_layer, n_head=n_head, vocab_size=50257, n_positions=1024)
+        kw.update(_tiny_override(config, "lm"))
+        return GPT2LMHeadModel(GPT2Config(**kw))
+    from transformers import OPTConfig, OPTForCausalLM
+    if name not in OPT:
+        raise ValueError(f"no built-in architecture for {name}; known: {sorted(OPT)}")
+    hidden, layers, heads, ffn, proj, ln_before = OPT[name]
+    kw = dict(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, ffn_dim=ffn, word_embed_proj_dim=proj,
+              do_layer_norm_before=ln_before, vocab_size=50272, max_position_embeddings=2048)
+    kw.update(_tiny_override(config, "lm"))
+    return OPTForCausalLM(OPTConfig(**kw))

@@ -1,0 +1,74 @@
+"""Build libflamingo_fusion.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m flamingo_mini_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to <package>/csrc/_obj, the library next to this file so it
+travels with the source tree (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion.so")
+SOURCES = ["ff_api.hip", "ff_gemm.hip", "ff_rowwise.hip", "ff_attention.hip"]
+HEADERS = ["ff_common.h", "ff_internal.h", os.path.join("..", "..", "include", "flamingo_fusion.h")]
+ARCH = "gfx950"
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (needs ROCm >= 7.0 for gfx950)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    obj_dir = os.path.join(CSRC, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-4000:]}")
+        if verbose:
+            print("compiled", os.path.basename(s))
+        return o
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        list(ex.map(compile_one, jobs))
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB_PATH, objs):
+        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print("linked", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,484 @@
+// Module-level entry points: PerceiverResampler and GatedCrossAttentionBlock, forward and hand-written backward,
+// composed from the kernels in ff_gemm / ff_rowwise / ff_attention.  No allocation, no synchronisation: the caller
+// provides `saved` (activations kept for backward) and `scratch` buffers sized by the *_bytes() queries.
+#include <stdarg.h>
+#include <stdio.h>
+#include <math.h>
+#include "ff_common.h"
+#include "ff_internal.h"
+
+namespace ff {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return FF_ERR_LAUNCH;
+    }
+    return FF_OK;
+}
+
+static LnArgs ln_args(int dtype, int rows, int cols, RowMap x, RowMap y, RowMap dx) {
+    LnArgs a;
+    a.dtype = dtype; a.rows = rows; a.cols = cols;
+    a.x_map = x; a.y_map = y; a.dx_map = dx;
+    a.add_rows_per_seg = 0; a.add_div = 0; a.eps = 1e-5f; a.stats_given = 0;
+    return a;
+}
+
+// =====================================================================================================
+// PerceiverResampler
+// =====================================================================================================
+struct RsDims {
+    int dt, Bn, T, v, D, F, q, H, dh, inner, ffi, R, depth, nte, act;
+    size_t es;
+    float scale;
+    explicit RsDims(const ff_resampler_desc& d) {
+        dt = d.dtype; Bn = d.batch; T = d.n_frames; v = d.n_tokens; D = d.dim; F = T * v; q = d.num_latents;
+        H = d.heads; dh = d.dim_head; inner = H * dh; ffi = d.ff_mult * D; R = F + q; depth = d.depth;
+        nte = d.num_time_embeds; act = d.act; es = dtype_size(dt); scale = 1.0f / sqrtf((float)dh);
+    }
+};
+struct RsLayerSaved {
+    void *x_in, *kv_in, *Qs, *K, *V, *O, *x_mid, *xn_f, *Hpre, *Aact;
+    float *mean_l, *rstd_l, *lse, *mean_f, *rstd_f;
+};
+constexpr int kMaxDepth = 64;
+struct RsSaved {
+    float *mean_m, *rstd_m, *mean_o, *rstd_o;
+    void* x_last;
+    RsLayerSaved L[kMaxDepth];
+};
+static size_t rs_saved_layout(const RsDims& s, void* base, size_t cap, RsSaved& o) {
+    Arena a(base, cap);
+    const size_t rows_q = (size_t)s.Bn * s.q, rows_kv = (size_t)s.Bn * s.R;
+    o.mean_m = a.take<float>((size_t)s.Bn * s.F * 4);
+    o.rstd_m = a.take<float>((size_t)s.Bn * s.F * 4);
+    for (int l = 0; l < s.depth; l++) {
+        RsLayerSaved& L = o.L[l];
+        L.x_in = l == 0 ? nullptr : a.take(rows_q * s.D * s.es);
+        L.mean_l = a.take<float>(rows_q * 4);
+        L.rstd_l = a.take<float>(rows_q * 4);
+        L.kv_in = a.take(rows_kv * s.D * s.es);
+        L.Qs = a.take(rows_q * s.inner * s.es);
+        L.K = a.take(rows_kv * s.inner * s.es);
+        L.V = a.take(rows_kv * s.inner * s.es);
+        L.lse = a.take<float>((size_t)s.Bn * s.H * s.q * 4);
+        L.O = a.take(rows_q * s.inner * s.es);
+        L.x_mid = a.take(rows_q * s.D * s.es);
+        L.mean_f = a.take<float>(rows_q * 4);
+        L.rstd_f = a.take<float>(rows_q * 4);
+        L.xn_f = a.take(rows_q * s.D * s.es);
+        L.Hpre = a.take(rows_q * s.ffi * s.es);
+        L.Aact = a.take(rows_q * s.ffi * s.es);
+    }
+    o.x_last = a.take(rows_q * s.D * s.es);
+    o.mean_o = a.take<float>(rows_q * 4);
+    o.rstd_o = a.take<float>(rows_q * 4);
+    return align_up(a.used);
+}
+
+struct RsScratch {
+    void *dx, *dH, *dxn, *dO, *dQs, *dK, *dV, *dkv, *dln, *dxf, *ws;
+    size_t ws_bytes;
+};
+static size_t rs_ws_bytes(const RsDims& s) {
+    const int Mq = s.Bn * s.q, Mkv = s.Bn * s.R;
+    size_t w = 0;
+    auto g = [&](int M, int N, int K, int nz) { w = std::max(w, gemm_workspace_bytes(s.dt, M, N, K, nz, 0)); };
+    g(Mq, s.inner, s.D, 1); g(Mkv, s.inner, s.D, 2); g(Mq, s.D, s.inner, 1); g(Mq, s.ffi, s.D, 1); g(Mq, s.D, s.ffi, 1);   // fwd
+    g(s.D, s.ffi, Mq, 1); g(s.ffi, s.D, Mq, 1); g(s.D, s.inner, Mq, 1); g(s.inner, s.D, Mq, 1); g(s.inner, s.D, Mkv, 2);  // wgrad
+    g(Mkv, s.D, s.inner, 1);
+    w = std::max(w, layernorm_bwd_workspace(s.Bn * s.F, s.D));
+    w = std::max(w, layernorm_bwd_workspace(Mq, s.D));
+    w = std::max(w, rows_reduce_workspace(Mq, s.D, s.q, 1));
+    w = std::max(w, rows_reduce_workspace(s.Bn * s.F, s.D, s.F, s.v));
+    return align_up(w) + align_up((size_t)s.Bn * s.H * s.q * 4);
+}
+static size_t rs_scratch_layout(const RsDims& s, void* base, size_t cap, bool bwd, RsScratch& o) {
+    Arena a(base, cap);
+    const size_t rows_q = (size_t)s.Bn * s.q, rows_kv = (size_t)s.Bn * s.R;
+    o.ws_bytes = rs_ws_bytes(s);
+    o.ws = a.take(o.ws_bytes);
+    if (bwd) {
+        o.dx = a.take(rows_q * s.D * s.es);
+        o.dH = a.take(rows_q * s.ffi * s.es);
+        o.dxn = a.take(rows_q * s.D * s.es);
+        o.dO = a.take(rows_q * s.inner * s.es);
+        o.dQs = a.take(rows_q * s.inner * s.es);
+        o.dK = a.take(rows_kv * s.inner * s.es);
+        o.dV = a.take(rows_kv * s.inner * s.es);
+        o.dkv = a.take(rows_kv * s.D * s.es);
+        o.dln = a.take(rows_q * s.D * s.es);
+        o.dxf = a.take((size_t)s.Bn * s.F * s.D * s.es);
+    }
+    return align_up(a.used);
+}
+
+static int rs_check(const ff_resampler_desc* d) {
+    FF_CHECK(d, FF_ERR_SHAPE, "resampler: null descriptor");
+    FF_CHECK(d->dtype == FF_DTYPE_F32 || d->dtype == FF_DTYPE_BF16, FF_ERR_UNSUPPORTED, "resampler: dtype %d", d->dtype);
+    FF_CHECK(d->batch > 0 && d->n_frames > 0 && d->n_tokens > 0 && d->dim > 0 && d->depth > 0 && d->depth <= kMaxDepth && d->heads > 0 &&
+                 d->dim_head > 0 && d->num_latents > 0 && d->ff_mult > 0,
+             FF_ERR_SHAPE, "resampler: bad dimensions");
+    FF_CHECK(d->n_frames <= d->num_time_embeds, FF_ERR_SHAPE, "resampler: %d frames > num_time_embeds %d (perceiver_resampler.py:166)",
+             d->n_frames, d->num_time_embeds);
+    FF_CHECK(d->act >= FF_ACT_GELU && d->act <= FF_ACT_RELU, FF_ERR_SHAPE, "resampler: act %d", d->act);
+    return FF_OK;
+}
+
+static ff_attn_desc rs_attn_desc(const RsDims& s) {
+    ff_attn_desc a = {};
+    a.dtype = s.dt; a.batch = s.Bn; a.heads = s.H; a.dim_head = s.dh; a.n_q = s.q; a.n_kv = s.R; a.mode = FF_ATTN_DENSE;
+    const ff_strides sq = {(long long)s.q * s.inner, s.inner, s.dh}, sk = {(long long)s.R * s.inner, s.inner, s.dh};
+    a.q = sq; a.o = sq; a.dq = sq; a.dout = sq;
+    a.k = sk; a.v = sk; a.dk = sk; a.dv = sk;
+    return a;
+}
+
+static int resampler_fwd(const ff_resampler_desc* d, const void* x_f, const void* const* P, void* out, void* saved, size_t saved_bytes,
+                         void* scratch, size_t scratch_bytes, hipStream_t st) {
+    FF_TRY(rs_check(d));
+    FF_CHECK(x_f && P && out && saved && scratch, FF_ERR_SHAPE, "resampler_fwd: null argument");
+    const RsDims s(*d);
+    RsSaved S;
+    RsScratch W;
+    FF_CHECK(rs_saved_layout(s, saved, saved_bytes, S) <= saved_bytes, FF_ERR_WORKSPACE, "resampler_fwd: saved buffer too small");
+    FF_CHECK(rs_scratch_layout(s, scratch, scratch_bytes, false, W) <= scratch_bytes, FF_ERR_WORKSPACE, "resampler_fwd: scratch too small");
+    const int Mq = s.Bn * s.q, Mkv = s.Bn * s.R, Mf = s.Bn * s.F;
+    const RowMap pD = plain_rows(s.D), pI = plain_rows(s.inner), pF = plain_rows(s.ffi);
+    const RowMap lat_bcast = RowMap{s.D, 0, s.q};                                   // latents (q, D) repeated over the batch (:179)
+    const RowMap kv_media = RowMap{s.D, (long long)s.R * s.D, s.F};                // media rows inside kv_in
+    const RowMap kv_lat = RowMap{s.D, (long long)s.R * s.D, s.q};                  // latent rows inside kv_in (base + F*D)
+    const void *latents = P[0], *tpe = P[1];
+
+    {   // statistics of x_f + time_pos_emb, shared by the norm_media of every layer (:166, :52)
+        LnArgs a = ln_args(s.dt, Mf, s.D, pD, pD, pD);
+        a.add_rows_per_seg = s.F; a.add_div = s.v;
+        FF_TRY(layernorm_fwd(a, x_f, tpe, nullptr, nullptr, nullptr, S.mean_m, S.rstd_m, st));
+    }
+    for (int l = 0; l < s.depth; l++) {
+        const void* const* p = P + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
+        RsLayerSaved& L = S.L[l];
+        const void* x_in = l == 0 ? latents : L.x_in;
+        const RowMap x_map = l == 0 ? lat_bcast : pD;
+        void* x_next = l + 1 < s.depth ? S.L[l + 1].x_in : S.x_last;
+        char* kv_lat_base = (char*)L.kv_in + (size_t)s.F * s.D * s.es;
+        {   // norm_media -> media rows of kv_in (:52,65)
+            LnArgs a = ln_args(s.dt, Mf, s.D, pD, kv_media, pD);
+            a.add_rows_per_seg = s.F; a.add_div = s.v; a.stats_given = 1;
+            FF_TRY(layernorm_fwd(a, x_f, tpe, p[0], p[1], L.kv_in, S.mean_m, S.rstd_m, st));
+        }
+        {   // norm_latents -> latent rows of kv_in (:53,65)
+            LnArgs a = ln_args(s.dt, Mq, s.D, x_map, kv_lat, pD);
+            FF_TRY(layernorm_fwd(a, x_in, nullptr, p[2], p[3], kv_lat_base, L.mean_l, L.rstd_l, st));
+        }
+        // q = to_q(latents) * scale (:57,79)
+        FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, kv_lat).b(0, pD).c(pI).scale(s.scale).problem(kv_lat_base, p[4], L.Qs).run(W.ws, W.ws_bytes, st));
+        // k, v = to_k / to_v (cat(media, latents)) (:69-70), one grouped launch
+        FF_TRY(Gemm(s.dt, Mkv, s.inner, s.D).a(0, pD).b(0, pD).c(pI).problem(L.kv_in, p[5], L.K).problem(L.kv_in, p[6], L.V).run(W.ws, W.ws_bytes, st));
+        FF_TRY(attention_fwd(rs_attn_desc(s), L.Qs, L.K, L.V, nullptr, L.O, L.lse, st));   // :85-92
+        // x = x + to_out(o) (:96, :182)
+        FF_TRY(Gemm(s.dt, Mq, s.D, s.inner).a(0, pI).b(0, pI).c(pD).res_map(x_map).problem(L.O, p[7], L.x_mid, nullptr, nullptr, x_in).run(W.ws, W.ws_bytes, st));
+        // x = x + ffw(x) (:183; utils.py:45-50)
+        FF_TRY(layernorm_fwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), L.x_mid, nullptr, p[8], p[9], L.xn_f, L.mean_f, L.rstd_f, st));
+        FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(0, pD).c(pF).act(s.act).problem(L.xn_f, p[10], L.Aact, L.Hpre).run(W.ws, W.ws_bytes, st));
+        FF_TRY(Gemm(s.dt, Mq, s.D, s.ffi).a(0, pF).b(0, pF).c(pD).problem(L.Aact, p[11], x_next, nullptr, nullptr, L.x_mid).run(W.ws, W.ws_bytes, st));
+    }
+    return layernorm_fwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), S.x_last, nullptr, P[2], P[3], out, S.mean_o, S.rstd_o, st);   // :187
+}
+
+static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void* const* P, const void* dout, const void* saved,
+                         size_t saved_bytes, void* const* G, void* dx_f, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    FF_TRY(rs_check(d));
+    FF_CHECK(x_f && P && dout && saved && G && scratch, FF_ERR_SHAPE, "resampler_bwd: null argument");
+    const RsDims s(*d);
+    RsSaved S;
+    RsScratch W;
+    FF_CHECK(rs_saved_layout(s, (void*)saved, saved_bytes, S) <= saved_bytes, FF_ERR_WORKSPACE, "resampler_bwd: saved buffer too small");
+    FF_CHECK(rs_scratch_layout(s, scratch, scratch_bytes, true, W) <= scratch_bytes, FF_ERR_WORKSPACE, "resampler_bwd: scratch too small");
+    const int Mq = s.Bn * s.q, Mkv = s.Bn * s.R, Mf = s.Bn * s.F;
+    const RowMap pD = plain_rows(s.D), pI = plain_rows(s.inner), pF = plain_rows(s.ffi);
+    const RowMap lat_bcast = RowMap{s.D, 0, s.q};
+    const RowMap kv_media = RowMap{s.D, (long long)s.R * s.D, s.F};
+    const RowMap kv_lat = RowMap{s.D, (long long)s.R * s.D, s.q};
+    const void *latents = P[0], *tpe = P[1];
+    void* dxf = dx_f ? dx_f : W.dxf;
+    // attention workspace lives behind the shared workspace
+    float* attn_ws = (float*)((char*)W.ws + W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4));
+    const size_t gws = W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4);
+
+    // final norm (:187)
+    FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), dout, S.x_last, nullptr, P[2], S.mean_o, S.rstd_o, W.dx, nullptr, G[2], G[3],
+                         W.ws, gws, st));
+    for (int l = s.depth - 1; l >= 0; l--) {
+        const void* const* p = P + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
+        void* const* g = G + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
+        const RsLayerSaved& L = S.L[l];
+        const void* x_in = l == 0 ? latents : L.x_in;
+        const RowMap x_map = l == 0 ? lat_bcast : pD;
+        const char* kv_lat_base = (const char*)L.kv_in + (size_t)s.F * s.D * s.es;
+        char* dkv_lat_base = (char*)W.dkv + (size_t)s.F * s.D * s.es;
+
+        // ---- FeedForward backward (x_next = x_mid + W3 act(W1 LN(x_mid))) ----
+        FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(1, pF).c(pF).act_bwd(s.act).problem(W.dx, p[11], W.dH, nullptr, L.Hpre).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, s.D, s.ffi, Mq).a(1, pD).b(1, pF).c(pF).problem(W.dx, L.Aact, g[11]).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, Mq, s.D, s.ffi).a(0, pF).b(1, pD).c(pD).problem(W.dH, p[10], W.dxn).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, s.ffi, s.D, Mq).a(1, pF).b(1, pD).c(pD).problem(W.dH, L.xn_f, g[10]).run(W.ws, gws, st));
+        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), W.dxn, L.x_mid, nullptr, p[8], L.mean_f, L.rstd_f, W.dx, W.dx, g[8], g[9],
+                             W.ws, gws, st));                                           // W.dx is now d x_mid
+        // ---- attention backward (x_mid = x_in + Wo O) ----
+        FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, pD).b(1, pI).c(pI).problem(W.dx, p[7], W.dO).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, s.D, s.inner, Mq).a(1, pD).b(1, pI).c(pI).problem(W.dx, L.O, g[7]).run(W.ws, gws, st));
+        FF_TRY(attention_bwd(rs_attn_desc(s), L.Qs, L.K, L.V, nullptr, L.O, W.dO, L.lse, W.dQs, W.dK, W.dV, attn_ws,
+                             (size_t)s.Bn * s.H * s.q * 4, st));
+        // d to_q, d to_k, d to_v
+        FF_TRY(Gemm(s.dt, s.inner, s.D, Mq).a(1, pI).b(1, kv_lat).c(pD).scale(s.scale).problem(W.dQs, kv_lat_base, g[4]).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, s.inner, s.D, Mkv).a(1, pI).b(1, pD).c(pD).problem(W.dK, L.kv_in, g[5]).problem(W.dV, L.kv_in, g[6]).run(W.ws, gws, st));
+        // d kv_in = dK Wk + dV Wv
+        FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(W.dK, p[5], W.dkv).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(W.dV, p[6], W.dkv, nullptr, nullptr, W.dkv).run(W.ws, gws, st));
+        // d LN(latents) = scale * dQs Wq + d kv_in[latent rows]
+        FF_TRY(Gemm(s.dt, Mq, s.D, s.inner).a(0, pI).b(1, pD).c(pD).res_map(kv_lat).scale(s.scale)
+                   .problem(W.dQs, p[4], W.dln, nullptr, nullptr, dkv_lat_base).run(W.ws, gws, st));
+        // norm_latents backward, accumulated onto the residual path: W.dx becomes d x_in
+        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, x_map, pD, pD), W.dln, x_in, nullptr, p[2], L.mean_l, L.rstd_l, W.dx, W.dx, g[2], g[3],
+                             W.ws, gws, st));
+        {   // norm_media backward: d x_f accumulates over the layers (needed for d time_pos_emb even with CLIP frozen)
+            LnArgs a = ln_args(s.dt, Mf, s.D, pD, kv_media, pD);
+            a.add_rows_per_seg = s.F; a.add_div = s.v;
+            FF_TRY(layernorm_bwd(a, W.dkv, x_f, tpe, p[0], S.mean_m, S.rstd_m, dxf, l == s.depth - 1 ? nullptr : dxf, g[0], g[1], W.ws, gws, st));
+        }
+    }
+    // d latents = sum over the batch of d x_0 (:179);  d time_pos_emb[t] = sum_{b, n} d x_f[b, t, n] (:166)
+    FF_TRY(rows_reduce(s.dt, Mq, s.D, pD, s.q, 1, W.dx, G[0], W.ws, gws, st));
+    if (s.nte > s.T) {
+        hipError_t e = hipMemsetAsync((char*)G[1] + (size_t)s.T * s.D * s.es, 0, (size_t)(s.nte - s.T) * s.D * s.es, st);
+        FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "resampler_bwd: memset: %s", hipGetErrorString(e));
+    }
+    return rows_reduce(s.dt, Mf, s.D, pD, s.F, s.v, dxf, G[1], W.ws, gws, st);
+}
+
+// =====================================================================================================
+// GatedCrossAttentionBlock
+// =====================================================================================================
+struct XaDims {
+    int dt, b, L, d, dv, Nm, nv, Nk, H, dh, inner, ffi, act;
+    size_t es;
+    float scale;
+    explicit XaDims(const ff_xattn_desc& x) {
+        dt = x.dtype; b = x.batch; L = x.n_tokens; d = x.dim; dv = x.dim_visual; Nm = x.n_media; nv = x.n_visual; Nk = Nm * nv;
+        H = x.heads; dh = x.dim_head; inner = H * dh; ffi = x.ff_mult * d; act = x.act; es = dtype_size(dt);
+        scale = 1.0f / sqrtf((float)dh);
+    }
+};
+struct XaSaved {
+    float *mean_a, *rstd_a, *lse, *mean_f, *rstd_f;
+    void *yn, *Qs, *KV, *O, *attn_out, *y1, *xn_f, *Hpre, *Aact, *ffw_out;
+    size_t kv_offset;
+};
+static size_t xa_saved_layout(const XaDims& s, void* base, size_t cap, XaSaved& o) {
+    Arena a(base, cap);
+    const size_t M = (size_t)s.b * s.L;
+    o.KV = a.take((size_t)s.b * s.Nk * 2 * s.inner * s.es);   // first: its offset is part of the ABI (ff_xattn_kv_offset)
+    o.kv_offset = 0;
+    o.mean_a = a.take<float>(M * 4);
+    o.rstd_a = a.take<float>(M * 4);
+    o.yn = a.take(M * s.d * s.es);
+    o.Qs = a.take(M * s.inner * s.es);
+    o.lse = a.take<float>((size_t)s.b * s.H * s.L * 4);
+    o.O = a.take(M * s.inner * s.es);
+    o.attn_out = a.take(M * s.d * s.es);
+    o.y1 = a.take(M * s.d * s.es);
+    o.mean_f = a.take<float>(M * 4);
+    o.rstd_f = a.take<float>(M * 4);
+    o.xn_f = a.take(M * s.d * s.es);
+    o.Hpre = a.take(M * s.ffi * s.es);
+    o.Aact = a.take(M * s.ffi * s.es);
+    o.ffw_out = a.take(M * s.d * s.es);
+    return align_up(a.used);
+}
+struct XaScratch {
+    void *dy1, *dH, *dxn, *dO, *dQs, *dKV, *dyn, *ws;
+    size_t ws_bytes;
+};
+static size_t xa_ws_bytes(const XaDims& s) {
+    const int M = s.b * s.L, Mk = s.b * s.Nk;
+    size_t w = 0;
+    auto g = [&](int m, int n, int k) { w = std::max(w, gemm_workspace_bytes(s.dt, m, n, k, 1, 0)); };
+    g(M, s.inner, s.d); g(Mk, 2 * s.inner, s.dv); g(M, s.d, s.inner); g(M, s.ffi, s.d); g(M, s.d, s.ffi);
+    g(s.d, s.ffi, M); g(s.ffi, s.d, M); g(s.d, s.inner, M); g(s.inner, s.d, M); g(2 * s.inner, s.dv, Mk); g(Mk, s.dv, 2 * s.inner);
+    w = std::max(w, layernorm_bwd_workspace(M, s.d));
+    w = std::max(w, gate_grad_workspace(M, s.d));
+    return align_up(w) + align_up((size_t)s.b * s.H * s.L * 4);
+}
+static size_t xa_scratch_layout(const XaDims& s, void* base, size_t cap, bool bwd, XaScratch& o) {
+    Arena a(base, cap);
+    const size_t M = (size_t)s.b * s.L;
+    o.ws_bytes = xa_ws_bytes(s);
+    o.ws = a.take(o.ws_bytes);
+    if (bwd) {
+        o.dy1 = a.take(M * s.d * s.es);
+        o.dH = a.take(M * s.ffi * s.es);
+        o.dxn = a.take(M * s.d * s.es);
+        o.dO = a.take(M * s.inner * s.es);
+        o.dQs = a.take(M * s.inner * s.es);
+        o.dKV = a.take((size_t)s.b * s.Nk * 2 * s.inner * s.es);
+        o.dyn = a.take(M * s.d * s.es);
+    }
+    return align_up(a.used);
+}
+static int xa_check(const ff_xattn_desc* d) {
+    FF_CHECK(d, FF_ERR_SHAPE, "xattn: null descriptor");
+    FF_CHECK(d->dtype == FF_DTYPE_F32 || d->dtype == FF_DTYPE_BF16, FF_ERR_UNSUPPORTED, "xattn: dtype %d", d->dtype);
+    FF_CHECK(d->batch > 0 && d->n_tokens > 0 && d->dim > 0 && d->dim_visual > 0 && d->n_media > 0 && d->n_visual > 0 && d->heads > 0 &&
+                 d->dim_head > 0 && d->ff_mult > 0,
+             FF_ERR_SHAPE, "xattn: bad dimensions");
+    FF_CHECK(d->act >= FF_ACT_GELU && d->act <= FF_ACT_RELU, FF_ERR_SHAPE, "xattn: act %d", d->act);
+    return FF_OK;
+}
+static ff_attn_desc xa_attn_desc(const ff_xattn_desc& x, const XaDims& s, bool cached) {
+    ff_attn_desc a = {};
+    a.dtype = s.dt; a.batch = s.b; a.heads = s.H; a.dim_head = s.dh; a.n_q = s.L; a.n_kv = s.Nk;
+    a.mode = FF_ATTN_MEDIA; a.n_visual = s.nv; a.tt_stride = x.tt_stride; a.tt_offset = x.tt_offset;
+    const ff_strides sq = {(long long)s.L * s.inner, s.inner, s.dh};
+    const ff_strides sk = {(long long)s.Nk * 2 * s.inner, 2LL * s.inner, s.dh};
+    a.q = sq; a.o = sq; a.dq = sq; a.dout = sq;
+    a.k = cached ? x.cached_k : sk;
+    a.v = cached ? x.cached_v : sk;
+    a.dk = sk; a.dv = sk;
+    return a;
+}
+
+static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, const int* tt, const void* const* P, const void* ck,
+                     const void* cv, void* y_out, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    FF_TRY(xa_check(d));
+    const bool cached = ck != nullptr;
+    FF_CHECK(y && tt && P && y_out && saved && scratch && (cached ? cv != nullptr : vf != nullptr), FF_ERR_SHAPE, "xattn_fwd: null argument");
+    const XaDims s(*d);
+    XaSaved S;
+    XaScratch W;
+    FF_CHECK(xa_saved_layout(s, saved, saved_bytes, S) <= saved_bytes, FF_ERR_WORKSPACE, "xattn_fwd: saved buffer too small");
+    FF_CHECK(xa_scratch_layout(s, scratch, scratch_bytes, false, W) <= scratch_bytes, FF_ERR_WORKSPACE, "xattn_fwd: scratch too small");
+    const int M = s.b * s.L, Mk = s.b * s.Nk;
+    const RowMap pd = plain_rows(s.d), pI = plain_rows(s.inner), pF = plain_rows(s.ffi), pV = plain_rows(s.dv), pKV = plain_rows(2 * s.inner);
+    // y = norm(y); q = to_q(y) * scale (:74-78)
+    FF_TRY(layernorm_fwd(ln_args(s.dt, M, s.d, pd, pd, pd), y, nullptr, P[2], P[3], S.yn, S.mean_a, S.rstd_a, st));
+    FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(0, pd).c(pI).scale(s.scale).problem(S.yn, P[4], S.Qs).run(W.ws, W.ws_bytes, st));
+    const void *Kp, *Vp;
+    if (!cached) {  // k, v = to_kv(flatten(visual_features)).chunk(2) (:84-86): K = columns [0, inner), V = [inner, 2 inner)
+        FF_TRY(Gemm(s.dt, Mk, 2 * s.inner, s.dv).a(0, pV).b(0, pV).c(pKV).problem(vf, P[5], S.KV).run(W.ws, W.ws_bytes, st));
+        Kp = S.KV;
+        Vp = (const char*)S.KV + (size_t)s.inner * s.es;
+    } else {
+        Kp = ck; Vp = cv;
+    }
+    FF_TRY(attention_fwd(xa_attn_desc(*d, s, cached), S.Qs, Kp, Vp, tt, S.O, S.lse, st));           // :95-123
+    // y = y + tanh(alpha_attn) * to_out(o) (:126, :180)
+    FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(0, pI).c(pd).problem(S.O, P[6], S.y1, S.attn_out, nullptr, y, P[0]).run(W.ws, W.ws_bytes, st));
+    // y = y + tanh(alpha_ffw) * ffw(y) (:182)
+    FF_TRY(layernorm_fwd(ln_args(s.dt, M, s.d, pd, pd, pd), S.y1, nullptr, P[7], P[8], S.xn_f, S.mean_f, S.rstd_f, st));
+    FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(0, pd).c(pF).act(s.act).problem(S.xn_f, P[9], S.Aact, S.Hpre).run(W.ws, W.ws_bytes, st));
+    return Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(0, pF).c(pd).problem(S.Aact, P[10], y_out, S.ffw_out, nullptr, S.y1, P[1]).run(W.ws, W.ws_bytes, st);
+}
+
+static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, const int* tt, const void* const* P, const void* dy2,
+                     const void* saved, size_t saved_bytes, void* const* G, void* dy, void* dvf, void* scratch, size_t scratch_bytes,
+                     hipStream_t st) {
+    FF_TRY(xa_check(d));
+    FF_CHECK(y && vf && tt && P && dy2 && saved && G && dy && scratch, FF_ERR_SHAPE, "xattn_bwd: null argument");
+    const XaDims s(*d);
+    XaSaved S;
+    XaScratch W;
+    FF_CHECK(xa_saved_layout(s, (void*)saved, saved_bytes, S) <= saved_bytes, FF_ERR_WORKSPACE, "xattn_bwd: saved buffer too small");
+    FF_CHECK(xa_scratch_layout(s, scratch, scratch_bytes, true, W) <= scratch_bytes, FF_ERR_WORKSPACE, "xattn_bwd: scratch too small");
+    const int M = s.b * s.L, Mk = s.b * s.Nk;
+    const RowMap pd = plain_rows(s.d), pI = plain_rows(s.inner), pF = plain_rows(s.ffi), pV = plain_rows(s.dv), pKV = plain_rows(2 * s.inner);
+    const size_t attn_ws_bytes = align_up((size_t)s.b * s.H * s.L * 4);
+    const size_t gws = W.ws_bytes - attn_ws_bytes;
+    float* attn_ws = (float*)((char*)W.ws + gws);
+
+    // ---- y2 = y1 + tanh(alpha_ffw) * ffw(y1) ----
+    FF_TRY(gate_grad(s.dt, M, s.d, dy2, S.ffw_out, P[1], G[1], W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(1, pF).c(pF).act_bwd(s.act).problem(dy2, P[10], W.dH, nullptr, S.Hpre, nullptr, P[1]).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, s.d, s.ffi, M).a(1, pd).b(1, pF).c(pF).problem(dy2, S.Aact, G[10], nullptr, nullptr, nullptr, P[1]).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(1, pd).c(pd).problem(W.dH, P[9], W.dxn).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, s.ffi, s.d, M).a(1, pF).b(1, pd).c(pd).problem(W.dH, S.xn_f, G[9]).run(W.ws, gws, st));
+    FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, W.dy1, dy2, G[7], G[8], W.ws, gws, st));
+    // ---- y1 = y + tanh(alpha_attn) * to_out(attention) ----
+    FF_TRY(gate_grad(s.dt, M, s.d, W.dy1, S.attn_out, P[0], G[0], W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(W.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(W.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
+    char* dK = (char*)W.dKV;
+    char* dV = dK + (size_t)s.inner * s.es;
+    FF_TRY(attention_bwd(xa_attn_desc(*d, s, false), S.Qs, S.KV, (const char*)S.KV + (size_t)s.inner * s.es, tt, S.O, W.dO, S.lse, W.dQs, dK,
+                         dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
+    FF_TRY(Gemm(s.dt, s.inner, s.d, M).a(1, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, S.yn, G[4]).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, P[4], W.dyn).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(W.ws, gws, st));
+    if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(W.ws, gws, st));
+    return layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, W.dy1, G[2], G[3], W.ws, gws, st);
+}
+
+}  // namespace ff
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" int ff_version(void) { return 1; }
+extern "C" const char* ff_arch(void) { return "gfx950"; }
+extern "C" const char* ff_last_error(void) { return ff::g_err; }
+
+extern "C" size_t ff_resampler_saved_bytes(const ff_resampler_desc* d) {
+    if (ff::rs_check(d) != FF_OK) return 0;
+    ff::RsSaved S;
+    return ff::rs_saved_layout(ff::RsDims(*d), nullptr, 0, S);
+}
+extern "C" size_t ff_resampler_scratch_bytes(const ff_resampler_desc* d) {
+    if (ff::rs_check(d) != FF_OK) return 0;
+    ff::RsScratch W;
+    return ff::rs_scratch_layout(ff::RsDims(*d), nullptr, 0, true, W);
+}
+extern "C" int ff_resampler_fwd(const ff_resampler_desc* d, const void* x_f, const void* const* params, void* out, void* saved,
+                                size_t saved_bytes, void* scratch, size_t scratch_bytes, ff_stream_t stream) {
+    return ff::resampler_fwd(d, x_f, params, out, saved, saved_bytes, scratch, scratch_bytes, (hipStream_t)stream);
+}
+extern "C" int ff_resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void* const* params, const void* dout,
+                                const void* saved, size_t saved_bytes, void* const* grads, void* dx_f, void* scratch,
+                                size_t scratch_bytes, ff_stream_t stream) {
+    return ff::resampler_bwd(d, x_f, params, dout, saved, saved_bytes, grads, dx_f, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t ff_xattn_saved_bytes(const ff_xattn_desc* d) {
+    if (ff::xa_check(d) != FF_OK) return 0;
+    ff::XaSaved S;
+    return ff::xa_saved_layout(ff::XaDims(*d), nullptr, 0, S);
+}
+extern "C" size_t ff_xattn_scratch_bytes(const ff_xattn_desc* d) {
+    if (ff::xa_check(d) != FF_OK) return 0;
+    ff::XaScratch W;
+    return ff::xa_scratch_layout(ff::XaDims(*d), nullptr, 0, true, W);
+}
+extern "C" size_t ff_xattn_kv_offset(const ff_xattn_desc* d) {
+    (void)d;
+    return 0;
+}
+extern "C" int ff_xattn_block_fwd(const ff_xattn_desc* d, const void* y, const void* visual_features, const int* text_time,
+                                  const void* const* params, const void* cached_k, const void* cached_v, void* y_out, void* saved,
+                                  size_t saved_bytes, void* scratch, size_t scratch_bytes, ff_stream_t stream) {
+    return ff::xattn_fwd(d, y, visual_features, text_time, params, cached_k, cached_v, y_out, saved, saved_bytes, scratch, scratch_bytes,
+                         (hipStream_t)stream);
+}
+extern "C" int ff_xattn_block_bwd(const ff_xattn_desc* d, const void* y, const void* visual_features, const int* text_time,
+                                  const void* const* params, const void* dy_out, const void* saved, size_t saved_bytes, void* const* grads,
+                                  void* dy, void* dvisual_features, void* scratch, size_t scratch_bytes, ff_stream_t stream) {
+    return ff::xattn_bwd(d, y, visual_features, text_time, params, dy_out, saved, saved_bytes, grads, dy, dvisual_features, scratch,
+                         scratch_bytes, (hipStream_t)stream);
+}

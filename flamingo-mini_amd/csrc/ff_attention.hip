@@ -1,0 +1,454 @@
+// Attention core of the fusion path:  O = softmax(Q K^T) V  without materialising the score matrix.
+// Serves both PerceiverAttentionLayer (dense, perceiver_resampler.py:79-92) and MaskedCrossAttention
+// (per-image equality mask, zero rows, uniform rows: gated_cross_attention.py:95-123).
+//
+// Work split: a workgroup = 4 waves = 64 "own" rows (queries in fwd / dQ, keys in dK/dV); the "other" side is
+// streamed through LDS in 64-row tiles shared by the 4 waves.  Everything is kept TRANSPOSED:
+//     Z[other][own]   = X_tile[other][:] . own[own][:]          (S^T = K Q^T  resp.  S = Q K^T)
+//     Acc^T[d][own]  += Y_tile[other][d] * Z'[other][own]       (O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS)
+// so that (a) the softmax statistics of an own row are lane-local (lane & 15 = own row), (b) Z' leaves the first
+// MFMA in exactly the register layout the second MFMA wants as its B operand (no LDS round trip for P), and
+// (c) the strided operand of the second product comes from the row-major LDS tile via ds_read_b64_tr_b16 (bf16)
+// or plain ds_read_b32 (fp32).  Wave64 reductions: 2 shuffles (xor 16, 32) per row maximum / sum.
+#include "ff_common.h"
+#include "ff_internal.h"
+
+namespace ff {
+
+constexpr int kTile = 64;  // rows per workgroup / per LDS tile
+constexpr float kNegBig = -1.0e30f, kPosBig = 1.0e30f;
+
+template <typename T> struct AttnCfg;
+template <> struct AttnCfg<bf16> { static constexpr int pad = 8; };   // LDS row padding (elements)
+template <> struct AttnCfg<float> { static constexpr int pad = 4; };
+
+// ---- fragments of the 16 own rows of a wave (B-operand style: lane (c, g) holds row c) -------------
+template <typename T, int DH> struct OwnFrag;
+template <int DH> struct OwnFrag<bf16, DH> {
+    bf16x8 f[DH / 32];
+    FF_DEV void load(const bf16* row, int g) {  // row == nullptr -> zeros
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ks++) {
+            if (row) f[ks] = *(const bf16x8*)(row + ks * 32 + g * 8);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[ks][e] = (bf16)0.f;
+        }
+    }
+    FF_DEV float dot(const OwnFrag& o) const {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ks++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += (float)f[ks][e] * (float)o.f[ks][e];
+        return s;
+    }
+};
+template <int DH> struct OwnFrag<float, DH> {
+    f32x4 f[DH / 16];
+    FF_DEV void load(const float* row, int g) {
+#pragma unroll
+        for (int s = 0; s < DH / 16; s++) f[s] = row ? *(const f32x4*)(row + s * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    FF_DEV float dot(const OwnFrag& o) const {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < DH / 16; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) s += f[i][e] * o.f[i][e];
+        return s;
+    }
+};
+
+// ---- global -> LDS staging of a [64][DH] tile (zero filled past n_valid rows) ----------------------
+template <typename T, int DH>
+FF_DEV void stage_tile(T* lds, const T* base, long long row_stride, int row0, int n_rows) {
+    constexpr int LD = DH + AttnCfg<T>::pad;
+    constexpr int VN = Vec<T>::N, CH = DH / VN;
+    for (int idx = threadIdx.x; idx < kTile * CH; idx += 256) {
+        const int r = idx / CH, ch = idx - r * CH;
+        uint4 v = {0, 0, 0, 0};
+        if (row0 + r < n_rows) v = *(const uint4*)(base + (long long)(row0 + r) * row_stride + ch * VN);
+        *(uint4*)(lds + r * LD + ch * VN) = v;
+    }
+}
+
+// ---- Z[sub][r] (other row sub*16 + g*4 + r, own row c) += X_tile . own^T ---------------------------
+template <int DH> FF_DEV void mma_k(f32x4 (&z)[4], const bf16* tile, const OwnFrag<bf16, DH>& own) {
+    constexpr int LD = DH + AttnCfg<bf16>::pad;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ks++) {
+            const bf16x8 a = *(const bf16x8*)(tile + (sub * 16 + c) * LD + ks * 32 + g * 8);
+            z[sub] = mfma_bf16(a, own.f[ks], z[sub]);
+        }
+}
+template <int DH> FF_DEV void mma_k(f32x4 (&z)[4], const float* tile, const OwnFrag<float, DH>& own) {
+    constexpr int LD = DH + AttnCfg<float>::pad;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+        for (int s = 0; s < DH / 16; s++) {
+            const f32x4 a = *(const f32x4*)(tile + (sub * 16 + c) * LD + s * 16 + g * 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) z[sub] = mfma_f32(a[j], own.f[s][j], z[sub]);
+        }
+}
+
+// ---- Acc^T[dt][r] (d = dt*16 + g*4 + r, own row c) += Y_tile^T . Z' --------------------------------
+template <int DH> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const bf16* tile, const f32x4 (&z)[4]) {
+    constexpr int LD = DH + AttnCfg<bf16>::pad;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {  // k-step of 32 other rows = sub-tiles 2s, 2s+1
+        bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            b[e] = (bf16)z[2 * s][e];
+            b[4 + e] = (bf16)z[2 * s + 1][e];
+        }
+        const bf16* p = tile + ((2 * s) * 16 + g * 4 + (c >> 2)) * LD + (c & 3) * 4;
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; dt++) {
+            const bf16x8 a = cat4(lds_read_tr16(p + dt * 16), lds_read_tr16(p + 16 * LD + dt * 16));
+            acc[dt] = mfma_bf16(a, b, acc[dt]);
+        }
+    }
+}
+template <int DH> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const float* tile, const f32x4 (&z)[4]) {
+    constexpr int LD = DH + AttnCfg<float>::pad;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float* row = tile + (sub * 16 + g * 4 + r) * LD + c;
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; dt++) acc[dt] = mfma_f32(row[dt * 16], z[sub][r], acc[dt]);
+        }
+}
+
+// ---- which keys a query row may see ------------------------------------------------------------------
+struct RowRange {
+    int lo, hi;   // attended keys [lo, hi)
+    int softmax;  // 1: ordinary softmax row (gradient flows to the scores); 0: zero row or uniform row
+    int uniform;  // 1: fully masked row -> scores are all equal (gated_cross_attention.py:112-115)
+};
+FF_DEV RowRange row_range(const ff_attn_desc& d, const int* tt, int b, int q) {
+    RowRange r;
+    if (q >= d.n_q) { r.lo = r.hi = 0; r.softmax = 0; r.uniform = 0; return r; }
+    if (d.mode == FF_ATTN_DENSE) { r.lo = 0; r.hi = d.n_kv; r.softmax = 1; r.uniform = 0; return r; }
+    const int t = tt[(long long)b * d.tt_stride + d.tt_offset + q];
+    const int n_media = d.n_kv / d.n_visual;
+    if (t <= 0) { r.lo = r.hi = 0; r.softmax = 0; r.uniform = 0; }                              // :119-121 zeroed row
+    else if (t <= n_media) { r.lo = (t - 1) * d.n_visual; r.hi = t * d.n_visual; r.softmax = 1; r.uniform = 0; }  // :111
+    else { r.lo = 0; r.hi = d.n_kv; r.softmax = 0; r.uniform = 1; }                            // all masked -> uniform
+    return r;
+}
+
+template <typename T, int DH> FF_DEV void store_acc_row(T* row, const f32x4 (&acc)[DH / 16], float scale, int g) {
+    typedef __attribute__((ext_vector_type(4))) T vec4;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; dt++) {
+        vec4 v;
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = from_f32<T>(acc[dt][r] * scale);
+        *(vec4*)(row + dt * 16 + g * 4) = v;
+    }
+}
+
+FF_DEV float group_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16, 64)), fmaxf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
+FF_DEV float group_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+
+// block-wide [min lo, max hi) over the 64 own rows, to skip key tiles nobody attends to
+FF_DEV void block_range(int lo, int hi, int* sh, int& blo, int& bhi) {
+    if (hi <= lo) { lo = 0x7fffffff; hi = 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w] = lo; sh[4 + w] = hi; }
+    __syncthreads();
+    blo = min(min(sh[0], sh[1]), min(sh[2], sh[3]));
+    bhi = max(max(sh[4], sh[5]), max(sh[6], sh[7]));
+}
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const ff_attn_desc d, const T* __restrict__ Q, const T* __restrict__ K,
+                                                       const T* __restrict__ V, const int* __restrict__ tt, T* __restrict__ O,
+                                                       float* __restrict__ lse) {
+    constexpr int LD = DH + AttnCfg<T>::pad;
+    __shared__ __attribute__((aligned(16))) T sK[kTile * LD];
+    __shared__ __attribute__((aligned(16))) T sV[kTile * LD];
+    __shared__ int sh[8];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * kTile + w * 16 + c;
+    const RowRange rr = row_range(d, tt, b, q);
+    int blo, bhi;
+    block_range(rr.lo, rr.hi, sh, blo, bhi);
+
+    OwnFrag<T, DH> fq;
+    fq.load(q < d.n_q ? Q + b * d.q.sb + (long long)q * d.q.sr + h * d.q.sh : nullptr, g);
+
+    f32x4 acc[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; dt++) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = kNegBig, lsum = 0.f;
+
+    const T* Kb = K + b * d.k.sb + h * d.k.sh;
+    const T* Vb = V + b * d.v.sb + h * d.v.sh;
+    for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
+        __syncthreads();
+        stage_tile<T, DH>(sK, Kb, d.k.sr, k0, d.n_kv);
+        stage_tile<T, DH>(sV, Vb, d.v.sr, k0, d.n_kv);
+        __syncthreads();
+        f32x4 z[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) z[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma_k<DH>(z, sK, fq);
+        float tmax = kNegBig;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = k0 + s * 16 + g * 4 + r;
+                const bool ok = key >= rr.lo && key < rr.hi;
+                const float v = rr.uniform ? 0.f : z[s][r];
+                z[s][r] = ok ? v : kNegBig;
+                tmax = fmaxf(tmax, z[s][r]);
+            }
+        tmax = group_max(tmax);
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = __expf(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float p = z[s][r] > 0.5f * kNegBig ? __expf(z[s][r] - m_new) : 0.f;
+                z[s][r] = p;
+                psum += p;
+            }
+        lsum = lsum * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; dt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[dt][r] *= alpha;
+        mma_t<DH>(acc, sV, z);
+    }
+    lsum = group_sum(lsum);
+    if (q < d.n_q) {
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        store_acc_row<T, DH>(O + b * d.o.sb + (long long)q * d.o.sr + h * d.o.sh, acc, inv, g);
+        if (g == 0 && lse) lse[((long long)b * d.heads + h) * d.n_q + q] = lsum > 0.f ? m + __logf(lsum) : kPosBig;
+    }
+}
+
+// =====================================================================================================
+// backward, dQ (own rows = queries).  Also emits Dsum[b][h][q] = sum_d dO*O for the dK/dV kernel.
+// =====================================================================================================
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const ff_attn_desc d, const T* __restrict__ Q, const T* __restrict__ K,
+                                                          const T* __restrict__ V, const int* __restrict__ tt, const T* __restrict__ O,
+                                                          const T* __restrict__ dO, const float* __restrict__ lse, T* __restrict__ dQ,
+                                                          float* __restrict__ Dsum) {
+    constexpr int LD = DH + AttnCfg<T>::pad;
+    __shared__ __attribute__((aligned(16))) T sK[kTile * LD];
+    __shared__ __attribute__((aligned(16))) T sV[kTile * LD];
+    __shared__ int sh[8];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * kTile + w * 16 + c;
+    const bool qok = q < d.n_q;
+    RowRange rr = row_range(d, tt, b, q);
+
+    OwnFrag<T, DH> fq, fdo, fo;
+    fq.load(qok ? Q + b * d.q.sb + (long long)q * d.q.sr + h * d.q.sh : nullptr, g);
+    fdo.load(qok ? dO + b * d.dout.sb + (long long)q * d.dout.sr + h * d.dout.sh : nullptr, g);
+    fo.load(qok ? O + b * d.o.sb + (long long)q * d.o.sr + h * d.o.sh : nullptr, g);
+    const float Dq = group_sum(fdo.dot(fo));
+    const long long sidx = ((long long)b * d.heads + h) * d.n_q + q;
+    if (qok && g == 0) Dsum[sidx] = Dq;
+    const float L = qok ? lse[sidx] : kPosBig;
+    if (!rr.softmax) rr.lo = rr.hi = 0;  // zero / uniform rows: no gradient reaches the scores
+    int blo, bhi;
+    block_range(rr.lo, rr.hi, sh, blo, bhi);
+
+    f32x4 acc[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; dt++) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* Kb = K + b * d.k.sb + h * d.k.sh;
+    const T* Vb = V + b * d.v.sb + h * d.v.sh;
+    for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
+        __syncthreads();
+        stage_tile<T, DH>(sK, Kb, d.k.sr, k0, d.n_kv);
+        stage_tile<T, DH>(sV, Vb, d.v.sr, k0, d.n_kv);
+        __syncthreads();
+        f32x4 z[4], dp[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_k<DH>(z, sK, fq);     // S^T
+        mma_k<DH>(dp, sV, fdo);   // dP^T = V dO^T
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = k0 + s * 16 + g * 4 + r;
+                const bool ok = key >= rr.lo && key < rr.hi;
+                const float p = ok ? __expf(z[s][r] - L) : 0.f;
+                z[s][r] = p * (dp[s][r] - Dq);  // dS^T
+            }
+        mma_t<DH>(acc, sK, z);    // dQ^T += K^T dS^T
+    }
+    if (qok) store_acc_row<T, DH>(dQ + b * d.dq.sb + (long long)q * d.dq.sr + h * d.dq.sh, acc, 1.f, g);
+}
+
+// =====================================================================================================
+// backward, dK / dV (own rows = keys)
+// =====================================================================================================
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const ff_attn_desc d, const T* __restrict__ Q, const T* __restrict__ K,
+                                                           const T* __restrict__ V, const int* __restrict__ tt, const T* __restrict__ dO,
+                                                           const float* __restrict__ lse, const float* __restrict__ Dsum,
+                                                           T* __restrict__ dK, T* __restrict__ dV) {
+    constexpr int LD = DH + AttnCfg<T>::pad;
+    __shared__ __attribute__((aligned(16))) T sQ[kTile * LD];
+    __shared__ __attribute__((aligned(16))) T sDO[kTile * LD];
+    __shared__ int s_lo[kTile], s_hi[kTile], s_flag[kTile];
+    __shared__ float s_lse[kTile], s_D[kTile];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4, w = threadIdx.x >> 6;
+    const int key = blockIdx.x * kTile + w * 16 + c;
+    const bool kok = key < d.n_kv;
+
+    OwnFrag<T, DH> fk, fv;
+    fk.load(kok ? K + b * d.k.sb + (long long)key * d.k.sr + h * d.k.sh : nullptr, g);
+    fv.load(kok ? V + b * d.v.sb + (long long)key * d.v.sr + h * d.v.sh : nullptr, g);
+
+    f32x4 acc_k[DH / 16], acc_v[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; dt++) { acc_k[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_v[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const T* Qb = Q + b * d.q.sb + h * d.q.sh;
+    const T* dOb = dO + b * d.dout.sb + h * d.dout.sh;
+    for (int q0 = 0; q0 < d.n_q; q0 += kTile) {
+        __syncthreads();
+        stage_tile<T, DH>(sQ, Qb, d.q.sr, q0, d.n_q);
+        stage_tile<T, DH>(sDO, dOb, d.dout.sr, q0, d.n_q);
+        if (threadIdx.x < kTile) {
+            const int q = q0 + threadIdx.x;
+            const RowRange rr = row_range(d, tt, b, q);
+            s_lo[threadIdx.x] = rr.lo;
+            s_hi[threadIdx.x] = rr.hi;
+            s_flag[threadIdx.x] = rr.softmax | (rr.uniform << 1);
+            const long long sidx = ((long long)b * d.heads + h) * d.n_q + q;
+            s_lse[threadIdx.x] = q < d.n_q ? lse[sidx] : kPosBig;
+            s_D[threadIdx.x] = q < d.n_q ? Dsum[sidx] : 0.f;
+        }
+        __syncthreads();
+        f32x4 z[4], dp[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_k<DH>(z, sQ, fk);     // S[q][key]
+        mma_k<DH>(dp, sDO, fv);   // dP[q][key]
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int qi = s * 16 + g * 4 + r;
+                const bool ok = key >= s_lo[qi] && key < s_hi[qi];
+                const int flag = s_flag[qi];
+                const float sc = (flag & 2) ? 0.f : z[s][r];
+                const float p = ok ? __expf(sc - s_lse[qi]) : 0.f;
+                z[s][r] = p;                                                   // P
+                dp[s][r] = (flag & 1) ? p * (dp[s][r] - s_D[qi]) : 0.f;        // dS
+            }
+        mma_t<DH>(acc_v, sDO, z);   // dV^T += dO^T P
+        mma_t<DH>(acc_k, sQ, dp);   // dK^T += Q^T dS
+    }
+    if (kok) {
+        store_acc_row<T, DH>(dK + b * d.dk.sb + (long long)key * d.dk.sr + h * d.dk.sh, acc_k, 1.f, g);
+        store_acc_row<T, DH>(dV + b * d.dv.sb + (long long)key * d.dv.sr + h * d.dv.sh, acc_v, 1.f, g);
+    }
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static int check_desc(const ff_attn_desc& d, bool bwd) {
+    FF_CHECK(d.batch > 0 && d.heads > 0 && d.n_q > 0 && d.n_kv > 0, FF_ERR_SHAPE, "attention: bad shape b=%d h=%d nq=%d nkv=%d", d.batch,
+             d.heads, d.n_q, d.n_kv);
+    FF_CHECK(d.mode == FF_ATTN_DENSE || (d.mode == FF_ATTN_MEDIA && d.n_visual > 0 && d.n_kv % d.n_visual == 0), FF_ERR_SHAPE,
+             "attention: mode %d with n_visual=%d n_kv=%d", d.mode, d.n_visual, d.n_kv);
+    const int vec = d.dtype == FF_DTYPE_BF16 ? 8 : 4;
+    auto ok = [&](const ff_strides& s) { return s.sb % vec == 0 && s.sr % vec == 0 && s.sh % vec == 0; };
+    bool aligned = ok(d.q) && ok(d.k) && ok(d.v) && ok(d.o);
+    if (bwd) aligned = aligned && ok(d.dq) && ok(d.dk) && ok(d.dv) && ok(d.dout);
+    FF_CHECK(aligned, FF_ERR_UNSUPPORTED, "attention: strides must be multiples of %d elements", vec);
+    return FF_OK;
+}
+
+#define FF_ATTN_DISPATCH(d, ...)                                                                                  \
+    do {                                                                                                           \
+        if ((d).dtype == FF_DTYPE_BF16) {                                                                          \
+            typedef bf16 T;                                                                                        \
+            if ((d).dim_head == 64) { constexpr int DH = 64; __VA_ARGS__; }                                               \
+            else if ((d).dim_head == 32) { constexpr int DH = 32; __VA_ARGS__; }                                          \
+            else if ((d).dim_head == 128) { constexpr int DH = 128; __VA_ARGS__; }                                        \
+            else FF_CHECK(false, FF_ERR_UNSUPPORTED, "attention: bf16 dim_head %d (supported 32/64/128)", (d).dim_head); \
+        } else if ((d).dtype == FF_DTYPE_F32) {                                                                    \
+            typedef float T;                                                                                       \
+            if ((d).dim_head == 64) { constexpr int DH = 64; __VA_ARGS__; }                                               \
+            else if ((d).dim_head == 16) { constexpr int DH = 16; __VA_ARGS__; }                                          \
+            else if ((d).dim_head == 32) { constexpr int DH = 32; __VA_ARGS__; }                                          \
+            else if ((d).dim_head == 128) { constexpr int DH = 128; __VA_ARGS__; }                                        \
+            else FF_CHECK(false, FF_ERR_UNSUPPORTED, "attention: fp32 dim_head %d (supported 16/32/64/128)", (d).dim_head); \
+        } else FF_CHECK(false, FF_ERR_UNSUPPORTED, "attention: dtype %d", (d).dtype);                              \
+    } while (0)
+
+int attention_fwd(const ff_attn_desc& d, const void* Q, const void* K, const void* V, const int* tt, void* O, float* lse, hipStream_t st) {
+    FF_TRY(check_desc(d, false));
+    FF_CHECK(Q && K && V && O && (d.mode == FF_ATTN_DENSE || tt), FF_ERR_SHAPE, "attention_fwd: null argument");
+    const dim3 grid(cdiv(d.n_q, kTile), d.heads, d.batch);
+    FF_ATTN_DISPATCH(d, attn_fwd_kernel<T, DH><<<grid, dim3(256), 0, st>>>(d, (const T*)Q, (const T*)K, (const T*)V, tt, (T*)O, lse));
+    return check_launch("attn_fwd");
+}
+
+size_t attention_bwd_workspace(const ff_attn_desc& d) { return (size_t)d.batch * d.heads * d.n_q * sizeof(float); }
+
+int attention_bwd(const ff_attn_desc& d, const void* Q, const void* K, const void* V, const int* tt, const void* O, const void* dO,
+                  const float* lse, void* dQ, void* dK, void* dV, void* ws, size_t ws_bytes, hipStream_t st) {
+    FF_TRY(check_desc(d, true));
+    FF_CHECK(Q && K && V && O && dO && lse && dQ && dK && dV && (d.mode == FF_ATTN_DENSE || tt), FF_ERR_SHAPE, "attention_bwd: null argument");
+    FF_CHECK(ws && ws_bytes >= attention_bwd_workspace(d), FF_ERR_WORKSPACE, "attention_bwd workspace: need %zu have %zu",
+             attention_bwd_workspace(d), ws_bytes);
+    float* Dsum = (float*)ws;
+    const dim3 gq(cdiv(d.n_q, kTile), d.heads, d.batch), gk(cdiv(d.n_kv, kTile), d.heads, d.batch);
+    FF_ATTN_DISPATCH(d, attn_bwd_dq_kernel<T, DH><<<gq, dim3(256), 0, st>>>(d, (const T*)Q, (const T*)K, (const T*)V, tt, (const T*)O, (const T*)dO, lse, (T*)dQ, Dsum));
+    FF_TRY(check_launch("attn_bwd_dq"));
+    FF_ATTN_DISPATCH(d, attn_bwd_dkv_kernel<T, DH><<<gk, dim3(256), 0, st>>>(d, (const T*)Q, (const T*)K, (const T*)V, tt, (const T*)dO, lse, (const float*)Dsum, (T*)dK, (T*)dV));
+    return check_launch("attn_bwd_dkv");
+}
+
+}  // namespace ff
+
+extern "C" int ff_attention_fwd(const ff_attn_desc* d, const void* Q, const void* K, const void* V, const int* text_time, void* O,
+                                float* lse, ff_stream_t stream) {
+    return ff::attention_fwd(*d, Q, K, V, text_time, O, lse, (hipStream_t)stream);
+}
+extern "C" size_t ff_attention_bwd_workspace_bytes(const ff_attn_desc* d) { return ff::attention_bwd_workspace(*d); }
+extern "C" int ff_attention_bwd(const ff_attn_desc* d, const void* Q, const void* K, const void* V, const int* text_time, const void* O,
+                                const void* dO, const float* lse, void* dQ, void* dK, void* dV, void* workspace, size_t workspace_bytes,
+                                ff_stream_t stream) {
+    return ff::attention_bwd(*d, Q, K, V, text_time, O, dO, lse, dQ, dK, dV, workspace, workspace_bytes, (hipStream_t)stream);
+}

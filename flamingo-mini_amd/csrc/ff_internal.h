@@ -1,0 +1,106 @@
+// Internal (C++) interfaces between the translation units of libflamingo_fusion.
+#pragma once
+#include <algorithm>
+#include "ff_common.h"
+
+namespace ff {
+
+// ---- GEMM ----------------------------------------------------------------------------------
+constexpr int kGemmMaxZ = 4;
+struct GemmProblem {
+    const void* A;
+    const void* B;
+    void* C;
+    void* aux_out;
+    const void* aux_in;
+    const void* residual;
+    const void* gate;
+};
+struct GemmParams {
+    int M, N, K;
+    int a_layout, b_layout;
+    RowMap a_map, b_map, c_map, r_map;  // r_map addresses `residual` (defaults to c_map)
+    float scale;
+    int act, act_bwd;
+    int split_k, k_per_split;
+    float* partial;
+    int a_vec_ok, b_vec_ok;
+    int nz;
+    GemmProblem p[kGemmMaxZ];
+};
+int gemm_pick_split(int dtype, int M, int N, int K, int nz);
+size_t gemm_workspace_bytes(int dtype, int M, int N, int K, int nz, int split_k);
+int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipStream_t st);
+
+// Convenience builder used by the module-level code.
+struct Gemm {
+    GemmParams P;
+    int dtype;
+    Gemm(int dtype_, int M, int N, int K) : dtype(dtype_) {
+        P = GemmParams{};
+        P.M = M; P.N = N; P.K = K;
+        P.scale = 1.f; P.act = FF_ACT_NONE; P.act_bwd = FF_ACT_NONE; P.split_k = 0; P.nz = 0;
+        P.a_map = plain_rows(K); P.b_map = plain_rows(K); P.c_map = plain_rows(N); P.r_map = P.c_map;
+    }
+    // A stored [M][K] (layout 0) or [K][M] (layout 1); same for B with N.
+    Gemm& a(int layout, RowMap m) { P.a_layout = layout; P.a_map = m; return *this; }
+    Gemm& b(int layout, RowMap m) { P.b_layout = layout; P.b_map = m; return *this; }
+    Gemm& c(RowMap m) { P.c_map = m; P.r_map = m; return *this; }
+    Gemm& res_map(RowMap m) { P.r_map = m; return *this; }
+    Gemm& scale(float s) { P.scale = s; return *this; }
+    Gemm& act(int a) { P.act = a; return *this; }
+    Gemm& act_bwd(int a) { P.act_bwd = a; return *this; }
+    Gemm& problem(const void* A, const void* B, void* C, void* aux_out = nullptr, const void* aux_in = nullptr,
+                  const void* residual = nullptr, const void* gate = nullptr) {
+        P.p[P.nz++] = GemmProblem{A, B, C, aux_out, aux_in, residual, gate};
+        return *this;
+    }
+    size_t workspace() const { return gemm_workspace_bytes(dtype, P.M, P.N, P.K, std::max(P.nz, 1), P.split_k); }
+    int run(void* ws, size_t ws_bytes, hipStream_t st) const { return gemm_launch(P, dtype, ws, ws_bytes, st); }
+};
+
+// ---- row-wise kernels ------------------------------------------------------------------------
+struct LnArgs {
+    int dtype;
+    int rows, cols;
+    RowMap x_map, y_map, dx_map;
+    int add_rows_per_seg, add_div;
+    float eps;
+    int stats_given;
+};
+int layernorm_fwd(const LnArgs& a, const void* x, const void* add, const void* gamma, const void* beta, void* y,
+                  float* mean, float* rstd, hipStream_t st);
+size_t layernorm_bwd_workspace(int rows, int cols);
+int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* add, const void* gamma, const float* mean,
+                  const float* rstd, void* dx, const void* dx_residual, void* dgamma, void* dbeta, void* ws,
+                  size_t ws_bytes, hipStream_t st);
+size_t rows_reduce_workspace(int rows, int cols, int rows_per_batch, int rows_per_group);
+int rows_reduce(int dtype, int rows, int cols, RowMap x_map, int rows_per_batch, int rows_per_group, const void* x,
+                void* out, void* ws, size_t ws_bytes, hipStream_t st);
+size_t gate_grad_workspace(int rows, int cols);
+int gate_grad(int dtype, int rows, int cols, const void* a, const void* b, const void* alpha, void* dalpha, void* ws,
+              size_t ws_bytes, hipStream_t st);
+int text_time(int batch, int n_tokens, const void* ml, int elem_bytes, int* out, hipStream_t st);
+
+// ---- attention -------------------------------------------------------------------------------
+size_t attention_bwd_workspace(const ff_attn_desc& d);
+int attention_fwd(const ff_attn_desc& d, const void* Q, const void* K, const void* V, const int* tt, void* O, float* lse,
+                  hipStream_t st);
+int attention_bwd(const ff_attn_desc& d, const void* Q, const void* K, const void* V, const int* tt, const void* O,
+                  const void* dO, const float* lse, void* dQ, void* dK, void* dV, void* ws, size_t ws_bytes,
+                  hipStream_t st);
+
+// ---- bump allocator over a caller-provided buffer ----------------------------------------------
+struct Arena {
+    unsigned char* base;
+    size_t cap, used;
+    Arena(void* p, size_t c) : base((unsigned char*)p), cap(c), used(0) {}
+    template <typename T = void> T* take(size_t bytes) {
+        size_t at = align_up(used);
+        used = at + bytes;
+        return (T*)(base ? base + at : nullptr);  // base == nullptr: sizing pass
+    }
+    bool ok() const { return used <= cap; }
+};
+
+}  // namespace ff

@@ -1,0 +1,473 @@
+// Row-wise (HBM-bound) kernels of the fusion path: LayerNorm forward / backward, column reductions for the
+// parameter gradients (d gamma, d beta, d latents, d time_pos_emb), the tanh-gate scalar gradient and the
+// media-location cumulative sum.  One wave owns one row; 16-byte vector accesses; fp32 statistics.
+#include "ff_common.h"
+#include "ff_internal.h"
+
+namespace ff {
+
+// VEC consecutive elements as floats (VEC == Vec<T>::N -> one 16-byte access, VEC == 1 -> scalar fallback)
+template <typename T, int VEC> FF_DEV void ld(const T* p, float (&o)[VEC]) {
+    if constexpr (VEC == 1) o[0] = to_f32(p[0]);
+    else Vec<T>::load(p, o);
+}
+template <typename T, int VEC> FF_DEV void st(T* p, const float (&o)[VEC]) {
+    if constexpr (VEC == 1) p[0] = from_f32<T>(o[0]);
+    else Vec<T>::store(p, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x (+add) - mean) * rstd * gamma + beta       (perceiver_resampler.py:52-53,187;
+// gated_cross_attention.py:74; utils.py:46).  Two-pass statistics in fp32 like torch.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a, const T* __restrict__ x, const T* __restrict__ add,
+                                                     const T* __restrict__ gamma, const T* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const T* xr = x + a.x_map.off(row);
+    const T* ar = nullptr;
+    if (add) ar = add + (long long)((row % a.add_rows_per_seg) / a.add_div) * a.cols;
+    const int nchunk = a.cols / VEC;
+    float mu, rs;
+    if (a.stats_given) {
+        mu = mean[row];
+        rs = rstd[row];
+    } else {
+        float s = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            float v[VEC];
+            ld<T, VEC>(xr + c * VEC, v);
+            if (ar) {
+                float t[VEC];
+                ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+                for (int i = 0; i < VEC; i++) v[i] += t[i];
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; i++) s += v[i];
+        }
+        mu = wave_sum(s) / (float)a.cols;
+        float q = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            float v[VEC];
+            ld<T, VEC>(xr + c * VEC, v);
+            if (ar) {
+                float t[VEC];
+                ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+                for (int i = 0; i < VEC; i++) v[i] += t[i];
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; i++) q += (v[i] - mu) * (v[i] - mu);
+        }
+        rs = rsqrtf(wave_sum(q) / (float)a.cols + a.eps);
+        if (lane == 0 && mean) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+    if (!y) return;
+    T* yr = y + a.y_map.off(row);
+    for (int c = lane; c < nchunk; c += 64) {
+        float v[VEC], g[VEC], b[VEC];
+        ld<T, VEC>(xr + c * VEC, v);
+        if (ar) {
+            float t[VEC];
+            ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) v[i] += t[i];
+        }
+        ld<T, VEC>(gamma + c * VEC, g);
+        ld<T, VEC>(beta + c * VEC, b);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) v[i] = (v[i] - mu) * rs * g[i] + b[i];
+        st<T, VEC>(yr + c * VEC, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward, data gradient:  dx = dx_residual + rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)),
+// dyh = dy * gamma.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnArgs a, const T* __restrict__ dy, const T* __restrict__ x,
+                                                        const T* __restrict__ add, const T* __restrict__ gamma,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd, T* dx,
+                                                        const T* dx_res) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const T* xr = x + a.x_map.off(row);
+    const T* dyr = dy + a.y_map.off(row);
+    const T* ar = nullptr;
+    if (add) ar = add + (long long)((row % a.add_rows_per_seg) / a.add_div) * a.cols;
+    const float mu = mean[row], rs = rstd[row];
+    const int nchunk = a.cols / VEC;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+        float v[VEC], d[VEC], g[VEC];
+        ld<T, VEC>(xr + c * VEC, v);
+        if (ar) {
+            float t[VEC];
+            ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) v[i] += t[i];
+        }
+        ld<T, VEC>(dyr + c * VEC, d);
+        ld<T, VEC>(gamma + c * VEC, g);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            const float dyh = d[i] * g[i];
+            s1 += dyh;
+            s2 += dyh * (v[i] - mu) * rs;
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)a.cols, m2 = wave_sum(s2) / (float)a.cols;
+    const long long doff = a.dx_map.off(row);
+    for (int c = lane; c < nchunk; c += 64) {
+        float v[VEC], d[VEC], g[VEC], o[VEC];
+        ld<T, VEC>(xr + c * VEC, v);
+        if (ar) {
+            float t[VEC];
+            ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) v[i] += t[i];
+        }
+        ld<T, VEC>(dyr + c * VEC, d);
+        ld<T, VEC>(gamma + c * VEC, g);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) o[i] = rs * (d[i] * g[i] - m1 - (v[i] - mu) * rs * m2);
+        if (dx_res) {
+            float q[VEC];
+            ld<T, VEC>(dx_res + doff + c * VEC, q);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) o[i] += q[i];
+        }
+        st<T, VEC>(dx + doff + c * VEC, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column reductions.  Block = 64 column-threads (VEC columns each) x 4 row-lanes.
+//   MODE 0: out[g][c]  = sum_{rows of group g} x[r][c]
+//   MODE 1: out0[c] = sum_r dy[r][c] * xhat[r][c],  out1[c] = sum_r dy[r][c]        (LayerNorm d gamma, d beta)
+// grid = (column blocks, groups, row splits); partial[split][group][slot][cols] fp32, reduced by col_reduce_final.
+// ------------------------------------------------------------------------------------------------
+struct ColReduceArgs {
+    int rows, cols;
+    RowMap x_map, y_map;
+    int rows_per_batch, rows_per_group, n_batch;
+    int add_rows_per_seg, add_div;
+    int rows_per_split, nsplit, ngroups;
+};
+
+template <typename T, int VEC, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const ColReduceArgs a, const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const T* __restrict__ add, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ partial) {
+    constexpr int NS = MODE == 1 ? 2 : 1;
+    __shared__ float red[4][NS][64 * VEC];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + tx) * VEC;
+    const int g = blockIdx.y, split = blockIdx.z;
+    float acc[NS][VEC];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int i = 0; i < VEC; i++) acc[s][i] = 0.f;
+    if (col < a.cols) {
+        const int n_g = a.n_batch * a.rows_per_group;
+        const int i_end = min(n_g, (split + 1) * a.rows_per_split);
+        for (int i = split * a.rows_per_split + ty; i < i_end; i += 4) {
+            const int bi = i / a.rows_per_group, j = i - bi * a.rows_per_group;
+            const int row = bi * a.rows_per_batch + g * a.rows_per_group + j;
+            if (row >= a.rows) continue;
+            float v[VEC];
+            ld<T, VEC>(x + a.x_map.off(row) + col, v);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < VEC; e++) acc[0][e] += v[e];
+            } else {
+                if (add) {
+                    float t[VEC];
+                    ld<T, VEC>(add + (long long)((row % a.add_rows_per_seg) / a.add_div) * a.cols + col, t);
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) v[e] += t[e];
+                }
+                float d[VEC];
+                ld<T, VEC>(dy + a.y_map.off(row) + col, d);
+                const float mu = mean[row], rs = rstd[row];
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    acc[0][e] += d[e] * (v[e] - mu) * rs;
+                    acc[1][e] += d[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) red[ty][s][tx * VEC + e] = acc[s][e];
+    __syncthreads();
+    if (ty == 0 && col < a.cols) {
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                const float v = red[0][s][tx * VEC + e] + red[1][s][tx * VEC + e] + red[2][s][tx * VEC + e] + red[3][s][tx * VEC + e];
+                partial[(((long long)split * a.ngroups + g) * NS + s) * a.cols + col + e] = v;
+            }
+    }
+}
+
+// out_s[g][c] = sum_split partial[split][g][s][c]
+template <typename T>
+__global__ __launch_bounds__(256) void col_reduce_final_kernel(int nsplit, int ngroups, int nslots, int cols,
+                                                               const float* __restrict__ partial, T* out0, T* out1) {
+    const long long total = (long long)ngroups * nslots * cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < nsplit; s++) v += partial[(long long)s * total + idx];
+        const int c = (int)(idx % cols);
+        const long long gs = idx / cols;
+        const int slot = (int)(gs % nslots), g = (int)(gs / nslots);
+        T* out = slot == 0 ? out0 : out1;
+        out[(long long)g * cols + c] = from_f32<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// d alpha = (1 - tanh(alpha)^2) * sum(a .* b)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void dot_partial_kernel(long long n, const T* __restrict__ a, const T* __restrict__ b,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long long nchunk = n / VEC;
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < nchunk; c += (long long)gridDim.x * 256) {
+        float u[VEC], v[VEC];
+        ld<T, VEC>(a + c * VEC, u);
+        ld<T, VEC>(b + c * VEC, v);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) s += u[i] * v[i];
+    }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gate_grad_final_kernel(int nblk, const float* __restrict__ partial, const T* alpha, T* dalpha) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) {
+        const float t = tanhf(to_f32(alpha[0]));
+        dalpha[0] = from_f32<T>(s * (1.f - t * t));
+    }
+}
+
+// text_time[b][i] = inclusive prefix sum of media_locations (gated_cross_attention.py:97)
+template <typename I> __global__ void text_time_kernel(int batch, int n, const I* __restrict__ ml, int* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    int acc = 0;
+    for (int i = 0; i < n; i++) {
+        acc += (int)ml[(long long)b * n + i];
+        out[(long long)b * n + i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static bool vec_ok(int dtype, int cols, std::initializer_list<RowMap> maps, std::initializer_list<const void*> ptrs) {
+    const int n = dtype == FF_DTYPE_BF16 ? 8 : 4;
+    if (cols % n) return false;
+    for (const RowMap& m : maps)
+        if (m.ld % n || (m.rows_per_seg > 0 && m.seg_stride % n)) return false;
+    for (const void* p : ptrs)
+        if (p && (uintptr_t)p % 16) return false;
+    return true;
+}
+
+#define FF_DISPATCH_T_VEC(dtype, vec, ...)                 \
+    do {                                                    \
+        if ((dtype) == FF_DTYPE_BF16) {                     \
+            typedef bf16 T;                                 \
+            if (vec) { constexpr int VEC = 8; __VA_ARGS__; }       \
+            else { constexpr int VEC = 1; __VA_ARGS__; }           \
+        } else {                                            \
+            typedef float T;                                \
+            if (vec) { constexpr int VEC = 4; __VA_ARGS__; }       \
+            else { constexpr int VEC = 1; __VA_ARGS__; }           \
+        }                                                   \
+    } while (0)
+
+int layernorm_fwd(const LnArgs& a, const void* x, const void* add, const void* gamma, const void* beta, void* y, float* mean,
+                  float* rstd, hipStream_t st_) {
+    FF_CHECK(a.rows > 0 && a.cols > 0 && x, FF_ERR_SHAPE, "layernorm_fwd: bad shape rows=%d cols=%d", a.rows, a.cols);
+    FF_CHECK(!a.stats_given || (mean && rstd), FF_ERR_SHAPE, "layernorm_fwd: stats_given without statistics");
+    FF_CHECK(!y || (gamma && beta), FF_ERR_SHAPE, "layernorm_fwd: gamma/beta missing");
+    FF_CHECK(!add || (a.add_rows_per_seg > 0 && a.add_div > 0), FF_ERR_SHAPE, "layernorm_fwd: addend needs add_rows_per_seg/add_div");
+    const bool v = vec_ok(a.dtype, a.cols, {a.x_map, a.y_map}, {x, add, gamma, beta, y});
+    const int grid = cdiv(a.rows, 4);
+    FF_DISPATCH_T_VEC(a.dtype, v, ln_fwd_kernel<T, VEC><<<dim3(grid), dim3(256), 0, st_>>>(a, (const T*)x, (const T*)add, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd));
+    return check_launch("ln_fwd");
+}
+
+static void split_plan(int n_rows_in_group, int col_blocks, int ngroups, int& rows_per_split, int& nsplit) {
+    int target = std::max(1, 1024 / std::max(1, col_blocks * ngroups));
+    nsplit = std::max(1, std::min(target, cdiv(n_rows_in_group, 16)));
+    rows_per_split = cdiv(n_rows_in_group, nsplit);
+    nsplit = cdiv(n_rows_in_group, rows_per_split);
+}
+
+static size_t col_reduce_ws(int n_rows_in_group, int cols, int ngroups, int nslots) {
+    // upper bound independent of the vector width: col_blocks >= 1
+    int rps, ns;
+    split_plan(n_rows_in_group, 1, ngroups, rps, ns);
+    return (size_t)ns * ngroups * nslots * cols * sizeof(float);
+}
+
+size_t layernorm_bwd_workspace(int rows, int cols) { return col_reduce_ws(rows, cols, 1, 2); }
+
+int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* add, const void* gamma, const float* mean,
+                  const float* rstd, void* dx, const void* dx_residual, void* dgamma, void* dbeta, void* ws, size_t ws_bytes,
+                  hipStream_t st_) {
+    FF_CHECK(a.rows > 0 && a.cols > 0 && dy && x && gamma && mean && rstd, FF_ERR_SHAPE, "layernorm_bwd: null/shape");
+    FF_CHECK(!add || (a.add_rows_per_seg > 0 && a.add_div > 0), FF_ERR_SHAPE, "layernorm_bwd: addend needs add_rows_per_seg/add_div");
+    const bool v = vec_ok(a.dtype, a.cols, {a.x_map, a.y_map, a.dx_map}, {x, add, gamma, dy, dx, dx_residual});
+    if (dx) {
+        const int grid = cdiv(a.rows, 4);
+        FF_DISPATCH_T_VEC(a.dtype, v, ln_bwd_dx_kernel<T, VEC><<<dim3(grid), dim3(256), 0, st_>>>(a, (const T*)dy, (const T*)x, (const T*)add, (const T*)gamma, mean, rstd, (T*)dx, (const T*)dx_residual));
+        FF_TRY(check_launch("ln_bwd_dx"));
+    }
+    if (dgamma || dbeta) {
+        FF_CHECK(dgamma && dbeta, FF_ERR_SHAPE, "layernorm_bwd: dgamma and dbeta come together");
+        const int vecn = v ? (a.dtype == FF_DTYPE_BF16 ? 8 : 4) : 1;
+        ColReduceArgs c = {};
+        c.rows = a.rows; c.cols = a.cols; c.x_map = a.x_map; c.y_map = a.y_map;
+        c.rows_per_batch = a.rows; c.rows_per_group = a.rows; c.n_batch = 1; c.ngroups = 1;
+        c.add_rows_per_seg = a.add_rows_per_seg; c.add_div = a.add_div;
+        const int col_blocks = cdiv(a.cols, 64 * vecn);
+        split_plan(a.rows, col_blocks, 1, c.rows_per_split, c.nsplit);
+        const size_t need = (size_t)c.nsplit * 2 * a.cols * sizeof(float);
+        FF_CHECK(ws && ws_bytes >= need, FF_ERR_WORKSPACE, "layernorm_bwd workspace: need %zu have %zu", need, ws_bytes);
+        FF_DISPATCH_T_VEC(a.dtype, v, col_reduce_kernel<T, VEC, 1><<<dim3(col_blocks, 1, c.nsplit), dim3(256), 0, st_>>>(c, (const T*)x, (const T*)dy, (const T*)add, mean, rstd, (float*)ws));
+        FF_TRY(check_launch("ln_bwd_param_partial"));
+        const int grid = std::min(cdiv(2LL * a.cols, 256), 1024);
+        if (a.dtype == FF_DTYPE_BF16)
+            hipLaunchKernelGGL(col_reduce_final_kernel<bf16>, dim3(grid), dim3(256), 0, st_, c.nsplit, 1, 2, a.cols, (const float*)ws, (bf16*)dgamma, (bf16*)dbeta);
+        else
+            hipLaunchKernelGGL(col_reduce_final_kernel<float>, dim3(grid), dim3(256), 0, st_, c.nsplit, 1, 2, a.cols, (const float*)ws, (float*)dgamma, (float*)dbeta);
+        FF_TRY(check_launch("ln_bwd_param_final"));
+    }
+    return FF_OK;
+}
+
+size_t rows_reduce_workspace(int rows, int cols, int rows_per_batch, int rows_per_group) {
+    if (rows_per_batch <= 0 || rows_per_group <= 0) return 0;
+    const int ngroups = cdiv(rows_per_batch, rows_per_group);
+    const int n_batch = cdiv(rows, rows_per_batch);
+    return col_reduce_ws(n_batch * rows_per_group, cols, ngroups, 1);
+}
+
+int rows_reduce(int dtype, int rows, int cols, RowMap x_map, int rows_per_batch, int rows_per_group, const void* x, void* out,
+                void* ws, size_t ws_bytes, hipStream_t st_) {
+    FF_CHECK(rows > 0 && cols > 0 && rows_per_batch > 0 && rows_per_group > 0 && x && out, FF_ERR_SHAPE, "rows_reduce: bad arguments");
+    FF_CHECK(rows % rows_per_batch == 0 && rows_per_batch % rows_per_group == 0, FF_ERR_SHAPE,
+             "rows_reduce: rows=%d rows_per_batch=%d rows_per_group=%d do not nest", rows, rows_per_batch, rows_per_group);
+    const bool v = vec_ok(dtype, cols, {x_map}, {x, out});
+    const int vecn = v ? (dtype == FF_DTYPE_BF16 ? 8 : 4) : 1;
+    ColReduceArgs c = {};
+    c.rows = rows; c.cols = cols; c.x_map = x_map; c.y_map = x_map;
+    c.rows_per_batch = rows_per_batch; c.rows_per_group = rows_per_group;
+    c.n_batch = rows / rows_per_batch; c.ngroups = rows_per_batch / rows_per_group;
+    const int col_blocks = cdiv(cols, 64 * vecn);
+    split_plan(c.n_batch * rows_per_group, col_blocks, c.ngroups, c.rows_per_split, c.nsplit);
+    const size_t need = (size_t)c.nsplit * c.ngroups * cols * sizeof(float);
+    FF_CHECK(ws && ws_bytes >= need, FF_ERR_WORKSPACE, "rows_reduce workspace: need %zu have %zu", need, ws_bytes);
+    FF_DISPATCH_T_VEC(dtype, v, col_reduce_kernel<T, VEC, 0><<<dim3(col_blocks, c.ngroups, c.nsplit), dim3(256), 0, st_>>>(c, (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)ws));
+    FF_TRY(check_launch("rows_reduce_partial"));
+    const int grid = std::min(cdiv((long long)c.ngroups * cols, 256), 1024);
+    if (dtype == FF_DTYPE_BF16)
+        hipLaunchKernelGGL(col_reduce_final_kernel<bf16>, dim3(grid), dim3(256), 0, st_, c.nsplit, c.ngroups, 1, cols, (const float*)ws, (bf16*)out, (bf16*)nullptr);
+    else
+        hipLaunchKernelGGL(col_reduce_final_kernel<float>, dim3(grid), dim3(256), 0, st_, c.nsplit, c.ngroups, 1, cols, (const float*)ws, (float*)out, (float*)nullptr);
+    return check_launch("rows_reduce_final");
+}
+
+static int gate_blocks(long long n) { return (int)std::max<long long>(1, std::min<long long>(512, n / 4096)); }
+size_t gate_grad_workspace(int rows, int cols) { return (size_t)gate_blocks((long long)rows * cols) * sizeof(float); }
+
+int gate_grad(int dtype, int rows, int cols, const void* a, const void* b, const void* alpha, void* dalpha, void* ws,
+              size_t ws_bytes, hipStream_t st_) {
+    const long long n = (long long)rows * cols;
+    FF_CHECK(n > 0 && a && b && alpha && dalpha, FF_ERR_SHAPE, "gate_grad: bad arguments");
+    const int nblk = gate_blocks(n);
+    FF_CHECK(ws && ws_bytes >= nblk * sizeof(float), FF_ERR_WORKSPACE, "gate_grad workspace too small");
+    const bool v = vec_ok(dtype, cols, {}, {a, b});
+    FF_DISPATCH_T_VEC(dtype, v, dot_partial_kernel<T, VEC><<<dim3(nblk), dim3(256), 0, st_>>>(n, (const T*)a, (const T*)b, (float*)ws));
+    FF_TRY(check_launch("gate_grad_partial"));
+    if (dtype == FF_DTYPE_BF16)
+        hipLaunchKernelGGL(gate_grad_final_kernel<bf16>, dim3(1), dim3(256), 0, st_, nblk, (const float*)ws, (const bf16*)alpha, (bf16*)dalpha);
+    else
+        hipLaunchKernelGGL(gate_grad_final_kernel<float>, dim3(1), dim3(256), 0, st_, nblk, (const float*)ws, (const float*)alpha, (float*)dalpha);
+    return check_launch("gate_grad_final");
+}
+
+int text_time(int batch, int n_tokens, const void* ml, int elem_bytes, int* out, hipStream_t st_) {
+    FF_CHECK(batch > 0 && n_tokens > 0 && ml && out, FF_ERR_SHAPE, "text_time: bad arguments");
+    const int grid = cdiv(batch, 64);
+    if (elem_bytes == 8) hipLaunchKernelGGL(text_time_kernel<long long>, dim3(grid), dim3(64), 0, st_, batch, n_tokens, (const long long*)ml, out);
+    else if (elem_bytes == 4) hipLaunchKernelGGL(text_time_kernel<int>, dim3(grid), dim3(64), 0, st_, batch, n_tokens, (const int*)ml, out);
+    else if (elem_bytes == 1) hipLaunchKernelGGL(text_time_kernel<unsigned char>, dim3(grid), dim3(64), 0, st_, batch, n_tokens, (const unsigned char*)ml, out);
+    else FF_CHECK(false, FF_ERR_UNSUPPORTED, "text_time: media_locations element size %d", elem_bytes);
+    return check_launch("text_time");
+}
+
+}  // namespace ff
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static ff::LnArgs to_args(const ff_ln_desc* d) {
+    ff::LnArgs a;
+    a.dtype = d->dtype; a.rows = d->rows; a.cols = d->cols;
+    a.x_map = ff::make_rowmap(d->x_map); a.y_map = ff::make_rowmap(d->y_map); a.dx_map = ff::make_rowmap(d->dx_map);
+    a.add_rows_per_seg = d->add_rows_per_seg; a.add_div = d->add_div;
+    a.eps = d->eps; a.stats_given = d->stats_given;
+    return a;
+}
+extern "C" int ff_layernorm_fwd(const ff_ln_desc* d, const void* x, const void* add, const void* gamma, const void* beta, void* y,
+                                float* mean, float* rstd, ff_stream_t stream) {
+    return ff::layernorm_fwd(to_args(d), x, add, gamma, beta, y, mean, rstd, (hipStream_t)stream);
+}
+extern "C" size_t ff_layernorm_bwd_workspace_bytes(const ff_ln_desc* d) { return ff::layernorm_bwd_workspace(d->rows, d->cols); }
+extern "C" int ff_layernorm_bwd(const ff_ln_desc* d, const void* dy, const void* x, const void* add, const void* gamma,
+                                const float* mean, const float* rstd, void* dx, const void* dx_residual, void* dgamma, void* dbeta,
+                                void* workspace, size_t workspace_bytes, ff_stream_t stream) {
+    return ff::layernorm_bwd(to_args(d), dy, x, add, gamma, mean, rstd, dx, dx_residual, dgamma, dbeta, workspace, workspace_bytes,
+                             (hipStream_t)stream);
+}
+extern "C" size_t ff_rows_reduce_workspace_bytes(const ff_reduce_desc* d) {
+    return ff::rows_reduce_workspace(d->rows, d->cols, d->rows_per_batch, d->rows_per_group);
+}
+extern "C" int ff_rows_reduce(const ff_reduce_desc* d, const void* x, void* out, void* workspace, size_t workspace_bytes,
+                              ff_stream_t stream) {
+    return ff::rows_reduce(d->dtype, d->rows, d->cols, ff::make_rowmap(d->x_map), d->rows_per_batch, d->rows_per_group, x, out,
+                           workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" size_t ff_gate_grad_workspace_bytes(int rows, int cols) { return ff::gate_grad_workspace(rows, cols); }
+extern "C" int ff_gate_grad(int dtype, int rows, int cols, const void* a, const void* b, const void* alpha, void* dalpha,
+                            void* workspace, size_t workspace_bytes, ff_stream_t stream) {
+    return ff::gate_grad(dtype, rows, cols, a, b, alpha, dalpha, workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int ff_text_time(int batch, int n_tokens, const void* media_locations, int elem_bytes, int* text_time, ff_stream_t stream) {
+    return ff::text_time(batch, n_tokens, media_locations, elem_bytes, text_time, (hipStream_t)stream);
+}

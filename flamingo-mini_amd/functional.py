@@ -1,0 +1,309 @@
+"""torch.autograd.Function wrappers around the C ABI (one Function per fwd/bwd pair) plus thin wrappers of the
+primitive kernels used by the parity tests.
+
+Nothing here computes: every op below is a call into libflamingo_fusion.so on the current HIP stream.
+`set_checker_backend()` exists for CPU *plumbing tests only* (tests inject the oracle there); the product never
+sets it and CPU tensors raise.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+
+from . import ffi
+
+_checker_backend = None  # tests only: object with .resampler(x_f, params, cfg) and .xattn_block(...)
+
+
+def set_checker_backend(backend) -> None:
+    """TESTS ONLY.  Route CPU tensors to a checker (the oracle) so HF plumbing can be exercised without a GPU."""
+    global _checker_backend
+    _checker_backend = backend
+
+
+def _empty_bytes(n: int, device) -> torch.Tensor:
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+def _same_dtype(ref: torch.Tensor, tensors: Sequence[torch.Tensor], what: str) -> None:
+    for t in tensors:
+        if t.dtype != ref.dtype:
+            raise ffi.FusionLibraryError(f"{what}: parameters are {t.dtype} but activations are {ref.dtype}; "
+                                         "cast the module (module.to(dtype)) — the kernels compute in one dtype")
+
+
+# ----------------------------------------------------------------------------------------------------
+# text_time
+# ----------------------------------------------------------------------------------------------------
+def text_time(media_locations: torch.Tensor) -> torch.Tensor:
+    """cumsum(media_locations, -1) as int32 (gated_cross_attention.py:97), computed once per step."""
+    if not media_locations.is_cuda:
+        if _checker_backend is not None:
+            return media_locations.to(torch.int64).cumsum(-1).to(torch.int32)
+        ffi.require_cuda(media_locations)
+    ml = media_locations
+    if ml.dtype == torch.bool:
+        ml = ml.view(torch.uint8)
+    if ml.dtype not in (torch.int64, torch.int32, torch.uint8):
+        ml = ml.to(torch.int64)
+    ml = ml.contiguous()
+    b, n = ml.shape
+    out = torch.empty((b, n), dtype=torch.int32, device=ml.device)
+    ffi.check(ffi.lib().ff_text_time(b, n, ml.data_ptr(), ml.element_size(), out.data_ptr(), ffi.stream_handle(ml.device)), "ff_text_time")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# PerceiverResampler
+# ----------------------------------------------------------------------------------------------------
+class ResamplerCfg(tuple):
+    """(depth, heads, dim_head, num_latents, num_time_embeds, ff_mult, act)"""
+    __slots__ = ()
+
+
+def _resampler_desc(x_f: torch.Tensor, cfg) -> ffi.ResamplerDesc:
+    depth, heads, dim_head, num_latents, nte, ff_mult, act = cfg
+    b, T, v, d = x_f.shape
+    return ffi.ResamplerDesc(ffi.dtype_code(x_f.dtype), b, T, v, d, depth, heads, dim_head, num_latents, nte, ff_mult, ffi.ACTS[act])
+
+
+class _ResamplerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_f: torch.Tensor, cfg, *params: torch.Tensor):
+        lib = ffi.lib()
+        x_f = x_f.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        desc = _resampler_desc(x_f, cfg)
+        dev = x_f.device
+        saved = _empty_bytes(lib.ff_resampler_saved_bytes(desc), dev)
+        scratch = _empty_bytes(lib.ff_resampler_scratch_bytes(desc), dev)
+        out = torch.empty((x_f.shape[0], cfg[3], x_f.shape[3]), dtype=x_f.dtype, device=dev)
+        ffi.check(lib.ff_resampler_fwd(desc, x_f.data_ptr(), ffi.ptr_array(params), out.data_ptr(), saved.data_ptr(), saved.numel(),
+                                       scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_resampler_fwd")
+        ctx.cfg = cfg
+        ctx.save_for_backward(x_f, saved, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        lib = ffi.lib()
+        x_f, saved, *params = ctx.saved_tensors
+        desc = _resampler_desc(x_f, ctx.cfg)
+        dev = x_f.device
+        dout = dout.contiguous()
+        grads = [torch.empty_like(p) for p in params]
+        dx_f = torch.empty_like(x_f) if ctx.needs_input_grad[0] else None
+        scratch = _empty_bytes(lib.ff_resampler_scratch_bytes(desc), dev)
+        ffi.check(lib.ff_resampler_bwd(desc, x_f.data_ptr(), ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(),
+                                       ffi.ptr_array(grads), ffi.ptr(dx_f), scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)),
+                  "ff_resampler_bwd")
+        return (dx_f, None, *grads)
+
+
+def resampler(x_f: torch.Tensor, params: Sequence[torch.Tensor], cfg) -> torch.Tensor:
+    """x_f (b, T, v, d) -> (b, num_latents, d).  `params` in the order documented in flamingo_fusion.h."""
+    if not x_f.is_cuda and _checker_backend is not None:
+        return _checker_backend.resampler(x_f, params, cfg)
+    ffi.require_cuda(x_f, *params)
+    _same_dtype(x_f, params, "PerceiverResampler")
+    assert len(params) == ffi.RESAMPLER_GLOBAL_PARAMS + ffi.RESAMPLER_LAYER_PARAMS * cfg[0]
+    return _ResamplerFn.apply(x_f, tuple(cfg), *params)
+
+
+# ----------------------------------------------------------------------------------------------------
+# GatedCrossAttentionBlock
+# ----------------------------------------------------------------------------------------------------
+def _xattn_desc(y, n_media, n_visual, dim_visual, cfg, tt, tt_offset=0, ck=None, cv=None) -> ffi.XattnDesc:
+    heads, dim_head, ff_mult, act = cfg
+    b, L, d = y.shape
+    desc = ffi.XattnDesc(ffi.dtype_code(y.dtype), b, L, d, dim_visual, n_media, n_visual, heads, dim_head, ff_mult, ffi.ACTS[act],
+                         tt.shape[1], tt_offset)
+    if ck is not None:
+        desc.cached_k = ffi.Strides(ck.stride(0), ck.stride(2), ck.stride(1))   # (b, h, n, d) tensor -> (sb, sr, sh)
+        desc.cached_v = ffi.Strides(cv.stride(0), cv.stride(2), cv.stride(1))
+    return desc
+
+
+class _XattnBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, vf, tt, cfg, n_visual, *params):
+        lib = ffi.lib()
+        y = y.contiguous()
+        vf = vf.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        desc = _xattn_desc(y, vf.shape[1], n_visual, vf.shape[3], cfg, tt)
+        dev = y.device
+        saved = _empty_bytes(lib.ff_xattn_saved_bytes(desc), dev)
+        scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
+        out = torch.empty_like(y)
+        ffi.check(lib.ff_xattn_block_fwd(desc, y.data_ptr(), vf.data_ptr(), tt.data_ptr(), ffi.ptr_array(params), None, None,
+                                         out.data_ptr(), saved.data_ptr(), saved.numel(), scratch.data_ptr(), scratch.numel(),
+                                         ffi.stream_handle(dev)), "ff_xattn_block_fwd")
+        ctx.cfg, ctx.n_visual = cfg, n_visual
+        ctx.save_for_backward(y, vf, tt, saved, *params)
+        ctx.mark_non_differentiable(saved)
+        return out, saved
+
+    @staticmethod
+    def backward(ctx, dout, _dsaved):
+        lib = ffi.lib()
+        y, vf, tt, saved, *params = ctx.saved_tensors
+        desc = _xattn_desc(y, vf.shape[1], ctx.n_visual, vf.shape[3], ctx.cfg, tt)
+        dev = y.device
+        dout = dout.contiguous()
+        grads = [torch.empty_like(p) for p in params]
+        dy = torch.empty_like(y)
+        dvf = torch.empty_like(vf) if ctx.needs_input_grad[1] else None
+        scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
+        ffi.check(lib.ff_xattn_block_bwd(desc, y.data_ptr(), vf.data_ptr(), tt.data_ptr(), ffi.ptr_array(params), dout.data_ptr(),
+                                         saved.data_ptr(), saved.numel(), ffi.ptr_array(grads), dy.data_ptr(), ffi.ptr(dvf),
+                                         scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_bwd")
+        return (dy, dvf, None, None, None, *grads)
+
+
+def _kv_views(saved: torch.Tensor, y: torch.Tensor, n_kv: int, heads: int, dim_head: int):
+    """K / V as (b, h, n_kv, dim_head) views of the library's (b, n_kv, 2, h, dim_head) buffer (no copy)."""
+    b = y.shape[0]
+    n = b * n_kv * 2 * heads * dim_head
+    kv = saved[: n * y.element_size()].view(y.dtype).view(b, n_kv, 2, heads, dim_head)
+    return kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
+
+
+def xattn_block(y: torch.Tensor, visual_features: Optional[torch.Tensor], tt: torch.Tensor, params: Sequence[torch.Tensor], cfg,
+                n_visual: int, previous_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, output_kv: bool = False):
+    """GatedCrossAttentionBlock forward.  cfg = (heads, dim_head, ff_mult, act); tt = text_time int32 (b, L_total).
+    Returns (y_out, (k, v) or None)."""
+    if not y.is_cuda and _checker_backend is not None:
+        return _checker_backend.xattn_block(y, visual_features, tt, params, cfg, n_visual, previous_kv, output_kv)
+    ffi.require_cuda(y, tt, *params)
+    _same_dtype(y, params, "GatedCrossAttentionBlock")
+    heads, dim_head = cfg[0], cfg[1]
+    if previous_kv is None:
+        ffi.require_cuda(visual_features)
+        if visual_features.dtype != y.dtype:
+            visual_features = visual_features.to(y.dtype)
+        out, saved = _XattnBlockFn.apply(y, visual_features, tt, tuple(cfg), n_visual, *params)
+        kv = _kv_views(saved, y, visual_features.shape[1] * n_visual, heads, dim_head) if output_kv else None
+        return out, kv
+    # cached decode (gated_cross_attention.py:88-92,102-104): inference only, K/V reused, last n_token rows of text_time
+    lib = ffi.lib()
+    k, v = previous_kv
+    if k.dtype != y.dtype:
+        k, v = k.to(y.dtype), v.to(y.dtype)
+    if k.stride(3) != 1 or v.stride(3) != 1:
+        k, v = k.contiguous(), v.contiguous()
+    y = y.contiguous()
+    n_kv = k.shape[2]
+    L = y.shape[1]
+    desc = _xattn_desc(y, n_kv // n_visual, n_visual, params[5].shape[1], cfg, tt, tt_offset=tt.shape[1] - L, ck=k, cv=v)
+    dev = y.device
+    saved = _empty_bytes(lib.ff_xattn_saved_bytes(desc), dev)
+    scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
+    out = torch.empty_like(y)
+    with torch.no_grad():
+        ffi.check(lib.ff_xattn_block_fwd(desc, y.data_ptr(), None, tt.data_ptr(), ffi.ptr_array([p.contiguous() for p in params]),
+                                         k.data_ptr(), v.data_ptr(), out.data_ptr(), saved.data_ptr(), saved.numel(),
+                                         scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_fwd(cached)")
+    return out, ((k, v) if output_kv else None)
+
+
+# ----------------------------------------------------------------------------------------------------
+# primitive wrappers (parity tests / micro-benchmarks): thin, allocation + one C call each
+# ----------------------------------------------------------------------------------------------------
+def gemm(A, B, *, a_layout=0, b_layout=0, scale=1.0, act=None, act_bwd=None, aux_in=None, residual=None, gate=None,
+         want_aux_out=False, split_k=0):
+    lib = ffi.lib()
+    ffi.require_cuda(A, B)
+    M, K = (A.shape if a_layout == 0 else A.shape[::-1])
+    N = B.shape[0] if b_layout == 0 else B.shape[1]
+    C_ = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    aux_out = torch.empty_like(C_) if want_aux_out else None
+    d = ffi.GemmDesc(ffi.dtype_code(A.dtype), M, N, K, a_layout, b_layout, ffi.rowmap(A.stride(0)), ffi.rowmap(B.stride(0)),
+                     ffi.rowmap(N), float(scale), ffi.ACTS.get(act, ffi.ACT_NONE), ffi.ACTS.get(act_bwd, ffi.ACT_NONE), split_k)
+    ws = _empty_bytes(lib.ff_gemm_workspace_bytes(d), A.device)
+    ffi.check(lib.ff_gemm(d, A.data_ptr(), B.data_ptr(), C_.data_ptr(), ffi.ptr(aux_out), ffi.ptr(aux_in), ffi.ptr(residual), ffi.ptr(gate),
+                          ws.data_ptr(), ws.numel(), ffi.stream_handle(A.device)), "ff_gemm")
+    return (C_, aux_out) if want_aux_out else C_
+
+
+def layernorm_fwd(x, gamma, beta, add=None, add_rows_per_seg=0, add_div=0, eps=1e-5):
+    lib = ffi.lib()
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    d = ffi.LnDesc(ffi.dtype_code(x.dtype), rows, cols, ffi.rowmap(cols), ffi.rowmap(cols), ffi.rowmap(cols), add_rows_per_seg, add_div, eps, 0)
+    ffi.check(lib.ff_layernorm_fwd(d, x.data_ptr(), ffi.ptr(add), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                   rstd.data_ptr(), ffi.stream_handle(x.device)), "ff_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, add_rows_per_seg=0, add_div=0, dx_residual=None, eps=1e-5):
+    lib = ffi.lib()
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+    d = ffi.LnDesc(ffi.dtype_code(x.dtype), rows, cols, ffi.rowmap(cols), ffi.rowmap(cols), ffi.rowmap(cols), add_rows_per_seg, add_div, eps, 1)
+    ws = _empty_bytes(lib.ff_layernorm_bwd_workspace_bytes(d), x.device)
+    ffi.check(lib.ff_layernorm_bwd(d, dy.data_ptr(), x.data_ptr(), ffi.ptr(add), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                   dx.data_ptr(), ffi.ptr(dx_residual), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   ffi.stream_handle(x.device)), "ff_layernorm_bwd")
+    return dx, dg, db
+
+
+def rows_reduce(x, rows_per_batch, rows_per_group):
+    lib = ffi.lib()
+    rows, cols = x.shape
+    out = torch.empty((rows_per_batch // rows_per_group, cols), dtype=x.dtype, device=x.device)
+    d = ffi.ReduceDesc(ffi.dtype_code(x.dtype), rows, cols, ffi.rowmap(cols), rows_per_batch, rows_per_group)
+    ws = _empty_bytes(lib.ff_rows_reduce_workspace_bytes(d), x.device)
+    ffi.check(lib.ff_rows_reduce(d, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), ffi.stream_handle(x.device)), "ff_rows_reduce")
+    return out
+
+
+def gate_grad(a, b, alpha):
+    lib = ffi.lib()
+    rows, cols = a.shape
+    out = torch.empty_like(alpha)
+    ws = _empty_bytes(lib.ff_gate_grad_workspace_bytes(rows, cols), a.device)
+    ffi.check(lib.ff_gate_grad(ffi.dtype_code(a.dtype), rows, cols, a.data_ptr(), b.data_ptr(), alpha.data_ptr(), out.data_ptr(),
+                               ws.data_ptr(), ws.numel(), ffi.stream_handle(a.device)), "ff_gate_grad")
+    return out
+
+
+def _bnhd_strides(t):  # (b, n, h, d) tensor -> (sb, sr, sh)
+    return ffi.Strides(t.stride(0), t.stride(1), t.stride(2))
+
+
+def _attn_desc(q, k, mode, n_visual, tt):
+    b, nq, h, dh = q.shape
+    d = ffi.AttnDesc(ffi.dtype_code(q.dtype), b, h, dh, nq, k.shape[1], mode, n_visual, 0 if tt is None else tt.shape[1], 0)
+    return d
+
+
+def attention_fwd(q, k, v, tt=None, n_visual=0):
+    """q (b, nq, h, d), k/v (b, nkv, h, d) -> o (b, nq, h, d), lse (b, h, nq).  tt=None: dense."""
+    lib = ffi.lib()
+    mode = ffi.ATTN_DENSE if tt is None else ffi.ATTN_MEDIA
+    d = _attn_desc(q, k, mode, n_visual, tt)
+    o = torch.empty_like(q)
+    lse = torch.empty((q.shape[0], q.shape[2], q.shape[1]), dtype=torch.float32, device=q.device)
+    d.q, d.k, d.v, d.o = _bnhd_strides(q), _bnhd_strides(k), _bnhd_strides(v), _bnhd_strides(o)
+    ffi.check(lib.ff_attention_fwd(d, q.data_ptr(), k.data_ptr(), v.data_ptr(), ffi.ptr(tt), o.data_ptr(), lse.data_ptr(),
+                                   ffi.stream_handle(q.device)), "ff_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, tt=None, n_visual=0):
+    lib = ffi.lib()
+    mode = ffi.ATTN_DENSE if tt is None else ffi.ATTN_MEDIA
+    d = _attn_desc(q, k, mode, n_visual, tt)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    d.q, d.k, d.v, d.o = _bnhd_strides(q), _bnhd_strides(k), _bnhd_strides(v), _bnhd_strides(o)
+    d.dq, d.dk, d.dv, d.dout = _bnhd_strides(dq), _bnhd_strides(dk), _bnhd_strides(dv), _bnhd_strides(do)
+    ws = _empty_bytes(lib.ff_attention_bwd_workspace_bytes(d), q.device)
+    ffi.check(lib.ff_attention_bwd(d, q.data_ptr(), k.data_ptr(), v.data_ptr(), ffi.ptr(tt), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                   dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), ws.numel(), ffi.stream_handle(q.device)),
+              "ff_attention_bwd")
+    return dq, dk, dv

@@ -1,0 +1,356 @@
+"""FlamingoModel drop-in (reference: flamingo_mini/modeling_flamingo.py).
+
+Same public surface — FlamingoBaseModel / FlamingoGPT2 / FlamingoOPT / FlamingoModel, forward() arguments, freeze_*,
+parameters_trainable(), state_dict_trainable(), prepare_inputs_for_generation(), generate_captions(),
+score_sequences() — and the same parameter names, so `state_dict_trainable()` checkpoints interchange.
+The frozen CLIP and GPT-2 / OPT backbones stay stock Hugging Face modules on PyTorch-ROCm; the perceiver
+resampler and the gated cross-attention blocks hooked into the LM layer loop run in libflamingo_fusion.
+"""
+from __future__ import annotations
+
+import contextlib
+import logging
+from abc import ABC, abstractmethod
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+from transformers import PreTrainedModel
+from transformers.modeling_outputs import CausalLMOutputWithPast
+
+from . import functional as F
+from .backbones import load_language_model, load_vision_encoder
+from .configuration_flamingo import FlamingoConfig
+from .gated_cross_attention import ModifiedLMBlock
+from .perceiver_resampler import PerceiverResampler
+from .utils import get_common_prefix_length
+
+
+@contextlib.contextmanager
+def suppress_model_loading_warnings(suppress: bool = True):
+    logger = logging.getLogger("transformers.modeling_utils")
+    level = logger.level
+    if suppress:
+        logger.setLevel(logging.CRITICAL)
+    try:
+        yield
+    finally:
+        logger.setLevel(level)
+
+
+def _repeat_leading(t: torch.Tensor, m: int) -> torch.Tensor:
+    """'n ... -> (n m) ...' (each row repeated m times, as beam search does with input_ids)."""
+    return t.repeat_interleave(m, dim=0)
+
+
+class FlamingoBaseModel(ABC, PreTrainedModel):
+    """CLIP -> PerceiverResampler -> LM whose layers were wrapped by ModifiedLMBlock (reference :43-306)."""
+
+    config_class = FlamingoConfig
+    _supports_sdpa = True
+
+    def __init__(self, config: FlamingoConfig, suppress_warnings: bool = True):
+        assert isinstance(config, FlamingoConfig)
+        super().__init__(config)
+        with suppress_model_loading_warnings(suppress_warnings):
+            self.vision_encoder = load_vision_encoder(config)
+        self.resampler = PerceiverResampler(
+            dim=config.dim_visual, depth=config.resampler_depth, dim_head=config.resampler_dim_head,
+            heads=config.resampler_heads, num_latents=config.resampler_num_latents,
+            num_time_embeds=config.resampler_num_time_embeds, ff_mult=config.resampler_ff_mult, act=config.resampler_act)
+
+    def _init_weights(self, module):  # backbones initialise themselves; fusion modules use torch defaults like the reference
+        pass
+
+    def _init_layers(self, lm_layers: nn.ModuleList):
+        """Wrap every `xattn_every`-th LM layer in place (reference :76-94)."""
+        c = self.config
+        for i in range(0, len(lm_layers), c.xattn_every):
+            lm_layers[i] = ModifiedLMBlock(
+                lm_layers[i], dim=c.dim, dim_visual=c.dim_visual, dim_head=c.xattn_dim_head, heads=c.xattn_heads,
+                ff_mult=c.xattn_ff_mult, act=c.xattn_act, n_visual=c.resampler_num_latents)
+
+    @abstractmethod
+    def get_modified_layers(self) -> List[ModifiedLMBlock]:
+        raise NotImplementedError
+
+    # ---- freezing / trainable views (reference :100-138) ----
+    def freeze_vm(self):
+        self.vision_encoder.requires_grad_(False)
+
+    def freeze_lm(self):
+        """Freeze the LM except the (tied) token embedding and the gated xattn blocks."""
+        self.lm.requires_grad_(False)
+        self.lm.get_input_embeddings().weight.requires_grad = True
+        for hook in self.get_modified_layers():
+            hook.xattn_block.requires_grad_(True)
+
+    def unfreeze_lm(self):
+        self.lm.requires_grad_(True)
+
+    def state_dict_trainable(self) -> Dict[str, torch.Tensor]:
+        names = {n for n, p in self.named_parameters() if p.requires_grad}
+        return {k: v for k, v in self.state_dict().items() if k in names}
+
+    def parameters_trainable(self):
+        return (p for p in self.parameters() if p.requires_grad)
+
+    # ---- vision side (reference :140-181) ----
+    def encode_resample_visuals(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """(N c h w) | (b N c h w) | (b N T c h w)  ->  (b N q d)."""
+        if pixel_values.ndim == 4:
+            b, N, T = 1, pixel_values.size(0), 1
+        elif pixel_values.ndim == 5:
+            b, N, T = pixel_values.size(0), pixel_values.size(1), 1
+        elif pixel_values.ndim == 6:
+            b, N, T = pixel_values.shape[:3]
+        else:
+            raise ValueError("pixel_values must have ndim 5 or 6!")
+        frames = pixel_values.reshape(b * N * T, *pixel_values.shape[-3:])
+        with torch.no_grad():
+            feats = self.vision_encoder(frames).last_hidden_state                  # ((b N T), v, d), frozen
+        feats = feats.reshape(b * N, T, feats.shape[-2], feats.shape[-1])          # frames go to the KV axis inside the resampler
+        latents = self.resampler(feats)                                            # ((b N), q, d)
+        return latents.reshape(b, N, latents.shape[-2], latents.shape[-1])
+
+    # ---- forward (reference :183-306) ----
+    def forward(self, input_ids=None, attention_mask=None, media_locations=None, pixel_values=None, visual_features=None,
+                head_mask=None, inputs_embeds=None, use_cache: bool = False, past_key_values=None, return_dict: bool = True,
+                labels=None, loss_reduction: str = "mean", **kwargs) -> CausalLMOutputWithPast:
+        assert return_dict, "can only use return_dict=True at the moment!"
+        assert (input_ids is None) != (inputs_embeds is None), "you must pass either input_ids or inputs_embeds!"
+        ref = input_ids if input_ids is not None else inputs_embeds
+        batch_size, seq_length = ref.shape[:2]
+        device = ref.device
+        xattn_past = None if past_key_values is None else past_key_values[0]
+        lm_past = None if past_key_values is None else past_key_values[1]
+
+        if visual_features is None:
+            if xattn_past is None and pixel_values is not None:
+                assert pixel_values.size(0) == batch_size, "pixel_values must have the same batch size as the textual input!"
+                visual_features = self.encode_resample_visuals(pixel_values)
+            else:  # cached K/V make the features irrelevant; only the shape is used
+                visual_features = torch.zeros((batch_size, 1, self.config.resampler_num_latents, self.config.dim_visual),
+                                              dtype=self.resampler.latents.dtype, device=device)
+        if media_locations is None:
+            media_locations = torch.zeros((batch_size, seq_length), dtype=torch.int, device=device)
+
+        text_time = F.text_time(media_locations)       # once per step, shared by every block (the reference recomputes it per layer)
+        for i, hook in enumerate(self.get_modified_layers()):
+            hook.condition(visual_features, media_locations, None if xattn_past is None else xattn_past[i], text_time=text_time)
+
+        lm_kwargs = dict(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds, use_cache=use_cache,
+                         past_key_values=lm_past, return_dict=True, **kwargs)
+        if head_mask is not None:
+            lm_kwargs["head_mask"] = head_mask
+        out = self.lm(**lm_kwargs)
+        logits = self.lm_head(out.last_hidden_state)
+
+        new_xattn_past = [hook.kv_output for hook in self.get_modified_layers()] if use_cache else None
+
+        loss = None
+        if labels is not None:   # tokens < n predict n
+            shift_logits = logits[..., :-1, :].contiguous()
+            shift_labels = labels[..., 1:].contiguous()
+            loss = TF.cross_entropy(shift_logits.view(-1, shift_logits.size(-1)).float(), shift_labels.view(-1), reduction=loss_reduction)
+
+        return CausalLMOutputWithPast(
+            loss=loss, logits=logits,
+            past_key_values=(tuple(new_xattn_past), out.past_key_values) if use_cache else None,
+            hidden_states=getattr(out, "hidden_states", None), attentions=getattr(out, "attentions", None))
+
+
+class FlamingoGPT2(FlamingoBaseModel):
+    def __init__(self, config: FlamingoConfig):
+        assert config.lm.startswith("gpt")
+        super().__init__(config)
+        base_lm = load_language_model(config)
+        assert config.dim == base_lm.config.n_embd, \
+            f"specified {config.dim=} in FlamingoConfig, but {config.lm} has hidden size={base_lm.config.n_embd}"
+        base_lm.resize_token_embeddings(base_lm.config.vocab_size + 1)      # one extra row for <EOC>
+        self.lm = base_lm.transformer
+        self.lm_head = base_lm.lm_head
+        self._init_layers(self.lm.h)
+
+    def get_modified_layers(self):
+        return [layer for layer in self.lm.h if isinstance(layer, ModifiedLMBlock)]
+
+
+class FlamingoOPT(FlamingoBaseModel):
+    def __init__(self, config: FlamingoConfig):
+        assert config.lm.startswith("facebook/opt")
+        super().__init__(config)
+        base_lm = load_language_model(config)
+        assert config.dim == base_lm.config.hidden_size, \
+            f"specified {config.dim=} in FlamingoConfig, but {config.lm} has hidden size={base_lm.config.hidden_size}"
+        base_lm.resize_token_embeddings(base_lm.config.vocab_size + 1)
+        self.lm = base_lm.model
+        self.lm_head = base_lm.lm_head
+        self._init_layers(self.lm.decoder.layers)
+
+    def get_modified_layers(self):
+        return [layer for layer in self.lm.decoder.layers if isinstance(layer, ModifiedLMBlock)]
+
+
+class FlamingoModel(PreTrainedModel):
+    """LM-independent wrapper (reference :359-712)."""
+
+    config_class = FlamingoConfig
+    _LANGUAGE_MODEL_VERSIONS = {"gpt2": FlamingoGPT2, "facebook/opt": FlamingoOPT}
+    _keys_to_ignore_on_load_missing = [r"flamingo.vision_encoder"]
+
+    def __init__(self, config: FlamingoConfig, model_class: Optional[type] = None):
+        super().__init__(config)
+        if model_class is None:
+            model_class = self._find_flamingo_class(config.lm)
+        self.flamingo: FlamingoBaseModel = model_class(config)
+        if config.freeze_language_model:
+            self.freeze_lm()
+        if config.freeze_vision_model:
+            self.freeze_vm()
+
+    def _init_weights(self, module):
+        pass
+
+    @classmethod
+    def is_lm_supported(cls, lm_id: str) -> bool:
+        return any(lm_id.startswith(prefix) for prefix in cls._LANGUAGE_MODEL_VERSIONS)
+
+    @classmethod
+    def _find_flamingo_class(cls, language_model_id: str):
+        for prefix, flamingo_class in cls._LANGUAGE_MODEL_VERSIONS.items():
+            if language_model_id.startswith(prefix):
+                return flamingo_class
+        raise ValueError(f"unsupported language model {language_model_id}")
+
+    def parameters_trainable(self):
+        return self.flamingo.parameters_trainable()
+
+    def freeze_vm(self):
+        self.flamingo.freeze_vm()
+
+    def freeze_lm(self):
+        self.flamingo.freeze_lm()
+
+    def unfreeze_lm(self):
+        self.flamingo.unfreeze_lm()
+
+    def state_dict_trainable(self):
+        return self.flamingo.state_dict_trainable()
+
+    def forward(self, input_ids=None, attention_mask=None, media_locations=None, pixel_values=None, visual_features=None,
+                head_mask=None, inputs_embeds=None, use_cache: bool = False, past_key_values=None, return_dict: bool = True,
+                labels=None, loss_reduction: str = "mean", **kwargs) -> CausalLMOutputWithPast:
+        return self.flamingo(input_ids=input_ids, attention_mask=attention_mask, media_locations=media_locations,
+                             pixel_values=pixel_values, visual_features=visual_features, head_mask=head_mask,
+                             inputs_embeds=inputs_embeds, use_cache=use_cache, past_key_values=past_key_values,
+                             return_dict=return_dict, labels=labels, loss_reduction=loss_reduction, **kwargs)
+
+    # ---- generation helpers (reference :464-605) ----
+    def prepare_inputs_for_generation(self, input_ids, media_locations=None, attention_mask=None, pixel_values=None,
+                                      visual_features=None, past=None, past_key_values=None, **kwargs) -> Dict[str, Any]:
+        """Replicate visuals / media_locations to the beam-expanded batch; with a cache only the last token is fed."""
+        n_inputs = input_ids.shape[0]
+
+        def expand(t):
+            if t is None or t.shape[0] == n_inputs:
+                return t
+            assert n_inputs % t.shape[0] == 0
+            return _repeat_leading(t, n_inputs // t.shape[0])
+
+        cache = past_key_values if past_key_values is not None else past
+        if cache is not None:
+            input_ids = input_ids[:, -1:]
+        return dict(input_ids=input_ids, past_key_values=cache, media_locations=expand(media_locations),
+                    attention_mask=attention_mask, pixel_values=expand(pixel_values), visual_features=expand(visual_features), **kwargs)
+
+    def _reorder_cache(self, past, beam_idx):
+        xattn_past, lm_past = past
+        pick = lambda t: t.index_select(0, beam_idx.to(t.device))
+        xattn_new = tuple(tuple(pick(t) for t in layer) for layer in xattn_past)
+        if hasattr(lm_past, "reorder_cache"):      # transformers >= 4.36 Cache objects
+            lm_past.reorder_cache(beam_idx)
+            lm_new = lm_past
+        else:
+            lm_new = tuple(tuple(pick(t) for t in layer) for layer in lm_past)
+        return xattn_new, lm_new
+
+    @torch.no_grad()
+    def greedy_generate(self, input_ids, media_locations, attention_mask, pixel_values=None, visual_features=None,
+                        max_length: int = 150, eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None):
+        """Cached greedy decoding: the first step runs CLIP + resampler and fills the xattn / LM caches, later steps feed
+        one token and reuse the cross-attention K/V (the caption tokens/sec path)."""
+        ids, ml, am = input_ids, media_locations, attention_mask
+        finished = torch.zeros(ids.shape[0], dtype=torch.bool, device=ids.device)
+        past = None
+        step_ids = ids
+        while ids.shape[1] < max_length:
+            out = self.flamingo(input_ids=step_ids, attention_mask=am, media_locations=ml, use_cache=True, past_key_values=past,
+                                pixel_values=pixel_values if past is None else None,
+                                visual_features=visual_features if past is None else None)
+            past = out.past_key_values
+            nxt = out.logits[:, -1].argmax(-1)
+            if eos_token_id is not None:
+                nxt = torch.where(finished, torch.full_like(nxt, pad_token_id if pad_token_id is not None else eos_token_id), nxt)
+                finished = finished | (nxt == eos_token_id)
+            ids = torch.cat([ids, nxt[:, None]], dim=1)
+            ml = torch.cat([ml, torch.zeros_like(ml[:, :1])], dim=1)
+            am = torch.cat([am, torch.ones_like(am[:, :1])], dim=1)
+            step_ids = ids[:, -1:]
+            if eos_token_id is not None and bool(finished.all()):
+                break
+        return ids
+
+    @torch.no_grad()
+    def generate_captions(self, processor, pixel_values=None, images=None, prompt: str = "<image>", max_length: int = 150,
+                          num_beams: int = 1, device=None, **kwargs):
+        """Caption a batch of images; the prompt is replicated for every image."""
+        if device is None:
+            device = self.device
+        if images is not None:
+            assert pixel_values is None, "you can only pass either images or visual features to generate_captions()!"
+            if not isinstance(images, (list, tuple)):
+                images = [images]
+            pixel_values = processor(images=images, device=device)["pixel_values"]
+        assert pixel_values is not None, "you must pass either images or visual features to generate_captions()!"
+        batch_size = pixel_values.size(0)
+        input_ids, media_locations, attention_mask = processor.encode_text(prompt, device)
+        input_ids = input_ids[:1].expand(batch_size, -1).contiguous()
+        media_locations = media_locations[:1].expand(batch_size, -1).contiguous()
+        attention_mask = attention_mask[:1].expand(batch_size, -1).contiguous()
+        if num_beams != 1:
+            raise NotImplementedError("beam search needs transformers' GenerationMixin; this build decodes greedily")
+        lm_cfg = self.flamingo.lm.config
+        if pixel_values.ndim == 4:
+            pixel_values = pixel_values[:, None]       # (b c h w) -> one image per sequence
+        out_ids = self.greedy_generate(input_ids, media_locations, attention_mask, pixel_values=pixel_values, max_length=max_length,
+                                       eos_token_id=lm_cfg.eos_token_id, pad_token_id=lm_cfg.eos_token_id)
+        captions = processor.tokenizer.batch_decode(out_ids, skip_special_tokens=True)
+        return [processor.remove_tags(t) for t in captions]
+
+    @torch.no_grad()
+    def score_sequences(self, input_ids, media_locations, attention_mask, pixel_values=None, visual_features=None,
+                        k: int = 100000) -> torch.Tensor:
+        """EXPERIMENTAL zero-shot scoring (reference :607-712): log-prob of each candidate sequence given the same
+        visuals.  The shared prefix is run once with use_cache; its cross-attention K/V are reused for the candidates
+        (the LM self-attention prefix is recomputed: HF Cache objects are not sliceable per candidate)."""
+        assert visual_features is None or visual_features.ndim == 3
+        n_choices = input_ids.size(0)
+        n_reuse = get_common_prefix_length(input_ids)
+        k = min(k, n_choices)
+        out = self.flamingo(input_ids=input_ids[:1, :n_reuse], media_locations=media_locations[:1, :n_reuse],
+                            attention_mask=attention_mask[:1, :n_reuse],
+                            pixel_values=pixel_values.unsqueeze(0) if pixel_values is not None else None,
+                            visual_features=visual_features.unsqueeze(0) if visual_features is not None else None, use_cache=True)
+        next_tokens = input_ids[:, n_reuse]
+        topk = out.logits[0, -1, :].index_select(0, next_tokens).topk(k).indices
+        xattn_past = [tuple(t.expand(k, *t.shape[1:]) for t in kv) for kv in out.past_key_values[0]]
+        out2 = self.flamingo(input_ids=input_ids[topk], media_locations=media_locations[topk], attention_mask=attention_mask[topk],
+                             past_key_values=(xattn_past, None))
+        logp = out2.logits[:, n_reuse - 1:-1].float().log_softmax(-1)
+        tgt = input_ids[topk][:, n_reuse:]
+        tok = logp.gather(-1, tgt[..., None])[..., 0] * attention_mask[topk][:, n_reuse:]
+        scores = torch.full([n_choices], torch.finfo(torch.float).min, device=tok.device)
+        scores[topk] = tok.sum(1)
+        return scores.detach()

@@ -1,0 +1,210 @@
+/*
+ * libflamingo_fusion — C ABI of the MI355X (gfx950) Flamingo fusion path.
+ *
+ * This is the drop-in boundary below the Python modules: every entry point takes plain device pointers,
+ * sizes and a HIP stream; no torch / C++ types; kernels are enqueued on the caller's stream and never
+ * synchronise or allocate.  All tensors are caller-owned, 16-byte aligned, innermost dimension contiguous.
+ * Return value: FF_OK or a negative error code; ff_last_error() gives a thread-local message.
+ *
+ * What each entry point replaces in the reference (dhansmair/flamingo-mini, paths relative to its root):
+ *   ff_resampler_fwd/bwd     PerceiverResampler.forward + its autograd   flamingo_mini/perceiver_resampler.py:143-188
+ *                            (PerceiverAttentionLayer.forward :32-96, FeedForward flamingo_mini/utils.py:22-50)
+ *   ff_xattn_block_fwd/bwd   GatedCrossAttentionBlock.forward + autograd  flamingo_mini/gated_cross_attention.py:160-184
+ *                            (MaskedCrossAttention.forward :42-131, cached K/V path :88-92,102-104)
+ *   ff_text_time             media_locations.cumsum(dim=-1)               flamingo_mini/gated_cross_attention.py:97
+ * The primitive entry points (ff_gemm, ff_layernorm_*, ff_attention_*, ff_rows_reduce, ff_gate_grad) are the
+ * kernels those are built from; they are exported so each can be parity-tested on its own.
+ */
+#ifndef FLAMINGO_FUSION_H
+#define FLAMINGO_FUSION_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ff_stream_t; /* == hipStream_t */
+
+enum { FF_OK = 0, FF_ERR_SHAPE = -1, FF_ERR_UNSUPPORTED = -2, FF_ERR_WORKSPACE = -3, FF_ERR_LAUNCH = -4 };
+enum { FF_DTYPE_F32 = 0, FF_DTYPE_BF16 = 1 };
+enum { FF_ACT_NONE = -1, FF_ACT_GELU = 0, FF_ACT_SQRELU = 1, FF_ACT_RELU = 2 }; /* utils.py:26-30 */
+
+int ff_version(void);          /* ABI version, bumped on any signature change */
+const char* ff_arch(void);     /* "gfx950" */
+const char* ff_last_error(void);
+
+/* Row addressing shared by the row-wise kernels and the GEMM operands:
+ * logical row r lives at  base + (r / rows_per_seg) * seg_stride + (r % rows_per_seg) * ld   (elements).
+ * rows_per_seg <= 0: plain row-major with leading dimension ld.  seg_stride == 0 broadcasts one segment. */
+typedef struct ff_rowmap {
+    long long ld;
+    long long seg_stride;
+    int rows_per_seg;
+    int reserved;
+} ff_rowmap;
+
+/* ------------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:   v = scale * sum_k A[m,k] * B[k,n]
+ *                             aux_out[m,n] = v                      (if aux_out)
+ *                             v *= tanh(*gate)                      (if gate: device scalar of `dtype`)
+ *                             v  = act(v)                           (if act >= 0)
+ *                             v *= act'(aux_in[m,n])                (if act_bwd >= 0)
+ *                             C[m,n] = v + residual[m,n]            (residual optional)
+ * a_layout 0: A stored [M][K] (nn.Linear input);  1: A stored [K][M] (used for weight gradients, A = dY^T)
+ * b_layout 0: B stored [N][K] (nn.Linear weight (out,in));  1: B stored [K][N]
+ * a_map/b_map address the STORED rows (M or K rows of A; N or K rows of B); c_map addresses C, aux_*, residual.
+ * split_k > 1 needs workspace of ff_gemm_workspace_bytes().
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct ff_gemm_desc {
+    int dtype;
+    int M, N, K;
+    int a_layout, b_layout;
+    ff_rowmap a_map, b_map, c_map;
+    float scale;
+    int act;      /* FF_ACT_* or FF_ACT_NONE */
+    int act_bwd;  /* FF_ACT_* or FF_ACT_NONE */
+    int split_k;  /* 0 = choose automatically */
+} ff_gemm_desc;
+
+size_t ff_gemm_workspace_bytes(const ff_gemm_desc* d);
+int ff_gemm(const ff_gemm_desc* d, const void* A, const void* B, void* C, void* aux_out, const void* aux_in,
+            const void* residual, const void* gate, void* workspace, size_t workspace_bytes, ff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last axis (eps inside the sqrt, biased variance: torch.nn.LayerNorm).
+ * Optional broadcast addend fused in front: x[r] += add[((r % add_rows_per_seg) / add_div)]  — the
+ * time_pos_emb add of perceiver_resampler.py:166.
+ * fwd: stats_given != 0 reuses mean/rstd instead of recomputing; y == NULL computes the statistics only.
+ * bwd: dx = dx_residual + LN'(dy) (dx_residual optional, may alias dx); dgamma/dbeta are written, not accumulated.
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct ff_ln_desc {
+    int dtype;
+    int rows, cols;
+    ff_rowmap x_map;  /* x (fwd, bwd) */
+    ff_rowmap y_map;  /* y (fwd) / dy (bwd) */
+    ff_rowmap dx_map; /* dx and dx_residual (bwd) */
+    int add_rows_per_seg, add_div;
+    float eps;
+    int stats_given;
+} ff_ln_desc;
+
+int ff_layernorm_fwd(const ff_ln_desc* d, const void* x, const void* add, const void* gamma, const void* beta,
+                     void* y, float* mean, float* rstd, ff_stream_t stream);
+size_t ff_layernorm_bwd_workspace_bytes(const ff_ln_desc* d);
+int ff_layernorm_bwd(const ff_ln_desc* d, const void* dy, const void* x, const void* add, const void* gamma,
+                     const float* mean, const float* rstd, void* dx, const void* dx_residual, void* dgamma,
+                     void* dbeta, void* workspace, size_t workspace_bytes, ff_stream_t stream);
+
+/* out[g][c] = sum over rows r with group(r) == g of x[r][c],  group(r) = (r % rows_per_batch) / rows_per_group.
+ * (d latents: rows_per_batch = q, rows_per_group = 1;  d time_pos_emb: rows_per_batch = T*v, rows_per_group = v) */
+typedef struct ff_reduce_desc {
+    int dtype;
+    int rows, cols;
+    ff_rowmap x_map;
+    int rows_per_batch, rows_per_group;
+} ff_reduce_desc;
+size_t ff_rows_reduce_workspace_bytes(const ff_reduce_desc* d);
+int ff_rows_reduce(const ff_reduce_desc* d, const void* x, void* out, void* workspace, size_t workspace_bytes,
+                   ff_stream_t stream);
+
+/* d alpha = (1 - tanh(alpha)^2) * sum(a .* b) over rows x cols  (gated_cross_attention.py:180,182 backward) */
+size_t ff_gate_grad_workspace_bytes(int rows, int cols);
+int ff_gate_grad(int dtype, int rows, int cols, const void* a, const void* b, const void* alpha, void* dalpha,
+                 void* workspace, size_t workspace_bytes, ff_stream_t stream);
+
+/* text_time[b][i] = sum_{j<=i} media_locations[b][j]   (media_locations: int64 / int32 / uint8(bool)) */
+int ff_text_time(int batch, int n_tokens, const void* media_locations, int elem_bytes, int* text_time,
+                 ff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Attention core  O = softmax(Q K^T) V  over row ranges, never materialising the score matrix.
+ *   mode FF_ATTN_DENSE : every query attends to all n_kv keys (resampler, perceiver_resampler.py:85-92)
+ *   mode FF_ATTN_MEDIA : query i attends to the n_visual keys of image text_time[b][i]
+ *                        (gated_cross_attention.py:97-123): text_time == 0 -> output row 0 and no gradient;
+ *                        text_time > n_kv / n_visual -> uniform average over all keys (fully masked row).
+ * Q is expected pre-scaled.  Element (b, row, h, d) of a tensor lives at base + b*sb + row*sr + h*sh + d.
+ * lse[b][h][row] (fp32) is saved by fwd and consumed by bwd.
+ * ------------------------------------------------------------------------------------------------------ */
+enum { FF_ATTN_DENSE = 0, FF_ATTN_MEDIA = 1 };
+typedef struct ff_strides {
+    long long sb, sr, sh;
+} ff_strides;
+typedef struct ff_attn_desc {
+    int dtype;
+    int batch, heads, dim_head;
+    int n_q, n_kv;
+    int mode, n_visual;
+    int tt_stride;   /* row stride of text_time (elements); query i of batch b reads text_time[b*tt_stride + tt_offset + i] */
+    int tt_offset;
+    ff_strides q, k, v, o;      /* forward tensors; dq/dk/dv/do use dq, dk, dv, dout strides below */
+    ff_strides dq, dk, dv, dout;
+} ff_attn_desc;
+
+int ff_attention_fwd(const ff_attn_desc* d, const void* Q, const void* K, const void* V, const int* text_time,
+                     void* O, float* lse, ff_stream_t stream);
+size_t ff_attention_bwd_workspace_bytes(const ff_attn_desc* d);
+int ff_attention_bwd(const ff_attn_desc* d, const void* Q, const void* K, const void* V, const int* text_time,
+                     const void* O, const void* dO, const float* lse, void* dQ, void* dK, void* dV,
+                     void* workspace, size_t workspace_bytes, ff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * PerceiverResampler (perceiver_resampler.py:99-188).
+ * x_f: (batch, n_frames, n_tokens, dim) contiguous; out: (batch, num_latents, dim).
+ * params / grads: arrays of device pointers in this order (names = reference state_dict keys):
+ *   [0] latents  [1] time_pos_emb  [2] norm.weight  [3] norm.bias
+ *   then per layer i, base = 4 + 12*i:
+ *   +0 layers.i.0.norm_media.weight  +1 .norm_media.bias  +2 .norm_latents.weight  +3 .norm_latents.bias
+ *   +4 layers.i.0.to_q.weight  +5 .to_k.weight  +6 .to_v.weight  +7 .to_out.weight
+ *   +8 layers.i.1.0.weight  +9 layers.i.1.0.bias  +10 layers.i.1.1.weight  +11 layers.i.1.3.weight
+ * `saved` persists fwd -> bwd (activations, statistics); `scratch` is transient.
+ * bwd writes every gradient (no accumulation); dx_f may be NULL (CLIP frozen) — d time_pos_emb is still exact.
+ * ------------------------------------------------------------------------------------------------------ */
+#define FF_RESAMPLER_GLOBAL_PARAMS 4
+#define FF_RESAMPLER_LAYER_PARAMS 12
+typedef struct ff_resampler_desc {
+    int dtype;
+    int batch, n_frames, n_tokens, dim;
+    int depth, heads, dim_head, num_latents, num_time_embeds, ff_mult, act;
+} ff_resampler_desc;
+size_t ff_resampler_saved_bytes(const ff_resampler_desc* d);
+size_t ff_resampler_scratch_bytes(const ff_resampler_desc* d);
+int ff_resampler_fwd(const ff_resampler_desc* d, const void* x_f, const void* const* params, void* out,
+                     void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, ff_stream_t stream);
+int ff_resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void* const* params, const void* dout,
+                     const void* saved, size_t saved_bytes, void* const* grads, void* dx_f, void* scratch,
+                     size_t scratch_bytes, ff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * GatedCrossAttentionBlock (gated_cross_attention.py:135-184).
+ * y: (batch, n_tokens, dim); visual_features: (batch, n_media, n_visual, dim_visual); text_time from ff_text_time.
+ * params / grads order:
+ *   [0] alpha_attn [1] alpha_ffw [2] attn.norm.weight [3] attn.norm.bias [4] attn.to_q.weight
+ *   [5] attn.to_kv.weight [6] attn.to_out.weight [7] ffw.0.weight [8] ffw.0.bias [9] ffw.1.weight [10] ffw.3.weight
+ * Cached decode (previous_kv): pass cached_k/cached_v (+ strides) and visual_features = NULL; n_media is then
+ * n_kv / n_visual and text_time rows are read at tt_offset (the last n_tokens entries, :102-104).
+ * Uncached: K/V are produced in `saved` at ff_xattn_kv_offset() as (batch, n_media*n_visual, 2, heads, dim_head).
+ * ------------------------------------------------------------------------------------------------------ */
+#define FF_XATTN_PARAMS 11
+typedef struct ff_xattn_desc {
+    int dtype;
+    int batch, n_tokens, dim, dim_visual;
+    int n_media, n_visual, heads, dim_head, ff_mult, act;
+    int tt_stride, tt_offset;
+    ff_strides cached_k, cached_v; /* used only when cached_k != NULL */
+} ff_xattn_desc;
+size_t ff_xattn_saved_bytes(const ff_xattn_desc* d);
+size_t ff_xattn_scratch_bytes(const ff_xattn_desc* d);
+size_t ff_xattn_kv_offset(const ff_xattn_desc* d);
+int ff_xattn_block_fwd(const ff_xattn_desc* d, const void* y, const void* visual_features, const int* text_time,
+                       const void* const* params, const void* cached_k, const void* cached_v, void* y_out,
+                       void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, ff_stream_t stream);
+int ff_xattn_block_bwd(const ff_xattn_desc* d, const void* y, const void* visual_features, const int* text_time,
+                       const void* const* params, const void* dy_out, const void* saved, size_t saved_bytes,
+                       void* const* grads, void* dy, void* dvisual_features, void* scratch, size_t scratch_bytes,
+                       ff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLAMINGO_FUSION_H */

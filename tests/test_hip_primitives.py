@@ -1,0 +1,170 @@
+"""HIP kernels, one at a time, through the C ABI against numpy (float64) on the same (dtype-rounded) inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flamingo_oracle as O
+from util import TOL, as64, dev, rel, rnd
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def F():
+    from flamingo_mini_amd import functional
+    return functional
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 136, 72), (1024, 512, 1280), (96, 1024, 4104)])
+def test_gemm_layouts(dtype, al, bl, M, N, K):
+    A = dev(rnd((M, K) if al == 0 else (K, M), 1), dtype)
+    B = dev(rnd((N, K) if bl == 0 else (K, N), 2), dtype)
+    C = F().gemm(A, B, a_layout=al, b_layout=bl, scale=0.5)
+    a, b = as64(A), as64(B)
+    ref = 0.5 * (a if al == 0 else a.T) @ (b.T if bl == 0 else b)
+    assert rel(C, ref) < TOL[dtype]["out"] * 0.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("split_k", [0, 3])
+def test_gemm_epilogues(dtype, split_k):
+    M, N, K = 136, 264, 1024
+    A, B = dev(rnd((M, K), 3, 0.5), dtype), dev(rnd((N, K), 4, 0.05), dtype)
+    R, H = dev(rnd((M, N), 5), dtype), dev(rnd((M, N), 6), dtype)
+    gate = dev(np.array([0.7]), dtype)
+    a, b, r, h, g = as64(A), as64(B), as64(R), as64(H), np.tanh(as64(gate)[0])
+    acc = a @ b.T
+    for act in ("gelu", "sqrelu", "relu"):
+        C, aux = F().gemm(A, B, act=act, want_aux_out=True, split_k=split_k)
+        assert rel(aux, acc) < TOL[dtype]["out"]
+        assert rel(C, O.act_fwd(acc, act)) < TOL[dtype]["out"]
+        C = F().gemm(A, B, act_bwd=act, aux_in=H, gate=gate, split_k=split_k)
+        assert rel(C, acc * g * O.act_bwd(np.ones_like(h), h, act)) < TOL[dtype]["out"]
+    C, aux = F().gemm(A, B, residual=R, gate=gate, want_aux_out=True, split_k=split_k)
+    assert rel(aux, acc) < TOL[dtype]["out"]
+    assert rel(C, r + g * acc) < TOL[dtype]["out"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("rows,cols", [(37, 64), (1000, 1024), (64, 1280), (5, 36)])
+def test_layernorm_fwd_bwd(dtype, rows, cols):
+    x, g, b = dev(rnd((rows, cols), 1, 2.0), dtype), dev(1 + 0.2 * rnd((cols,), 2), dtype), dev(0.1 * rnd((cols,), 3), dtype)
+    dy, res = dev(rnd((rows, cols), 4), dtype), dev(rnd((rows, cols), 5), dtype)
+    y, mean, rstd = F().layernorm_fwd(x, g, b)
+    yr, cache = O.layernorm_fwd(as64(x), as64(g), as64(b))
+    assert rel(y, yr) < TOL[dtype]["out"]
+    assert rel(mean, as64(x).mean(-1)) < 1e-5 and rel(rstd, cache[1][:, 0]) < 1e-4
+    dx, dg, db = F().layernorm_bwd(dy, x, g, mean, rstd, dx_residual=res)
+    dxr, dgr, dbr = O.layernorm_bwd(as64(dy), cache, as64(g))
+    assert rel(dx, dxr + as64(res)) < TOL[dtype]["grad"]
+    assert rel(dg, dgr) < TOL[dtype]["grad"] and rel(db, dbr) < TOL[dtype]["grad"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_layernorm_time_embedding_addend(dtype):
+    b, T, v, D = 3, 2, 5, 64
+    x, tpe = dev(rnd((b * T * v, D), 1), dtype), dev(rnd((4, D), 2), dtype)
+    g, be = dev(1 + 0.2 * rnd((D,), 3), dtype), dev(0.1 * rnd((D,), 4), dtype)
+    y, mean, rstd = F().layernorm_fwd(x, g, be, add=tpe, add_rows_per_seg=T * v, add_div=v)
+    xx = as64(x).reshape(b, T, v, D) + as64(tpe)[:T][None, :, None, :]
+    yr, cache = O.layernorm_fwd(xx.reshape(-1, D), as64(g), as64(be))
+    assert rel(y, yr) < TOL[dtype]["out"]
+    dy = dev(rnd((b * T * v, D), 5), dtype)
+    dx, dg, db = F().layernorm_bwd(dy, x, g, mean, rstd, add=tpe, add_rows_per_seg=T * v, add_div=v)
+    dxr, dgr, dbr = O.layernorm_bwd(as64(dy), cache, as64(g))
+    assert rel(dx, dxr) < TOL[dtype]["grad"] and rel(dg, dgr) < TOL[dtype]["grad"] and rel(db, dbr) < TOL[dtype]["grad"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_rows_reduce_and_gate_grad(dtype):
+    b, T, v, D = 4, 3, 7, 128
+    x = dev(rnd((b * T * v, D), 1), dtype)
+    out = F().rows_reduce(x, T * v, v)                       # d time_pos_emb pattern
+    assert rel(out, as64(x).reshape(b, T, v, D).sum((0, 2))) < TOL[dtype]["grad"]
+    out = F().rows_reduce(x, T * v, 1)                       # d latents pattern
+    assert rel(out, as64(x).reshape(b, T * v, D).sum(0)) < TOL[dtype]["grad"]
+    a, c, alpha = dev(rnd((300, 256), 2), dtype), dev(rnd((300, 256), 3), dtype), dev(np.array([0.3]), dtype)
+    ga = F().gate_grad(a, c, alpha)
+    ref = (as64(a) * as64(c)).sum() * (1 - np.tanh(as64(alpha)[0]) ** 2)
+    assert abs(float(ga.float().cpu()) - ref) < TOL[dtype]["grad"] * max(1.0, abs(ref)) * 5
+
+
+def test_text_time_matches_cumsum():
+    ml = torch.tensor([[0, 0, 1, 0, 0, 1, 0, 1], [1, 0, 0, 0, 1, 0, 0, 0]])
+    for t in (ml, ml.int(), ml.bool()):
+        tt = F().text_time(t.cuda())
+        assert tt.dtype == torch.int32 and tt.cpu().tolist() == O.text_time_of(ml.numpy()).tolist()
+
+
+def _attn_ref(q, k, v, tt, n_visual):
+    """numpy attention on (b, n, h, d) arrays with the reference's masking rules; returns o and a backward closure."""
+    qh, kh, vh = (t.transpose(0, 2, 1, 3) for t in (q, k, v))
+    sim = qh @ kh.transpose(0, 1, 3, 2)
+    if tt is not None:
+        allow, no_media = O.attention_masks(tt, k.shape[1] // n_visual, n_visual)
+        sim = np.where(allow, sim, -np.finfo(np.float64).max)
+    p = O._softmax_lastdim(sim)
+    if tt is not None:
+        p = np.where(no_media, 0.0, p)
+    o = (p @ vh).transpose(0, 2, 1, 3)
+
+    def bwd(do):
+        doh = do.transpose(0, 2, 1, 3)
+        dp = doh @ vh.transpose(0, 1, 3, 2)
+        if tt is not None:
+            dp = np.where(no_media, 0.0, dp)
+        dv = p.transpose(0, 1, 3, 2) @ doh
+        ds = p * (dp - (dp * p).sum(-1, keepdims=True))
+        if tt is not None:
+            ds = np.where(allow, ds, 0.0)
+        return tuple(t.transpose(0, 2, 1, 3) for t in (ds @ kh, ds.transpose(0, 1, 3, 2) @ qh, dv))
+    return o, bwd
+
+
+@pytest.mark.parametrize("dtype,dh", [(torch.float32, 64), (torch.float32, 16), (torch.bfloat16, 64), (torch.bfloat16, 32)],
+                         ids=["f32-64", "f32-16", "bf16-64", "bf16-32"])
+@pytest.mark.parametrize("nq,nkv", [(64, 321), (8, 18), (64, 114)])
+def test_attention_dense(dtype, dh, nq, nkv):
+    b, h = 2, 3
+    q, k, v = (dev(rnd((b, n, h, dh), s, sc), dtype) for n, s, sc in ((nq, 1, dh ** -0.5), (nkv, 2, 1.0), (nkv, 3, 1.0)))
+    do = dev(rnd((b, nq, h, dh), 4), dtype)
+    o, lse = F().attention_fwd(q, k, v)
+    oref, bwd = _attn_ref(as64(q), as64(k), as64(v), None, 0)
+    assert rel(o, oref) < TOL[dtype]["out"]
+    dq, dk, dv = F().attention_bwd(q, k, v, o, do, lse)
+    for got, ref, name in zip((dq, dk, dv), bwd(as64(do)), "qkv"):
+        assert rel(got, ref) < TOL[dtype]["grad"], name
+
+
+@pytest.mark.parametrize("dtype,dh,nv", [(torch.float32, 16, 8), (torch.float32, 64, 64), (torch.bfloat16, 64, 64)], ids=["f32-toy", "f32", "bf16"])
+def test_attention_media_mask_quirks(dtype, dh, nv):
+    """equality mask, zero rows (text_time == 0), uniform rows (text_time > n_media): SURVEY.md F2/F3."""
+    b, h, L, N = 3, 2, 70, 2
+    ml = np.zeros((b, L), np.int64)
+    ml[0, [0, 33]] = 1
+    ml[1, [5, 40, 66]] = 1          # leading zero rows; third tag with only two images -> uniform rows
+    tt = O.text_time_of(ml)
+    q, k, v = (dev(rnd((b, n, h, dh), s, sc), dtype) for n, s, sc in ((L, 1, dh ** -0.5), (N * nv, 2, 1.0), (N * nv, 3, 1.0)))
+    do = dev(rnd((b, L, h, dh), 4), dtype)
+    ttd = torch.as_tensor(tt, dtype=torch.int32).cuda()
+    o, lse = F().attention_fwd(q, k, v, tt=ttd, n_visual=nv)
+    oref, bwd = _attn_ref(as64(q), as64(k), as64(v), tt, nv)
+    assert rel(o, oref) < TOL[dtype]["out"]
+    assert float(o[2].abs().max()) == 0.0 and float(o[1, :5].abs().max()) == 0.0     # exact zeros before any image
+    dq, dk, dv = F().attention_bwd(q, k, v, o, do, lse, tt=ttd, n_visual=nv)
+    for got, ref, name in zip((dq, dk, dv), bwd(as64(do)), "qkv"):
+        assert rel(got, ref) < TOL[dtype]["grad"], name
+    assert float(dq[1, 66:].abs().max()) == 0.0                                          # uniform rows: no gradient to q
+
+
+def test_online_softmax_rescale_is_exercised():
+    """A key far above the rest in a LATER tile forces the running-max rescale branch (guide rule 26)."""
+    b, h, dh, nq, nkv = 1, 1, 64, 64, 200
+    q, k, v = rnd((b, nq, h, dh), 1, 0.3), rnd((b, nkv, h, dh), 2, 0.3), rnd((b, nkv, h, dh), 3)
+    k[0, 150, 0] = q[0, 7, 0] * 40.0          # spike against query 7 in the third key tile
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    o, lse = F().attention_fwd(qd, kd, vd)
+    oref, _ = _attn_ref(as64(qd), as64(kd), as64(vd), None, 0)
+    assert rel(o, oref) < 2e-5 and rel(o[0, 7], oref[0, 7]) < 2e-5

@@ -1,0 +1,34 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Tolerances (relative L2 error against the fp64 oracle / reference vectors):
+#   fp32 path: MFMA fp32 FMA chains + __expf  -> 2e-5 (the 1e-3 logits target of BASELINE.json is far looser)
+#   bf16 path: inputs/activations rounded to bf16 at every kernel boundary; the reference's own bf16-vs-fp32 deviation is
+#              6.6e-3 (resampler) / 2.9e-3 (xattn block) -> 2e-2 on outputs, 4e-2 on gradients
+TOL = {torch.float32: dict(out=2e-5, grad=5e-5), torch.bfloat16: dict(out=2e-2, grad=4e-2)}
+
+
+def rel(a, b) -> float:
+    a = np.asarray(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, np.float64)
+    b = np.asarray(b.detach().float().cpu().numpy() if torch.is_tensor(b) else b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a, np.float64)).to(dtype).cuda()
+
+
+def rnd(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return (g.standard_normal(shape) * scale).astype(np.float32)
+
+
+def as64(t):
+    """what the kernel actually saw (after rounding to its dtype), as float64 numpy"""
+    return t.detach().float().cpu().numpy().astype(np.float64)

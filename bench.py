@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec (fwd+bwd) of flamingo-mini (gpt2-large + CLIP ViT-L/14), per-GPU batch 32, bf16, on
+1..8 MI355X (BASELINE.json `metric`, config B of SURVEY.md section 8d).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        bench.py --gpus 8 --steps 10 --warmup 3
+
+One step = CLIP forward (frozen) -> perceiver resampler -> 36 x (gated xattn block + frozen GPT-2 block) -> lm_head ->
+shifted cross-entropy -> backward -> mean all-reduce of the trainable gradients (N > 1) -> fused AdamW step.
+Synthetic data (N(0,1) pixels, uniform token ids, media tag at position 0), random-init weights of the named
+architectures (no network), gates alpha = 0.5 (zero gates would make the fusion path an identity with zero gradients).
+The resampler / xattn blocks run in libflamingo_fusion (hand-written HIP); the run aborts if that library is missing.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live: every GEMM launch of the fusion library inside the timed
+steps is bracketed by HIP events on its stream (ff_gemm_profile_*); the dominant kernel variant is reported against the
+dense bf16 MFMA peak.  `cpu_baseline` times the numpy oracle of the same hot path on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (AMD's 5 PF headline is 2:1 sparse)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--seq-len", type=int, default=32)
+    ap.add_argument("--lm", default="gpt2-large")
+    ap.add_argument("--clip", default="openai/clip-vit-large-patch14")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hot-path-only", action="store_true", help="skip CLIP / LM: resampler + xattn blocks on synthetic activations")
+    return ap.parse_args()
+
+
+def build_model(args, device, dtype):
+    from flamingo_mini_amd import FlamingoConfig, FlamingoModel
+    from flamingo_mini_amd.backbones import CLIP_VISION, GPT2, OPT
+    dim = GPT2[args.lm][0] if args.lm in GPT2 else OPT[args.lm][0]
+    cfg = FlamingoConfig(lm=args.lm, clip_model_type=args.clip, dim=dim, dim_visual=CLIP_VISION[args.clip][0],
+                         random_init_backbones=True)
+    torch.manual_seed(1234)                                   # same weights on every rank (DDP broadcasts; here: same seed)
+    model = FlamingoModel(cfg)
+    with torch.no_grad():
+        for hook in model.flamingo.get_modified_layers():
+            hook.xattn_block.alpha_attn.fill_(0.5)
+            hook.xattn_block.alpha_ffw.fill_(0.5)
+    return model.to(device=device, dtype=dtype).train(), cfg
+
+
+def synthetic_batch(args, cfg, device, dtype, rank):
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    px = torch.randn((args.batch, 1, 3, 224, 224), generator=g).to(device=device, dtype=dtype)
+    vocab = 50257 if args.lm.startswith("gpt2") else 50272
+    ids = torch.randint(0, vocab, (args.batch, args.seq_len), generator=g).to(device)
+    ml = torch.zeros((args.batch, args.seq_len), dtype=torch.long, device=device)
+    ml[:, 0] = 1
+    return dict(pixel_values=px, input_ids=ids, media_locations=ml, attention_mask=torch.ones_like(ids), labels=ids)
+
+
+def gemm_profile_summary(lib, ffi, max_records):
+    recs = (ffi.GemmProfileRecord * max_records)()
+    n = lib.ff_gemm_profile_read(recs, max_records)
+    lib.ff_gemm_profile_enable(0)
+    groups = {}
+    for i in range(n):
+        r = recs[i]
+        key = (r.dtype, r.tile, r.a_layout, r.b_layout)
+        g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
+        g["ms"] += r.ms
+        g["flops"] += 2.0 * r.M * r.N * r.K * r.nz
+        g["launches"] += 1
+    return groups, n
+
+
+def cpu_baseline(args):
+    """numpy oracle (a port of the reference's algorithm) on the host cores: fwd+bwd of the hot path on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from detgen import det, resampler_params, xattn_params
+    from oracle import flamingo_oracle as O
+    try:
+        import threadpoolctl
+        cores = max(i["num_threads"] for i in threadpoolctl.threadpool_info() if i.get("user_api") == "blas")
+    except Exception:
+        cores = os.cpu_count() or 1
+    b, L, d, dv, n_blocks_timed, n_blocks = 2, args.seq_len, 1280, 1024, 2, 36
+    f32 = np.float32
+    rp = {k: v.astype(f32) for k, v in resampler_params(dv, 6, 8, 64, 64, 4, 4, tag="cpu").items()}
+    xp = {k: v.astype(f32) for k, v in xattn_params(d, dv, 8, 64, 4, tag="cpu").items()}
+    x = det((b, 1, 257, dv), "cpu-x"); y = det((b, L, d), "cpu-y"); ml = np.zeros((b, L), np.int64); ml[:, 0] = 1
+    t0 = time.perf_counter()
+    vf, c = O.resampler_fwd(x, rp)
+    O.resampler_bwd(np.ones_like(vf), c, rp)
+    t_rs = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(n_blocks_timed):
+        out, _, c2 = O.gated_xattn_block_fwd(y, vf.reshape(b, 1, 64, dv), ml, xp)
+        O.gated_xattn_block_bwd(np.ones_like(out), c2, xp)
+    t_blk = (time.perf_counter() - t0) / n_blocks_timed
+    hot = t_rs + n_blocks * t_blk
+    return {"value": round(b / hot, 3), "unit": "images/sec (hot path only: resampler + 36 xattn blocks, fwd+bwd, fp32)",
+            "cores": int(cores), "kind": "port",
+            "sample": f"numpy oracle, batch {b} of config B: resampler fwd+bwd {t_rs:.2f}s + {n_blocks_timed} of 36 xattn blocks "
+                      f"fwd+bwd ({t_blk:.3f}s each, extrapolated x36); excludes the frozen CLIP / GPT-2 backbones"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (see the docstring)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the fusion path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    from flamingo_mini_amd import ffi
+    from flamingo_mini_amd.data_parallel import GradientAllReducer
+    lib = ffi.lib()                                            # aborts loudly if the HIP library is missing
+
+    model, cfg = build_model(args, device, dtype)
+    batch = synthetic_batch(args, cfg, device, dtype, rank)
+    params = [p for p in model.parameters_trainable()]
+    n_trainable = sum(p.numel() for p in params)
+    opt = None if args.no_optimizer else torch.optim.AdamW(params, lr=1e-4, fused=True)
+    reducer = GradientAllReducer(model)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(**batch)
+        out.loss.backward()
+        reducer.finish()
+        if opt is not None:
+            opt.step()
+        return out.loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    max_rec = 4096 * max(args.steps, 1)
+    if rank == 0:
+        lib.ff_gemm_profile_enable(max_rec)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.float().item())
+
+    if rank == 0:
+        groups, nrec = gemm_profile_summary(lib, ffi, max_rec)
+        ms_per_step = elapsed / args.steps * 1e3
+        images = args.batch * world * args.steps
+        roofline = None
+        if groups:
+            key, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+            is_bf16 = key[0] == ffi.DTYPE_BF16
+            peak = MFMA_BF16_DENSE_PEAK_TFLOPS if is_bf16 else MFMA_F32_PEAK_TFLOPS
+            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            name = (f"gemm_bf16_kernel<{key[1]},{key[1]},{key[2]},{key[3]}>" if is_bf16 else f"gemm_f32_kernel<{key[2]},{key[3]}>")
+            tot_ms = sum(v["ms"] for v in groups.values())
+            tot_fl = sum(v["flops"] for v in groups.values())
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": None, "kernel": name, "launches": g["launches"],
+                        "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
+                        "avg_launch_gflop": round(g["flops"] / g["launches"] / 1e9, 3),
+                        "all_fusion_gemms": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                             "ms_per_step": round(tot_ms / args.steps, 3),
+                                             "share_of_step": round(tot_ms / args.steps / ms_per_step, 3)}}
+        result = {
+            "metric": "images/sec (fwd+bwd) flamingo-mini bs=32",
+            "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"flamingo-mini ({args.lm} + {args.clip}), 1 image (224x224) + {args.seq_len} tokens per sequence, "
+                                   f"per-GPU batch {args.batch}; step = fwd + bwd + grad all-reduce"
+                                   + ("" if args.no_optimizer else " + fused AdamW") + "; random-init weights, gates alpha=0.5",
+                       "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
+                       "trainable_params": n_trainable, "loss": round(loss_val, 4)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

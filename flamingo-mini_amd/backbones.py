@@ -40,11 +40,13 @@ def load_vision_encoder(config):
     from transformers import CLIPVisionConfig, CLIPVisionModel
     if not want_random_init(config):
         return CLIPVisionModel.from_pretrained(config.clip_model_type)
-    if config.clip_model_type not in CLIP_VISION:
+    kw = {}
+    if config.clip_model_type in CLIP_VISION:
+        hidden, layers, heads, inter, patch, image = CLIP_VISION[config.clip_model_type]
+        kw = dict(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter,
+                  patch_size=patch, image_size=image)
+    elif not _tiny_override(config, "clip"):
         raise ValueError(f"no built-in architecture for {config.clip_model_type}; known: {sorted(CLIP_VISION)}")
-    hidden, layers, heads, inter, patch, image = CLIP_VISION[config.clip_model_type]
-    kw = dict(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter,
-              patch_size=patch, image_size=image)
     kw.update(_tiny_override(config, "clip"))
     return CLIPVisionModel(CLIPVisionConfig(**kw))
 
@@ -60,17 +62,21 @@ def load_language_model(config):
         return OPTForCausalLM.from_pretrained(name)
     if name.startswith("gpt2"):
         from transformers import GPT2Config, GPT2LMHeadModel
-        if name not in GPT2:
+        kw = {}
+        if name in GPT2:
+            n_embd, n_layer, n_head = GPT2[name]
+            kw = dict(n_embd=n_embd, n_layer=n_layer, n_head=n_head, vocab_size=50257, n_positions=1024)
+        elif not _tiny_override(config, "lm"):
             raise ValueError(f"no built-in architecture for {name}; known: {sorted(GPT2)}")
-        n_embd, n_layer, n_head = GPT2[name]
-        kw = dict(n_embd=n_embd, n_layer=n_layer, n_head=n_head, vocab_size=50257, n_positions=1024)
         kw.update(_tiny_override(config, "lm"))
         return GPT2LMHeadModel(GPT2Config(**kw))
     from transformers import OPTConfig, OPTForCausalLM
-    if name not in OPT:
+    kw = {}
+    if name in OPT:
+        hidden, layers, heads, ffn, proj, ln_before = OPT[name]
+        kw = dict(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, ffn_dim=ffn, word_embed_proj_dim=proj,
+                  do_layer_norm_before=ln_before, vocab_size=50272, max_position_embeddings=2048)
+    elif not _tiny_override(config, "lm"):
         raise ValueError(f"no built-in architecture for {name}; known: {sorted(OPT)}")
-    hidden, layers, heads, ffn, proj, ln_before = OPT[name]
-    kw = dict(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, ffn_dim=ffn, word_embed_proj_dim=proj,
-              do_layer_norm_before=ln_before, vocab_size=50272, max_position_embeddings=2048)
     kw.update(_tiny_override(config, "lm"))
     return OPTForCausalLM(OPTConfig(**kw))

@@ -437,6 +437,31 @@ static int dispatch_f32(const GemmParams& P, hipStream_t st) {
     return check_launch("gemm_f32");
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// optional per-launch timing of the GEMM kernels with HIP events on the launch stream (bench.py's roofline leg)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ProfState {
+    bool on = false;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;     // 2 events per record
+    ff_gemm_profile_record* rec = nullptr;
+} g_prof;
+}
+static int prof_begin(const GemmParams& P, int dtype, int bm, hipStream_t st) {
+    if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+    const int i = g_prof.n++;
+    ff_gemm_profile_record& r = g_prof.rec[i];
+    r.dtype = dtype; r.tile = bm; r.a_layout = P.a_layout; r.b_layout = P.b_layout;
+    r.M = P.M; r.N = P.N; r.K = P.K; r.nz = P.nz; r.split_k = P.split_k; r.ms = 0.f;
+    hipEventRecord(g_prof.ev[2 * i], st);
+    return i;
+}
+static void prof_end(int i, hipStream_t st) {
+    if (i >= 0) hipEventRecord(g_prof.ev[2 * i + 1], st);
+}
+
 static bool big_tile(const GemmParams& P) { return (long long)cdiv(P.M, 128) * cdiv(P.N, 128) * P.nz >= 160; }
 
 int gemm_pick_split(int dtype, int M, int N, int K, int nz) {
@@ -478,6 +503,7 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.b_vec_ok = P.b_vec_ok && ((uintptr_t)P.p[z].B % 16 == 0);
     }
     int rc;
+    const int prof_id = prof_begin(P, dtype, dtype == FF_DTYPE_BF16 ? (big_tile(P) ? 128 : 64) : kFBM, st);
     if (dtype == FF_DTYPE_BF16) {
         FF_CHECK(P.a_vec_ok && P.b_vec_ok, FF_ERR_UNSUPPORTED,
                  "bf16 gemm needs 16-byte aligned operands with contiguous dims %% 8 == 0 (M=%d N=%d K=%d)", P.M, P.N, P.K);
@@ -486,6 +512,7 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
     } else {
         rc = dispatch_f32(P, st);
     }
+    prof_end(prof_id, st);   // main kernel only: the split-K epilogue is a separate (HBM-bound) kernel
     FF_TRY(rc);
     if (P.split_k > 1) {
         const long long total = (long long)P.nz * P.M * ((P.N + 3) / 4);
@@ -520,4 +547,36 @@ extern "C" int ff_gemm(const ff_gemm_desc* d, const void* A, const void* B, void
     P.nz = 1;
     P.p[0] = GemmProblem{A, B, C, aux_out, aux_in, residual, gate};
     return gemm_launch(P, d->dtype, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ff_gemm_profile_enable(int max_records) {
+    using namespace ff;
+    if (max_records <= 0) { g_prof.on = false; return FF_OK; }
+    if (max_records > g_prof.cap) {
+        hipEvent_t* ev = (hipEvent_t*)realloc(g_prof.ev, sizeof(hipEvent_t) * 2 * max_records);
+        ff_gemm_profile_record* rec = (ff_gemm_profile_record*)realloc(g_prof.rec, sizeof(ff_gemm_profile_record) * max_records);
+        FF_CHECK(ev && rec, FF_ERR_WORKSPACE, "gemm profile: out of host memory");
+        g_prof.ev = ev; g_prof.rec = rec;
+        for (int i = 2 * g_prof.cap; i < 2 * max_records; i++) {
+            hipError_t e = hipEventCreate(&g_prof.ev[i]);
+            FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+        g_prof.cap = max_records;
+    }
+    g_prof.n = 0;
+    g_prof.on = true;
+    return FF_OK;
+}
+extern "C" int ff_gemm_profile_read(ff_gemm_profile_record* out, int max_records) {
+    using namespace ff;
+    const int n = g_prof.n < max_records ? g_prof.n : max_records;
+    for (int i = 0; i < n; i++) {
+        hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        g_prof.rec[i].ms = ms;
+        out[i] = g_prof.rec[i];
+    }
+    g_prof.n = 0;
+    return n;
 }

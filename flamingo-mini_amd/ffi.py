@@ -41,6 +41,11 @@ class GemmDesc(C.Structure):
                 ("split_k", C.c_int)]
 
 
+class GemmProfileRecord(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("tile", C.c_int), ("a_layout", C.c_int), ("b_layout", C.c_int), ("M", C.c_int), ("N", C.c_int),
+                ("K", C.c_int), ("nz", C.c_int), ("split_k", C.c_int), ("ms", C.c_float)]
+
+
 class LnDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("x_map", RowMap), ("y_map", RowMap), ("dx_map", RowMap),
                 ("add_rows_per_seg", C.c_int), ("add_div", C.c_int), ("eps", C.c_float), ("stats_given", C.c_int)]
@@ -82,6 +87,8 @@ _SIGNATURES = {
     "ff_last_error": (C.c_char_p, []),
     "ff_gemm_workspace_bytes": (_SZ, [C.POINTER(GemmDesc)]),
     "ff_gemm": (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ff_gemm_profile_enable": (_I, [_I]),
+    "ff_gemm_profile_read": (_I, [C.POINTER(GemmProfileRecord), _I]),
     "ff_layernorm_fwd": (_I, [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "ff_layernorm_bwd_workspace_bytes": (_SZ, [C.POINTER(LnDesc)]),
     "ff_layernorm_bwd": (_I, [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),

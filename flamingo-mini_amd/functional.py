@@ -22,6 +22,30 @@ def set_checker_backend(backend) -> None:
     _checker_backend = backend
 
 
+_grad_ready_callbacks: list = []   # called with the flat gradient buffer of a fused module right after its backward is enqueued
+
+
+def add_grad_ready_callback(fn: Callable[[torch.Tensor], None]) -> None:
+    _grad_ready_callbacks.append(fn)
+
+
+def remove_grad_ready_callback(fn) -> None:
+    if fn in _grad_ready_callbacks:
+        _grad_ready_callbacks.remove(fn)
+
+
+def _flat_grads(params: Sequence[torch.Tensor]):
+    """One contiguous buffer holding every parameter gradient of a fused module (each slice 16-byte aligned).  Autograd
+    adopts the slices as `param.grad` without copying, so the buffer doubles as a ready-made all-reduce bucket."""
+    align = 16 // params[0].element_size()
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        total += (p.numel() + align - 1) // align * align
+    flat = torch.empty(total, dtype=params[0].dtype, device=params[0].device)   # alignment pads are never read
+    return flat, [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+
+
 def _empty_bytes(n: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
 
@@ -92,12 +116,14 @@ class _ResamplerFn(torch.autograd.Function):
         desc = _resampler_desc(x_f, ctx.cfg)
         dev = x_f.device
         dout = dout.contiguous()
-        grads = [torch.empty_like(p) for p in params]
+        flat, grads = _flat_grads(params)
         dx_f = torch.empty_like(x_f) if ctx.needs_input_grad[0] else None
         scratch = _empty_bytes(lib.ff_resampler_scratch_bytes(desc), dev)
         ffi.check(lib.ff_resampler_bwd(desc, x_f.data_ptr(), ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(),
                                        ffi.ptr_array(grads), ffi.ptr(dx_f), scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)),
                   "ff_resampler_bwd")
+        for cb in _grad_ready_callbacks:
+            cb(flat)
         return (dx_f, None, *grads)
 
 
@@ -152,13 +178,15 @@ class _XattnBlockFn(torch.autograd.Function):
         desc = _xattn_desc(y, vf.shape[1], ctx.n_visual, vf.shape[3], ctx.cfg, tt)
         dev = y.device
         dout = dout.contiguous()
-        grads = [torch.empty_like(p) for p in params]
+        flat, grads = _flat_grads(params)
         dy = torch.empty_like(y)
         dvf = torch.empty_like(vf) if ctx.needs_input_grad[1] else None
         scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
         ffi.check(lib.ff_xattn_block_bwd(desc, y.data_ptr(), vf.data_ptr(), tt.data_ptr(), ffi.ptr_array(params), dout.data_ptr(),
                                          saved.data_ptr(), saved.numel(), ffi.ptr_array(grads), dy.data_ptr(), ffi.ptr(dvf),
                                          scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_bwd")
+        for cb in _grad_ready_callbacks:
+            cb(flat)
         return (dy, dvf, None, None, None, *grads)
 
 

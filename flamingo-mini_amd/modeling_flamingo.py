@@ -153,7 +153,10 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
         if labels is not None:   # tokens < n predict n
             shift_logits = logits[..., :-1, :].contiguous()
             shift_labels = labels[..., 1:].contiguous()
-            loss = TF.cross_entropy(shift_logits.view(-1, shift_logits.size(-1)).float(), shift_labels.view(-1), reduction=loss_reduction)
+            flat = shift_logits.view(-1, shift_logits.size(-1))
+            if flat.dtype in (torch.bfloat16, torch.float16):
+                flat = flat.float()      # log-softmax over ~50k classes in fp32 (the reference stays in the autocast dtype)
+            loss = TF.cross_entropy(flat, shift_labels.view(-1), reduction=loss_reduction)
 
         return CausalLMOutputWithPast(
             loss=loss, logits=logits,

@@ -71,6 +71,18 @@ size_t ff_gemm_workspace_bytes(const ff_gemm_desc* d);
 int ff_gemm(const ff_gemm_desc* d, const void* A, const void* B, void* C, void* aux_out, const void* aux_in,
             const void* residual, const void* gate, void* workspace, size_t workspace_bytes, ff_stream_t stream);
 
+
+/* Optional measurement aid (bench.py's roofline leg): while enabled, every GEMM main-kernel launch is bracketed by two
+ * HIP events on its own stream.  ff_gemm_profile_read() waits for the recorded launches, fills `out` (returns the count)
+ * and clears the log.  ff_gemm_profile_enable(0) switches it off.  Not thread-safe; one stream at a time. */
+typedef struct ff_gemm_profile_record {
+    int dtype, tile, a_layout, b_layout;
+    int M, N, K, nz, split_k;
+    float ms;
+} ff_gemm_profile_record;
+int ff_gemm_profile_enable(int max_records);
+int ff_gemm_profile_read(ff_gemm_profile_record* out, int max_records);
+
 /* ------------------------------------------------------------------------------------------------------
  * LayerNorm over the last axis (eps inside the sqrt, biased variance: torch.nn.LayerNorm).
  * Optional broadcast addend fused in front: x[r] += add[((r % add_rows_per_seg) / add_div)]  — the

@@ -157,3 +157,67 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------------
+# tiny FULL model (reference FlamingoModel, OPT-backed) -> state_dict + inputs + logits / loss / grads
+# ---------------------------------------------------------------------------------------------------
+TINY = dict(
+    lm_kw=dict(hidden_size=32, num_hidden_layers=3, num_attention_heads=2, ffn_dim=64, word_embed_proj_dim=32,
+               do_layer_norm_before=True, vocab_size=96, max_position_embeddings=64, dropout=0.0),
+    clip_kw=dict(hidden_size=48, num_hidden_layers=2, num_attention_heads=2, intermediate_size=96, patch_size=16, image_size=32),
+    flamingo_kw=dict(lm="facebook/opt-tiny", clip_model_type="openai/clip-vit-tiny", dim=32, dim_visual=48, xattn_every=2,
+                     xattn_dim_head=16, xattn_heads=2, xattn_ff_mult=2, xattn_act="sqrelu", resampler_depth=2,
+                     resampler_dim_head=16, resampler_heads=2, resampler_num_latents=8, resampler_num_time_embeds=4,
+                     resampler_ff_mult=2, resampler_act="gelu"),
+)
+
+
+def full_model_case():
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel, OPTConfig, OPTForCausalLM
+    # the reference calls from_pretrained (needs the hub): build the same classes with tiny random-init configs instead
+    CLIPVisionModel.from_pretrained = classmethod(lambda cls, name, **kw: CLIPVisionModel(CLIPVisionConfig(**TINY["clip_kw"])))
+    OPTForCausalLM.from_pretrained = classmethod(lambda cls, name, **kw: OPTForCausalLM(OPTConfig(**TINY["lm_kw"])))
+    shim = sys.modules["einops_exts"]
+    for name in list(sys.modules):
+        if name.startswith("flamingo_mini"):
+            del sys.modules[name]
+    sys.modules["einops_exts"] = shim
+    sys.path.insert(0, REF)
+    import flamingo_mini as ref   # the real package this time (modeling_flamingo imports transformers)
+    torch.manual_seed(7)
+    cfg = ref.FlamingoConfig(**TINY["flamingo_kw"])
+    model = ref.FlamingoModel(cfg).double()
+    with torch.no_grad():
+        for i, hook in enumerate(model.flamingo.get_modified_layers()):
+            hook.xattn_block.alpha_attn.fill_(0.5 - 0.2 * i)
+            hook.xattn_block.alpha_ffw.fill_(-0.3 + 0.25 * i)
+    model.train()
+    b, L, N = 2, 10, 2
+    px = t64(det((b, N, 3, 32, 32), "full-px"))
+    ids = torch.from_numpy((np.abs(det((b, L), "full-ids")) * 96).astype(np.int64) % 96)
+    ml = torch.zeros(b, L, dtype=torch.long); ml[0, [0, 5]] = 1; ml[1, [2, 3, 7]] = 1   # row 1: 3 tags, 2 images -> quirk rows
+    am = torch.ones(b, L, dtype=torch.long)
+    out = model(input_ids=ids, attention_mask=am, media_locations=ml, pixel_values=px, labels=ids)
+    out.loss.backward()
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    grads = {k: p.grad.numpy() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    # cached two-step decode at the forward level: step 1 full prompt with use_cache, step 2 one more token
+    model.eval()
+    with torch.no_grad():
+        o1 = model(input_ids=ids[:, :-1], attention_mask=am[:, :-1], media_locations=ml[:, :-1], pixel_values=px, use_cache=True)
+        o2 = model(input_ids=ids[:, -1:], attention_mask=am, media_locations=ml, past_key_values=o1.past_key_values, use_cache=True)
+        full = model(input_ids=ids, attention_mask=am, media_locations=ml, pixel_values=px)
+    assert torch.allclose(o2.logits[:, -1], full.logits[:, -1], atol=1e-8)
+    save = {"sd." + k: v for k, v in sd.items()}
+    save.update({"g." + k: v for k, v in grads.items()})
+    save.update(px=px.numpy(), ids=ids.numpy(), ml=ml.numpy(), logits=out.logits.detach().numpy(), loss=np.array(out.loss.item()),
+                eval_logits=full.logits.numpy(), step2_logits=o2.logits.numpy())
+    np.savez_compressed(os.path.join(HERE, "full_opt_tiny.npz"), **save)
+    print("full_opt_tiny: logits", tuple(out.logits.shape), "loss", out.loss.item(), "trainable grads", len(grads),
+          "transformers", transformers.__version__)
+
+
+if __name__ == "__main__" and os.environ.get("FLAMINGO_GOLDEN_FULL", "1") == "1":
+    full_model_case()

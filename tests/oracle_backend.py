@@ -1,0 +1,71 @@
+"""TESTS ONLY: lets the drop-in modules run on CPU by routing the two fused ops to the numpy oracle (forward and its
+hand-written backward) behind torch.autograd.Function.  Installed with functional.set_checker_backend(); the product
+never does this — without it CPU tensors raise."""
+import numpy as np
+import torch
+
+from oracle import flamingo_oracle as O
+
+RS_LAYER_KEYS = ["0.norm_media.weight", "0.norm_media.bias", "0.norm_latents.weight", "0.norm_latents.bias", "0.to_q.weight",
+                 "0.to_k.weight", "0.to_v.weight", "0.to_out.weight", "1.0.weight", "1.0.bias", "1.1.weight", "1.3.weight"]
+XA_KEYS = ["alpha_attn", "alpha_ffw", "attn.norm.weight", "attn.norm.bias", "attn.to_q.weight", "attn.to_kv.weight",
+           "attn.to_out.weight", "ffw.0.weight", "ffw.0.bias", "ffw.1.weight", "ffw.3.weight"]
+
+
+def rs_keys(depth):
+    return ["latents", "time_pos_emb", "norm.weight", "norm.bias"] + [f"layers.{i}.{k}" for i in range(depth) for k in RS_LAYER_KEYS]
+
+
+def _np(t):
+    return t.detach().double().numpy()
+
+
+class _Rs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        depth, heads, dim_head, q, nte, ffm, act = cfg
+        p = dict(zip(rs_keys(depth), map(_np, params)))
+        y, cache = O.resampler_fwd(_np(x), p, heads=heads, dim_head=dim_head, act=act)
+        ctx.stuff = (cache, p, cfg, x.dtype, [t.dtype for t in params])
+        return torch.from_numpy(y).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cache, p, cfg, xdt, pdts = ctx.stuff
+        dx, g = O.resampler_bwd(_np(dy), cache, p, heads=cfg[1], dim_head=cfg[2], act=cfg[6])
+        return (torch.from_numpy(dx).to(xdt), None) + tuple(torch.from_numpy(g[k]).to(dt) for k, dt in zip(rs_keys(cfg[0]), pdts))
+
+
+class _Xa(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, vf, tt, cfg, n_visual, *params):
+        heads, dim_head, ffm, act = cfg
+        p = dict(zip(XA_KEYS, map(_np, params)))
+        ml = np.diff(tt.numpy().astype(np.int64), axis=1, prepend=0)       # text_time back to 0/1 tags
+        out, kv, cache = O.gated_xattn_block_fwd(_np(y), _np(vf), ml, p, heads=heads, dim_head=dim_head, act=act, n_visual=n_visual)
+        ctx.stuff = (cache, p, cfg, y.dtype, [t.dtype for t in params])
+        return torch.from_numpy(out).to(y.dtype), torch.from_numpy(kv[0]).to(y.dtype), torch.from_numpy(kv[1]).to(y.dtype)
+
+    @staticmethod
+    def backward(ctx, dout, _dk, _dv):
+        cache, p, cfg, ydt, pdts = ctx.stuff
+        dy, dvf, g = O.gated_xattn_block_bwd(_np(dout), cache, p, heads=cfg[0], dim_head=cfg[1], act=cfg[3])
+        return (torch.from_numpy(dy).to(ydt), torch.from_numpy(dvf).to(ydt), None, None, None) + \
+            tuple(torch.from_numpy(g[k]).to(dt) for k, dt in zip(XA_KEYS, pdts))
+
+
+class OracleBackend:
+    def resampler(self, x_f, params, cfg):
+        return _Rs.apply(x_f, tuple(cfg), *params)
+
+    def xattn_block(self, y, vf, tt, params, cfg, n_visual, previous_kv, output_kv):
+        if previous_kv is None:
+            out, k, v = _Xa.apply(y, vf, tt, tuple(cfg), n_visual, *params)
+            return out, ((k.detach(), v.detach()) if output_kv else None)
+        heads, dim_head, ffm, act = cfg
+        p = dict(zip(XA_KEYS, map(_np, params)))
+        tt_np = tt.numpy().astype(np.int64)
+        ml = np.diff(tt_np, axis=1, prepend=0)
+        out, _, _ = O.gated_xattn_block_fwd(_np(y), None, ml, p, heads=heads, dim_head=dim_head, act=act, n_visual=n_visual,
+                                            previous_kv=(_np(previous_kv[0]), _np(previous_kv[1])))
+        return torch.from_numpy(out).to(y.dtype), (previous_kv if output_kv else None)

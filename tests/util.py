@@ -14,8 +14,8 @@ TOL = {torch.float32: dict(out=2e-5, grad=5e-5), torch.bfloat16: dict(out=2e-2, 
 
 
 def rel(a, b) -> float:
-    a = np.asarray(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, np.float64)
-    b = np.asarray(b.detach().float().cpu().numpy() if torch.is_tensor(b) else b, np.float64)
+    a = np.asarray(a.detach().double().cpu().numpy() if torch.is_tensor(a) else a, np.float64)
+    b = np.asarray(b.detach().double().cpu().numpy() if torch.is_tensor(b) else b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
@@ -31,4 +31,4 @@ def rnd(shape, seed, scale=1.0):
 
 def as64(t):
     """what the kernel actually saw (after rounding to its dtype), as float64 numpy"""
-    return t.detach().float().cpu().numpy().astype(np.float64)
+    return t.detach().double().cpu().numpy()

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hot-path-only", action="store_true", help="skip CLIP / LM: resampler + xattn blocks on synthetic activations")
+    ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
     return ap.parse_args()
 
 
@@ -81,15 +81,16 @@ def gemm_profile_summary(lib, ffi, max_records):
     recs = (ffi.GemmProfileRecord * max_records)()
     n = lib.ff_gemm_profile_read(recs, max_records)
     lib.ff_gemm_profile_enable(0)
-    groups = {}
+    groups, shapes = {}, {}
     for i in range(n):
         r = recs[i]
         key = (r.dtype, r.tile, r.a_layout, r.b_layout)
-        g = groups.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
-        g["ms"] += r.ms
-        g["flops"] += 2.0 * r.M * r.N * r.K * r.nz
-        g["launches"] += 1
-    return groups, n
+        for table, k in ((groups, key), (shapes, (r.M, r.N, r.K, r.nz, r.a_layout, r.b_layout, r.tile, r.split_k))):
+            g = table.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
+            g["ms"] += r.ms
+            g["flops"] += 2.0 * r.M * r.N * r.K * r.nz
+            g["launches"] += 1
+    return groups, shapes
 
 
 def cpu_baseline(args):
@@ -183,7 +184,13 @@ def main():
     loss_val = float(loss.float().item())
 
     if rank == 0:
-        groups, nrec = gemm_profile_summary(lib, ffi, max_rec)
+        groups, shapes = gemm_profile_summary(lib, ffi, max_rec)
+        if args.gemm_table:
+            with open(args.gemm_table, "w") as f:
+                f.write("M N K nz aL bL tile splitK launches/step us/launch TF/s ms/step\n")
+                for k, g in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
+                    f.write(" ".join(map(str, k)) + f" {g['launches'] / args.steps:.1f} {g['ms'] / g['launches'] * 1e3:.1f} "
+                            f"{g['flops'] / (g['ms'] * 1e-3) / 1e12:.1f} {g['ms'] / args.steps:.3f}\n")
         ms_per_step = elapsed / args.steps * 1e3
         images = args.batch * world * args.steps
         roofline = None

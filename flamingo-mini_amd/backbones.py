@@ -27,6 +27,39 @@ OPT = {  # hidden, layers, heads, ffn, word_embed_proj_dim, do_layer_norm_before
 }
 
 
+class _PatchConvAsMatmul(torch.nn.Conv2d):
+    """Conv2d whose kernel equals its stride (ViT patch embedding) evaluated as one matmul over unfolded patches.
+    Same parameters / state_dict keys / result; avoids MIOpen's naive bf16 convolution (4.9 ms per call at 32x3x224x224 on
+    MI355X vs ~0.1 ms).  Still stock PyTorch ops - the backbone itself is untouched."""
+
+    def forward(self, x):
+        p = self.kernel_size[0]
+        b, c, h, w = x.shape
+        if self.kernel_size != self.stride or self.padding != (0, 0) or h % p or w % p:
+            return super().forward(x)
+        gh, gw = h // p, w // p
+        patches = x.reshape(b, c, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(b * gh * gw, c * p * p)
+        y = torch.nn.functional.linear(patches, self.weight.reshape(self.out_channels, -1), self.bias)
+        return y.reshape(b, gh, gw, self.out_channels).permute(0, 3, 1, 2)
+
+
+def _tune_vision_encoder(model):
+    vm = getattr(model, "vision_model", model)      # transformers < 5 nests the tower under .vision_model
+    emb = vm.embeddings.patch_embedding
+    if type(emb) is torch.nn.Conv2d:
+        emb.__class__ = _PatchConvAsMatmul
+    return model
+
+
+def _tune_gpt2(model):
+    """HF's NewGELUActivation spells the tanh GELU as ~8 elementwise kernels; torch's fused gelu(approximate='tanh') is the
+    same function in one kernel (forward and backward)."""
+    for block in model.transformer.h:
+        if type(block.mlp.act).__name__ == "NewGELUActivation":
+            block.mlp.act = torch.nn.GELU(approximate="tanh")
+    return model
+
+
 def want_random_init(config) -> bool:
     return bool(getattr(config, "random_init_backbones", False)) or os.environ.get("FLAMINGO_RANDOM_INIT_BACKBONES", "0") == "1"
 
@@ -39,7 +72,7 @@ def _tiny_override(config, key):
 def load_vision_encoder(config):
     from transformers import CLIPVisionConfig, CLIPVisionModel
     if not want_random_init(config):
-        return CLIPVisionModel.from_pretrained(config.clip_model_type)
+        return _tune_vision_encoder(CLIPVisionModel.from_pretrained(config.clip_model_type))
     kw = {}
     if config.clip_model_type in CLIP_VISION:
         hidden, layers, heads, inter, patch, image = CLIP_VISION[config.clip_model_type]
@@ -48,7 +81,7 @@ def load_vision_encoder(config):
     elif not _tiny_override(config, "clip"):
         raise ValueError(f"no built-in architecture for {config.clip_model_type}; known: {sorted(CLIP_VISION)}")
     kw.update(_tiny_override(config, "clip"))
-    return CLIPVisionModel(CLIPVisionConfig(**kw))
+    return _tune_vision_encoder(CLIPVisionModel(CLIPVisionConfig(**kw)))
 
 
 def load_language_model(config):
@@ -57,7 +90,7 @@ def load_language_model(config):
     if not want_random_init(config):
         if name.startswith("gpt2"):
             from transformers import GPT2LMHeadModel
-            return GPT2LMHeadModel.from_pretrained(name)
+            return _tune_gpt2(GPT2LMHeadModel.from_pretrained(name))
         from transformers import OPTForCausalLM
         return OPTForCausalLM.from_pretrained(name)
     if name.startswith("gpt2"):
@@ -69,7 +102,7 @@ def load_language_model(config):
         elif not _tiny_override(config, "lm"):
             raise ValueError(f"no built-in architecture for {name}; known: {sorted(GPT2)}")
         kw.update(_tiny_override(config, "lm"))
-        return GPT2LMHeadModel(GPT2Config(**kw))
+        return _tune_gpt2(GPT2LMHeadModel(GPT2Config(**kw)))
     from transformers import OPTConfig, OPTForCausalLM
     kw = {}
     if name in OPT:

@@ -10,6 +10,7 @@
 // Accumulators are kept transposed (D[n][m] = mfma(Bfrag, Afrag)) so a lane owns 4 consecutive n of one row m
 // and the epilogue issues 8/16-byte row-contiguous loads and stores.
 #include "ff_common.h"
+#include <stdlib.h>
 #include "ff_internal.h"
 
 namespace ff {
@@ -267,6 +268,200 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams P) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 kernel v2: operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, no VGPR staging, no ds_write)
+// into an NS-deep ring; tiles t+1 .. t+NS-2 stay in flight across the single s_barrier of a k-step (counted vmcnt).
+// The LDS-DMA destination is lane-linear (wave base + lane*16 B), so the bank-conflict swizzles live on the SOURCE
+// address: LDS 16-byte slot (row, c') holds global chunk c' ^ swz(row); readers apply the same XOR.
+//   K-major tile  [BR rows][64 k]  : swz = row & 7                       (ds_read_b128 fragment reads)
+//   M-major tile  [64 k][BR rows]  : swz = f(k) spreading the 4 k-rows of a tr-read block (and the two 16-lane
+//                                    groups of a half-wave) over distinct bank ranges   (ds_read_b64_tr_b16 reads)
+// Rows / k beyond the matrix are fetched with an out-of-range buffer offset, which the hardware returns as 0.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned kOobOffset = 0x80000000u;   // >= num_records of every descriptor we build
+
+template <int BR> FF_DEV int mswz(int k) {      // chunk XOR of k-row `k` in an M-major tile
+    if (BR == 128) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);
+    return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);
+}
+
+template <int BR, int LAYOUT>
+FF_DEV void dma_tile(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const RowMap& map, int row_base, int row_lim, int k0, int k_end,
+                     const unsigned* row_off_bytes, int w, int l) {
+    if (LAYOUT == 0) {   // wave instruction = 8 rows x 128 B
+        const int cp = l & 7;
+#pragma unroll
+        for (int p = 0; p < BR / 32; p++) {
+            const int row = p * 32 + w * 8 + (l >> 3);
+            const int k = k0 + ((cp ^ (row & 7)) << 3);
+            unsigned off = row_off_bytes[p] + (unsigned)k * 2u;
+            if (row_base + row >= row_lim || k >= k_end) off = kOobOffset;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + (p * 32 + w * 8) * kBK), 16, off, 0, 0, 0);
+        }
+    } else {             // wave instruction = 1 KiB of consecutive k-rows (BR*2 bytes each)
+        constexpr int CPR = BR / 8;            // 16-byte chunks per k-row
+        constexpr int RPI = 64 / CPR;          // k-rows per wave instruction
+        const int cp = l % CPR;
+#pragma unroll
+        for (int p = 0; p < kBK / (4 * RPI); p++) {
+            const int kr = p * 4 * RPI + w * RPI + l / CPR;
+            const int col = row_base + ((cp ^ mswz<BR>(kr)) << 3);
+            unsigned off = (unsigned)(map.off(min(k0 + kr, k_end - 1)) + col) * 2u;
+            if (k0 + kr >= k_end || col >= row_lim) off = kOobOffset;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + (p * 4 * RPI + w * RPI) * BR), 16, off, 0, 0, 0);
+        }
+    }
+}
+
+
+// Fast path of dma_tile for k-steps that lie fully inside [k_begin, k_end) (and plain row maps for M-major operands):
+// the per-lane byte offsets are loop invariants computed once; a k-step only advances the scalar soffset.
+template <int BR, int LAYOUT>
+FF_DEV void dma_prepare(const RowMap& map, int row_base, int row_lim, int w, int l, unsigned* voff) {
+    if (LAYOUT == 0) {
+        const int cp = l & 7;
+#pragma unroll
+        for (int p = 0; p < BR / 32; p++) {
+            const int row = p * 32 + w * 8 + (l >> 3);
+            voff[p] = row_base + row < row_lim ? (unsigned)map.off(row_base + row) * 2u + (unsigned)((cp ^ (row & 7)) << 4) : kOobOffset;
+        }
+    } else {
+        constexpr int CPR = BR / 8, RPI = 64 / CPR;
+        const int cp = l % CPR;
+#pragma unroll
+        for (int p = 0; p < BR / 32; p++) {
+            const int kr = p * 4 * RPI + w * RPI + l / CPR;
+            const int col = row_base + ((cp ^ mswz<BR>(kr)) << 3);
+            voff[p] = col < row_lim ? (unsigned)((long long)kr * map.ld + col) * 2u : kOobOffset;
+        }
+    }
+}
+template <int BR, int LAYOUT>
+FF_DEV void dma_tile_fast(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const unsigned* voff, unsigned soff, int w) {
+    constexpr int ROWS_PER_PASS_ELEMS = LAYOUT == 0 ? 32 * kBK : (4 * (64 / (BR / 8))) * BR;   // LDS elements covered by one pass of 4 waves
+    constexpr int WAVE_ELEMS = ROWS_PER_PASS_ELEMS / 4;
+#pragma unroll
+    for (int p = 0; p < BR / 32; p++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + p * ROWS_PER_PASS_ELEMS + w * WAVE_ELEMS), 16, voff[p], soff, 0, 0);
+}
+
+template <int BR, int LAYOUT> FF_DEV bf16x8 frag_read2(const bf16* s, int r0, int ks) {
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+    if (LAYOUT == 0) {
+        const int row = r0 + c;
+        const int chunk = ks * 4 + g;
+        return *(const bf16x8*)(s + row * kBK + ((chunk ^ (row & 7)) << 3));
+    } else {
+        const int k = ks * 32 + g * 8 + (c >> 2);
+        const int col = r0 + (c & 3) * 4;
+        const bf16* p = s + k * BR + (((col >> 3) ^ mswz<BR>(k)) << 3) + (col & 7);
+        return cat4(lds_read_tr16(p), lds_read_tr16(p + 4 * BR));   // mswz(k + 4) == mswz(k)
+    }
+}
+
+template <int N> FF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int AL, int BL, int NS>
+__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* smem = (bf16*)smem_raw;
+    constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
+    constexpr int PER_TILE = (AL == 0 ? BM / 32 : BM / 32) + (BL == 0 ? BN / 32 : BN / 32);   // DMA instructions per wave per k-step
+    static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
+
+    const int tiles_m = (P.M + BM - 1) / BM, tiles_n = (P.N + BN - 1) / BN;
+    const TileCoord tc = tile_coord(P, tiles_m, tiles_n);
+    const GemmProblem& pr = P.p[tc.z];
+    const int m_base = tc.tm * BM, n_base = tc.tn * BN;
+    const int k_begin = tc.split * P.k_per_split;
+    const int k_end = min(P.K, k_begin + P.k_per_split);
+    const int t = threadIdx.x, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pr.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)pr.B, 0, 0x7fffffff, 0x00020000);
+
+    unsigned a_off[BM / 32], b_off[BN / 32];
+    if (AL == 0) {
+#pragma unroll
+        for (int p = 0; p < BM / 32; p++) a_off[p] = (unsigned)P.a_map.off(min(m_base + p * 32 + w * 8 + (l >> 3), P.M - 1)) * 2u;
+    }
+    if (BL == 0) {
+#pragma unroll
+        for (int p = 0; p < BN / 32; p++) b_off[p] = (unsigned)P.b_map.off(min(n_base + p * 32 + w * 8 + (l >> 3), P.N - 1)) * 2u;
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (k_end - k_begin + kBK - 1) / kBK;
+    unsigned va[BM / 32], vb[BN / 32];
+    dma_prepare<BM, AL>(P.a_map, m_base, P.M, w, l, va);
+    dma_prepare<BN, BL>(P.b_map, n_base, P.N, w, l, vb);
+    const bool a_plain = AL == 0 || P.a_map.rows_per_seg <= 0, b_plain = BL == 0 || P.b_map.rows_per_seg <= 0;
+    const unsigned a_step = AL == 0 ? 2u : (unsigned)P.a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)P.b_map.ld * 2u;   // bytes per unit of k
+    auto issue = [&](int tile) {
+        bf16* st = smem + (tile % NS) * STAGE;
+        const int k0 = k_begin + tile * kBK;
+        const bool full = k0 + kBK <= k_end;       // wave-uniform
+        if (full && a_plain) dma_tile_fast<BM, AL>(ra, st, va, (unsigned)k0 * a_step, w);
+        else dma_tile<BM, AL>(ra, st, P.a_map, m_base, P.M, k0, k_end, a_off, w, l);
+        if (full && b_plain) dma_tile_fast<BN, BL>(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, w);
+        else dma_tile<BN, BL>(rb, st + A_ELEMS, P.b_map, n_base, P.N, k0, k_end, b_off, w, l);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; s++)
+        if (s < nk) issue(s);
+
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt must have landed; the up to NS-2 younger tiles may stay in flight across the barrier
+        const int younger = min(nk - 1 - kt, NS - 2);
+        if (NS >= 4 && younger == 2) wait_vmcnt<2 * PER_TILE>();
+        else if (NS >= 3 && younger >= 1) wait_vmcnt<PER_TILE>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                       // everyone's pieces of tile kt are in LDS; stage (kt-1)%NS is free
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        const bf16* sA = smem + (kt % NS) * STAGE;
+        const bf16* sB = sA + A_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < kBK / 32; ks++) {
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
+#pragma unroll
+            for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, BL>(sB, wn * WN + j * 16, ks);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
+        }
+    }
+
+    const int c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int m = m_base + wm * WM + i * 16 + c;
+        if (m >= P.M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int n = n_base + wn * WN + j * 16 + g * 4;
+            if (n >= P.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (P.split_k > 1) {
+                float* dst = P.partial + ((long long)(tc.z * P.split_k + tc.split) * P.M + m) * P.N + n;
+                *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                epilogue4<bf16>(P, pr, m, n, v);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp32 kernel (exact): 64x64x16 tiles, LDS tiles always stored [k][row]
 // ------------------------------------------------------------------------------------------------
@@ -462,11 +657,83 @@ static void prof_end(int i, hipStream_t st) {
     if (i >= 0) hipEventRecord(g_prof.ev[2 * i + 1], st);
 }
 
-static bool big_tile(const GemmParams& P) { return (long long)cdiv(P.M, 128) * cdiv(P.N, 128) * P.nz >= 160; }
+// FF_GEMM_TILE=64|128 forces the bf16 block tile (tuning / microbenchmarks only)
+static int g_force_tile = -1, g_force_stages = -1;
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int forced_tile() {
+    if (g_force_tile >= 0) return g_force_tile;
+    static const int v = env_int("FF_GEMM_TILE", 0);
+    return v;
+}
+
+// Block tile and split-K factor for a bf16 problem.  Measured on MI355X (tools/gemm_bench.py --sweep): a k-step's cost
+// is the L2 -> LDS traffic of its operand tiles, so 128x128 (64 FLOP/B) beats 64x64 (32 FLOP/B) whenever it can put
+// >= ~200 workgroups on the chip; long-K problems with few output tiles get there through split-K (fp32 partial slabs
+// + a reduce/epilogue kernel), short-K ones use 64x64 tiles.
+struct TilePlan { int tile, split; };
+static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split) {
+    const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;
+    TilePlan p;
+    const int ft = forced_tile();
+    if (ft == 128 || ft == 64) {
+        p.tile = ft;
+        if (want_split > 0) { p.split = want_split; return p; }
+        const long long t = ft == 128 ? t128 : t64;
+        p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
+        return p;
+    }
+    if (t128 >= 200) p = TilePlan{128, 1};
+    else if (K >= 2048) {
+        int s = (int)std::min<long long>(8, std::max<long long>(2, cdiv(384, t128)));
+        while (s > 1 && K / (64 * s) < 8) s--;
+        p = TilePlan{128, s};
+    } else if (t64 >= 200) p = TilePlan{64, 1};
+    else {
+        int s = (int)std::min<long long>(4, cdiv(256, t64));
+        while (s > 1 && K / (64 * s) < 4) s--;
+        p = TilePlan{64, s};
+    }
+    if (want_split > 0) p.split = want_split;
+    return p;
+}
+static bool big_tile(const GemmParams& P) { return P.tile == 128; }
+
+template <int BM, int BN, int AL, int BL, int NS> static int launch_bf16_dma(const GemmParams& P, hipStream_t st) {
+    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<BM, BN, AL, BL, NS>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm dma lds=%zu): %s", lds, hipGetErrorString(e));
+        }
+        attr_done = true;
+    }
+    const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
+    gemm_bf16_dma_kernel<BM, BN, AL, BL, NS><<<dim3(grid), dim3(256), lds, st>>>(P);
+    return check_launch("gemm_bf16_dma");
+}
+template <int BM, int BN, int NS> static int dispatch_bf16_dma(const GemmParams& P, hipStream_t st) {
+    if (P.a_layout == 0 && P.b_layout == 0) return launch_bf16_dma<BM, BN, 0, 0, NS>(P, st);
+    if (P.a_layout == 0 && P.b_layout == 1) return launch_bf16_dma<BM, BN, 0, 1, NS>(P, st);
+    if (P.a_layout == 1 && P.b_layout == 0) return launch_bf16_dma<BM, BN, 1, 0, NS>(P, st);
+    return launch_bf16_dma<BM, BN, 1, 1, NS>(P, st);
+}
+static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
+    static const int ns_env = env_int("FF_GEMM_STAGES", 0);
+    // default 2 stages: 64 KiB (128x128) / 16 KiB (64x64) per workgroup, so several workgroups per CU overlap each other's
+    // DMA-issue and barrier stalls - measured faster than deeper rings at lower occupancy (tools/gemm_bench.py --sweep)
+    const int ns = g_force_stages > 0 ? g_force_stages : ns_env > 0 ? ns_env : 2;
+    if (big_tile(P)) return ns == 2 ? dispatch_bf16_dma<128, 128, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<128, 128, 4>(P, st) : dispatch_bf16_dma<128, 128, 3>(P, st);
+    return ns == 2 ? dispatch_bf16_dma<64, 64, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<64, 64, 4>(P, st) : dispatch_bf16_dma<64, 64, 3>(P, st);
+}
 
 int gemm_pick_split(int dtype, int M, int N, int K, int nz) {
-    const int bm = dtype == FF_DTYPE_BF16 ? ((long long)cdiv(M, 128) * cdiv(N, 128) * nz >= 160 ? 128 : 64) : kFBM;
-    const long long tiles = (long long)cdiv(M, bm) * cdiv(N, bm) * nz;
+    if (dtype == FF_DTYPE_BF16) return plan_bf16(M, N, K, nz, 0).split;
+    const long long tiles = (long long)cdiv(M, kFBM) * cdiv(N, kFBM) * nz;
     if (tiles >= 128 || K < 1024) return 1;
     int s = (int)(256 / tiles);
     s = std::min(s, K / 512);
@@ -482,7 +749,12 @@ size_t gemm_workspace_bytes(int dtype, int M, int N, int K, int nz, int split_k)
 int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipStream_t st) {
     FF_CHECK(P.M > 0 && P.N > 0 && P.K > 0 && P.nz >= 1 && P.nz <= kGemmMaxZ, FF_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d nz=%d",
              P.M, P.N, P.K, P.nz);
-    if (P.split_k <= 0) P.split_k = gemm_pick_split(dtype, P.M, P.N, P.K, P.nz);
+    P.tile = kFBM;
+    if (dtype == FF_DTYPE_BF16) {
+        const TilePlan plan = plan_bf16(P.M, P.N, P.K, P.nz, P.split_k);
+        P.tile = plan.tile;
+        P.split_k = plan.split;
+    } else if (P.split_k <= 0) P.split_k = gemm_pick_split(dtype, P.M, P.N, P.K, P.nz);
     const int kq = dtype == FF_DTYPE_BF16 ? kBK : kFBK;
     P.k_per_split = cdiv(cdiv(P.K, P.split_k), kq) * kq;
     P.split_k = cdiv(P.K, P.k_per_split);
@@ -503,16 +775,24 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.b_vec_ok = P.b_vec_ok && ((uintptr_t)P.p[z].B % 16 == 0);
     }
     int rc;
-    const int prof_id = prof_begin(P, dtype, dtype == FF_DTYPE_BF16 ? (big_tile(P) ? 128 : 64) : kFBM, st);
+    const int prof_id = prof_begin(P, dtype, P.tile, st);
     if (dtype == FF_DTYPE_BF16) {
         FF_CHECK(P.a_vec_ok && P.b_vec_ok, FF_ERR_UNSUPPORTED,
                  "bf16 gemm needs 16-byte aligned operands with contiguous dims %% 8 == 0 (M=%d N=%d K=%d)", P.M, P.N, P.K);
         FF_CHECK(P.N % 4 == 0 && P.c_map.ld % 4 == 0, FF_ERR_UNSUPPORTED, "bf16 gemm needs N %% 4 == 0 (N=%d)", P.N);
-        rc = big_tile(P) ? dispatch_bf16<128, 128>(P, st) : dispatch_bf16<64, 64>(P, st);
+        static const int version = env_int("FF_GEMM_V", 2);
+        // v2 addresses operands through 32-bit buffer offsets: fall back to v1 for (never seen) spans >= 1 GiB elements
+        auto span_ok = [&](const RowMap& m, int rows, int contig) {
+            const long long last = (m.rows_per_seg > 0 ? (long long)((rows - 1) / m.rows_per_seg) * m.seg_stride + (long long)((rows - 1) % m.rows_per_seg) * m.ld
+                                                      : (long long)(rows - 1) * m.ld) + contig;
+            return last < (1LL << 30);
+        };
+        const bool small = span_ok(P.a_map, P.a_layout == 0 ? P.M : P.K, a_contig) && span_ok(P.b_map, P.b_layout == 0 ? P.N : P.K, b_contig);
+        if (version >= 2 && small) rc = run_bf16_dma(P, st);
+        else rc = big_tile(P) ? dispatch_bf16<128, 128>(P, st) : dispatch_bf16<64, 64>(P, st);
     } else {
         rc = dispatch_f32(P, st);
     }
-    prof_end(prof_id, st);   // main kernel only: the split-K epilogue is a separate (HBM-bound) kernel
     FF_TRY(rc);
     if (P.split_k > 1) {
         const long long total = (long long)P.nz * P.M * ((P.N + 3) / 4);
@@ -521,6 +801,7 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         else hipLaunchKernelGGL(gemm_splitk_epilogue_kernel<float>, dim3(grid), dim3(256), 0, st, P);
         FF_TRY(check_launch("gemm_splitk_epilogue"));
     }
+    prof_end(prof_id, st);   // a record covers the main kernel and, for split-K, its reduce/epilogue kernel
     return FF_OK;
 }
 
@@ -579,4 +860,9 @@ extern "C" int ff_gemm_profile_read(ff_gemm_profile_record* out, int max_records
     }
     g_prof.n = 0;
     return n;
+}
+
+extern "C" void ff_gemm_set_tuning(int tile, int stages) {   /* tuning / microbenchmarks: 0 = automatic */
+    ff::g_force_tile = tile > 0 ? tile : -1;
+    ff::g_force_stages = stages > 0 ? stages : -1;
 }

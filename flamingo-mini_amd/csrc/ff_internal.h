@@ -23,6 +23,7 @@ struct GemmParams {
     float scale;
     int act, act_bwd;
     int split_k, k_per_split;
+    int tile;   // block tile edge chosen by the host (bf16: 64 or 128)
     float* partial;
     int a_vec_ok, b_vec_ok;
     int nz;

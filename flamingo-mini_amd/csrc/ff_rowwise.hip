@@ -230,8 +230,16 @@ __global__ __launch_bounds__(256) void col_reduce_final_kernel(int nsplit, int n
                                                                const float* __restrict__ partial, T* out0, T* out1) {
     const long long total = (long long)ngroups * nslots * cols;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < nsplit; s++) v += partial[(long long)s * total + idx];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;     // independent chains: keep 4+ loads in flight per thread
+        int s = 0;
+        for (; s + 4 <= nsplit; s += 4) {
+            v0 += partial[(long long)s * total + idx];
+            v1 += partial[(long long)(s + 1) * total + idx];
+            v2 += partial[(long long)(s + 2) * total + idx];
+            v3 += partial[(long long)(s + 3) * total + idx];
+        }
+        for (; s < nsplit; s++) v0 += partial[(long long)s * total + idx];
+        const float v = (v0 + v1) + (v2 + v3);
         const int c = (int)(idx % cols);
         const long long gs = idx / cols;
         const int slot = (int)(gs % nslots), g = (int)(gs / nslots);
@@ -321,8 +329,8 @@ int layernorm_fwd(const LnArgs& a, const void* x, const void* add, const void* g
 }
 
 static void split_plan(int n_rows_in_group, int col_blocks, int ngroups, int& rows_per_split, int& nsplit) {
-    int target = std::max(1, 1024 / std::max(1, col_blocks * ngroups));
-    nsplit = std::max(1, std::min(target, cdiv(n_rows_in_group, 16)));
+    int target = std::max(1, 512 / std::max(1, col_blocks * ngroups));
+    nsplit = std::max(1, std::min(std::min(target, 32), cdiv(n_rows_in_group, 32)));
     rows_per_split = cdiv(n_rows_in_group, nsplit);
     nsplit = cdiv(n_rows_in_group, rows_per_split);
 }

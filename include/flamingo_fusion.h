@@ -82,6 +82,8 @@ typedef struct ff_gemm_profile_record {
 } ff_gemm_profile_record;
 int ff_gemm_profile_enable(int max_records);
 int ff_gemm_profile_read(ff_gemm_profile_record* out, int max_records);
+/* Tuning aid: force the bf16 block tile (64 / 128) and LDS ring depth (2..4); 0 = automatic choice. */
+void ff_gemm_set_tuning(int tile, int stages);
 
 /* ------------------------------------------------------------------------------------------------------
  * LayerNorm over the last axis (eps inside the sqrt, biased variance: torch.nn.LayerNorm).

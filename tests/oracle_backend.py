@@ -20,20 +20,32 @@ def _np(t):
     return t.detach().double().numpy()
 
 
+def _emit_flat(grads_np, keys, like):
+    """Mirror the product's backward: all parameter gradients of a fused module live in ONE flat buffer whose slices
+    become param.grad, and the grad-ready callbacks (data-parallel reducer) are told about it."""
+    from flamingo_mini_amd import functional as F
+    flat, views = F._flat_grads(like)
+    for v, k in zip(views, keys):
+        v.copy_(torch.from_numpy(np.asarray(grads_np[k])).to(v.dtype).reshape(v.shape))
+    for cb in F._grad_ready_callbacks:
+        cb(flat)
+    return tuple(views)
+
+
 class _Rs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cfg, *params):
         depth, heads, dim_head, q, nte, ffm, act = cfg
         p = dict(zip(rs_keys(depth), map(_np, params)))
         y, cache = O.resampler_fwd(_np(x), p, heads=heads, dim_head=dim_head, act=act)
-        ctx.stuff = (cache, p, cfg, x.dtype, [t.dtype for t in params])
+        ctx.stuff = (cache, p, cfg, x.dtype, [torch.empty_like(t) for t in params])
         return torch.from_numpy(y).to(x.dtype)
 
     @staticmethod
     def backward(ctx, dy):
-        cache, p, cfg, xdt, pdts = ctx.stuff
+        cache, p, cfg, xdt, like = ctx.stuff
         dx, g = O.resampler_bwd(_np(dy), cache, p, heads=cfg[1], dim_head=cfg[2], act=cfg[6])
-        return (torch.from_numpy(dx).to(xdt), None) + tuple(torch.from_numpy(g[k]).to(dt) for k, dt in zip(rs_keys(cfg[0]), pdts))
+        return (torch.from_numpy(dx).to(xdt), None) + _emit_flat(g, rs_keys(cfg[0]), like)
 
 
 class _Xa(torch.autograd.Function):
@@ -43,15 +55,14 @@ class _Xa(torch.autograd.Function):
         p = dict(zip(XA_KEYS, map(_np, params)))
         ml = np.diff(tt.numpy().astype(np.int64), axis=1, prepend=0)       # text_time back to 0/1 tags
         out, kv, cache = O.gated_xattn_block_fwd(_np(y), _np(vf), ml, p, heads=heads, dim_head=dim_head, act=act, n_visual=n_visual)
-        ctx.stuff = (cache, p, cfg, y.dtype, [t.dtype for t in params])
+        ctx.stuff = (cache, p, cfg, y.dtype, [torch.empty_like(t) for t in params])
         return torch.from_numpy(out).to(y.dtype), torch.from_numpy(kv[0]).to(y.dtype), torch.from_numpy(kv[1]).to(y.dtype)
 
     @staticmethod
     def backward(ctx, dout, _dk, _dv):
-        cache, p, cfg, ydt, pdts = ctx.stuff
+        cache, p, cfg, ydt, like = ctx.stuff
         dy, dvf, g = O.gated_xattn_block_bwd(_np(dout), cache, p, heads=cfg[0], dim_head=cfg[1], act=cfg[3])
-        return (torch.from_numpy(dy).to(ydt), torch.from_numpy(dvf).to(ydt), None, None, None) + \
-            tuple(torch.from_numpy(g[k]).to(dt) for k, dt in zip(XA_KEYS, pdts))
+        return (torch.from_numpy(dy).to(ydt), torch.from_numpy(dvf).to(ydt), None, None, None) + _emit_flat(g, XA_KEYS, like)
 
 
 class OracleBackend:

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <math.h>
+#include <stdlib.h>
 #include "ff_common.h"
 #include "ff_internal.h"
 
@@ -24,6 +25,64 @@ int check_launch(const char* what) {
     }
     return FF_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Fork / join onto a library-owned side stream.  The weight-gradient GEMMs (and gate-gradient reductions) of a
+// backward pass are not on its critical path and no single GEMM of these sizes fills 256 CUs, so they run
+// concurrently with the data-gradient chain when FF_OVERLAP=1.  Measured on MI355X at config B: no gain (57.1 vs 56.8 ms
+// per step) - the GEMMs are bound by chip-wide operand-tile traffic, so concurrent kernels only slow each other down -
+// hence OFF by default (everything on the caller's stream).  Ordering is by events only.  The side stream joins the caller's stream before the entry point returns.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct SideState {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[64];
+    int next = 0;
+    bool ready = false;
+};
+SideState g_side[16];
+bool overlap_enabled() {
+    static const int v = [] { const char* e = getenv("FF_OVERLAP"); return e ? atoi(e) : 0; }();
+    return v != 0;
+}
+}  // namespace
+
+class Fork {
+  public:
+    explicit Fork(hipStream_t main) : main_(main), side_(main), st_(nullptr) {
+        if (!overlap_enabled()) return;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+        SideState& s = g_side[dev];
+        if (!s.ready) {
+            if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return;
+            for (auto& e : s.ev)
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
+            s.ready = true;
+        }
+        st_ = &s;
+        side_ = s.stream;
+        side_after_main();
+    }
+    ~Fork() { join(); }
+    hipStream_t side() const { return side_; }
+    bool active() const { return st_ != nullptr; }
+    void side_after_main() { link(main_, side_); }    // side stream waits for everything enqueued on main so far
+    void join() {                                     // main waits for everything enqueued on the side stream so far
+        link(side_, main_);
+    }
+
+  private:
+    void link(hipStream_t from, hipStream_t to) {
+        if (!st_) return;
+        hipEvent_t e = st_->ev[st_->next++ & 63];
+        hipEventRecord(e, from);
+        hipStreamWaitEvent(to, e, 0);
+    }
+    hipStream_t main_, side_;
+    SideState* st_;
+};
 
 static LnArgs ln_args(int dtype, int rows, int cols, RowMap x, RowMap y, RowMap dx) {
     LnArgs a;
@@ -86,7 +145,7 @@ static size_t rs_saved_layout(const RsDims& s, void* base, size_t cap, RsSaved& 
 }
 
 struct RsScratch {
-    void *dx, *dH, *dxn, *dO, *dQs, *dK, *dV, *dkv, *dln, *dxf, *ws;
+    void *dx, *dx_b, *dH, *dxn, *dO, *dQs, *dK, *dV, *dkv, *dln, *dxf, *ws, *ws2, *dx_mid;
     size_t ws_bytes;
 };
 static size_t rs_ws_bytes(const RsDims& s) {
@@ -107,8 +166,12 @@ static size_t rs_scratch_layout(const RsDims& s, void* base, size_t cap, bool bw
     const size_t rows_q = (size_t)s.Bn * s.q, rows_kv = (size_t)s.Bn * s.R;
     o.ws_bytes = rs_ws_bytes(s);
     o.ws = a.take(o.ws_bytes);
+    o.ws2 = nullptr; o.dx_mid = nullptr;
     if (bwd) {
+        o.ws2 = a.take(o.ws_bytes);                 // workspace of the side stream
+        o.dx_mid = a.take(rows_q * s.D * s.es);     // d x_mid is read by side-stream GEMMs while d x_in is produced
         o.dx = a.take(rows_q * s.D * s.es);
+        o.dx_b = a.take(rows_q * s.D * s.es);
         o.dH = a.take(rows_q * s.ffi * s.es);
         o.dxn = a.take(rows_q * s.D * s.es);
         o.dO = a.take(rows_q * s.inner * s.es);
@@ -215,8 +278,17 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
     float* attn_ws = (float*)((char*)W.ws + W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4));
     const size_t gws = W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4);
 
+    // Weight gradients go to the side stream (`sd`, workspace ws2); the data-gradient chain stays on `st`.  d x ping-pongs
+    // between two buffers (dx_in -> dx_mid -> dx_out) so nothing the side stream still reads is overwritten; the side
+    // stream is joined at the end of every layer.
+    Fork fork(st);
+    hipStream_t sd = fork.side();
+    void* ws2 = fork.active() ? W.ws2 : W.ws;
+    void* dx_in = W.dx;
+    void* dx_out = W.dx_b;
+
     // final norm (:187)
-    FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), dout, S.x_last, nullptr, P[2], S.mean_o, S.rstd_o, W.dx, nullptr, G[2], G[3],
+    FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), dout, S.x_last, nullptr, P[2], S.mean_o, S.rstd_o, dx_in, nullptr, G[2], G[3],
                          W.ws, gws, st));
     for (int l = s.depth - 1; l >= 0; l--) {
         const void* const* p = P + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
@@ -227,38 +299,44 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
         const char* kv_lat_base = (const char*)L.kv_in + (size_t)s.F * s.D * s.es;
         char* dkv_lat_base = (char*)W.dkv + (size_t)s.F * s.D * s.es;
 
+        fork.side_after_main();                                                                // dx_in ready
         // ---- FeedForward backward (x_next = x_mid + W3 act(W1 LN(x_mid))) ----
-        FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(1, pF).c(pF).act_bwd(s.act).problem(W.dx, p[11], W.dH, nullptr, L.Hpre).run(W.ws, gws, st));
-        FF_TRY(Gemm(s.dt, s.D, s.ffi, Mq).a(1, pD).b(1, pF).c(pF).problem(W.dx, L.Aact, g[11]).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, s.D, s.ffi, Mq).a(1, pD).b(1, pF).c(pF).problem(dx_in, L.Aact, g[11]).run(ws2, gws, sd));
+        FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(1, pF).c(pF).act_bwd(s.act).problem(dx_in, p[11], W.dH, nullptr, L.Hpre).run(W.ws, gws, st));
+        fork.side_after_main();                                                                // dH ready
+        FF_TRY(Gemm(s.dt, s.ffi, s.D, Mq).a(1, pF).b(1, pD).c(pD).problem(W.dH, L.xn_f, g[10]).run(ws2, gws, sd));
         FF_TRY(Gemm(s.dt, Mq, s.D, s.ffi).a(0, pF).b(1, pD).c(pD).problem(W.dH, p[10], W.dxn).run(W.ws, gws, st));
-        FF_TRY(Gemm(s.dt, s.ffi, s.D, Mq).a(1, pF).b(1, pD).c(pD).problem(W.dH, L.xn_f, g[10]).run(W.ws, gws, st));
-        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), W.dxn, L.x_mid, nullptr, p[8], L.mean_f, L.rstd_f, W.dx, W.dx, g[8], g[9],
-                             W.ws, gws, st));                                           // W.dx is now d x_mid
+        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), W.dxn, L.x_mid, nullptr, p[8], L.mean_f, L.rstd_f, W.dx_mid, dx_in, g[8], g[9],
+                             W.ws, gws, st));                                                  // W.dx_mid = d x_mid
         // ---- attention backward (x_mid = x_in + Wo O) ----
-        FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, pD).b(1, pI).c(pI).problem(W.dx, p[7], W.dO).run(W.ws, gws, st));
-        FF_TRY(Gemm(s.dt, s.D, s.inner, Mq).a(1, pD).b(1, pI).c(pI).problem(W.dx, L.O, g[7]).run(W.ws, gws, st));
+        fork.side_after_main();                                                                // dx_mid ready
+        FF_TRY(Gemm(s.dt, s.D, s.inner, Mq).a(1, pD).b(1, pI).c(pI).problem(W.dx_mid, L.O, g[7]).run(ws2, gws, sd));
+        FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, pD).b(1, pI).c(pI).problem(W.dx_mid, p[7], W.dO).run(W.ws, gws, st));
         FF_TRY(attention_bwd(rs_attn_desc(s), L.Qs, L.K, L.V, nullptr, L.O, W.dO, L.lse, W.dQs, W.dK, W.dV, attn_ws,
                              (size_t)s.Bn * s.H * s.q * 4, st));
+        fork.side_after_main();                                                                // dQs, dK, dV ready
         // d to_q, d to_k, d to_v
-        FF_TRY(Gemm(s.dt, s.inner, s.D, Mq).a(1, pI).b(1, kv_lat).c(pD).scale(s.scale).problem(W.dQs, kv_lat_base, g[4]).run(W.ws, gws, st));
-        FF_TRY(Gemm(s.dt, s.inner, s.D, Mkv).a(1, pI).b(1, pD).c(pD).problem(W.dK, L.kv_in, g[5]).problem(W.dV, L.kv_in, g[6]).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, s.inner, s.D, Mq).a(1, pI).b(1, kv_lat).c(pD).scale(s.scale).problem(W.dQs, kv_lat_base, g[4]).run(ws2, gws, sd));
+        FF_TRY(Gemm(s.dt, s.inner, s.D, Mkv).a(1, pI).b(1, pD).c(pD).problem(W.dK, L.kv_in, g[5]).problem(W.dV, L.kv_in, g[6]).run(ws2, gws, sd));
         // d kv_in = dK Wk + dV Wv
         FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(W.dK, p[5], W.dkv).run(W.ws, gws, st));
         FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(W.dV, p[6], W.dkv, nullptr, nullptr, W.dkv).run(W.ws, gws, st));
         // d LN(latents) = scale * dQs Wq + d kv_in[latent rows]
         FF_TRY(Gemm(s.dt, Mq, s.D, s.inner).a(0, pI).b(1, pD).c(pD).res_map(kv_lat).scale(s.scale)
                    .problem(W.dQs, p[4], W.dln, nullptr, nullptr, dkv_lat_base).run(W.ws, gws, st));
-        // norm_latents backward, accumulated onto the residual path: W.dx becomes d x_in
-        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, x_map, pD, pD), W.dln, x_in, nullptr, p[2], L.mean_l, L.rstd_l, W.dx, W.dx, g[2], g[3],
+        // norm_latents backward, accumulated onto the residual path: dx_out = d x_in
+        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, x_map, pD, pD), W.dln, x_in, nullptr, p[2], L.mean_l, L.rstd_l, dx_out, W.dx_mid, g[2], g[3],
                              W.ws, gws, st));
         {   // norm_media backward: d x_f accumulates over the layers (needed for d time_pos_emb even with CLIP frozen)
             LnArgs a = ln_args(s.dt, Mf, s.D, pD, kv_media, pD);
             a.add_rows_per_seg = s.F; a.add_div = s.v;
             FF_TRY(layernorm_bwd(a, W.dkv, x_f, tpe, p[0], S.mean_m, S.rstd_m, dxf, l == s.depth - 1 ? nullptr : dxf, g[0], g[1], W.ws, gws, st));
         }
+        fork.join();                                // this layer's weight gradients are done before its buffers are reused
+        std::swap(dx_in, dx_out);
     }
     // d latents = sum over the batch of d x_0 (:179);  d time_pos_emb[t] = sum_{b, n} d x_f[b, t, n] (:166)
-    FF_TRY(rows_reduce(s.dt, Mq, s.D, pD, s.q, 1, W.dx, G[0], W.ws, gws, st));
+    FF_TRY(rows_reduce(s.dt, Mq, s.D, pD, s.q, 1, dx_in, G[0], W.ws, gws, st));
     if (s.nte > s.T) {
         hipError_t e = hipMemsetAsync((char*)G[1] + (size_t)s.T * s.D * s.es, 0, (size_t)(s.nte - s.T) * s.D * s.es, st);
         FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "resampler_bwd: memset: %s", hipGetErrorString(e));
@@ -306,7 +384,7 @@ static size_t xa_saved_layout(const XaDims& s, void* base, size_t cap, XaSaved& 
     return align_up(a.used);
 }
 struct XaScratch {
-    void *dy1, *dH, *dxn, *dO, *dQs, *dKV, *dyn, *ws;
+    void *dy1, *dH, *dxn, *dO, *dQs, *dKV, *dyn, *ws, *ws2;
     size_t ws_bytes;
 };
 static size_t xa_ws_bytes(const XaDims& s) {
@@ -324,7 +402,9 @@ static size_t xa_scratch_layout(const XaDims& s, void* base, size_t cap, bool bw
     const size_t M = (size_t)s.b * s.L;
     o.ws_bytes = xa_ws_bytes(s);
     o.ws = a.take(o.ws_bytes);
+    o.ws2 = nullptr;
     if (bwd) {
+        o.ws2 = a.take(o.ws_bytes);                 // workspace of the side stream
         o.dy1 = a.take(M * s.d * s.es);
         o.dH = a.take(M * s.ffi * s.es);
         o.dxn = a.take(M * s.d * s.es);
@@ -405,26 +485,34 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     const size_t gws = W.ws_bytes - attn_ws_bytes;
     float* attn_ws = (float*)((char*)W.ws + gws);
 
+    // Weight gradients / gate gradients go to the side stream (`sd`, workspace ws2); the data-gradient chain stays on `st`.
+    Fork fork(st);
+    hipStream_t sd = fork.side();
+    void* ws2 = fork.active() ? W.ws2 : W.ws;
     // ---- y2 = y1 + tanh(alpha_ffw) * ffw(y1) ----
-    FF_TRY(gate_grad(s.dt, M, s.d, dy2, S.ffw_out, P[1], G[1], W.ws, gws, st));
+    FF_TRY(gate_grad(s.dt, M, s.d, dy2, S.ffw_out, P[1], G[1], ws2, gws, sd));
+    FF_TRY(Gemm(s.dt, s.d, s.ffi, M).a(1, pd).b(1, pF).c(pF).problem(dy2, S.Aact, G[10], nullptr, nullptr, nullptr, P[1]).run(ws2, gws, sd));
     FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(1, pF).c(pF).act_bwd(s.act).problem(dy2, P[10], W.dH, nullptr, S.Hpre, nullptr, P[1]).run(W.ws, gws, st));
-    FF_TRY(Gemm(s.dt, s.d, s.ffi, M).a(1, pd).b(1, pF).c(pF).problem(dy2, S.Aact, G[10], nullptr, nullptr, nullptr, P[1]).run(W.ws, gws, st));
+    fork.side_after_main();                                                                    // dH ready
+    FF_TRY(Gemm(s.dt, s.ffi, s.d, M).a(1, pF).b(1, pd).c(pd).problem(W.dH, S.xn_f, G[9]).run(ws2, gws, sd));
     FF_TRY(Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(1, pd).c(pd).problem(W.dH, P[9], W.dxn).run(W.ws, gws, st));
-    FF_TRY(Gemm(s.dt, s.ffi, s.d, M).a(1, pF).b(1, pd).c(pd).problem(W.dH, S.xn_f, G[9]).run(W.ws, gws, st));
     FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, W.dy1, dy2, G[7], G[8], W.ws, gws, st));
     // ---- y1 = y + tanh(alpha_attn) * to_out(attention) ----
-    FF_TRY(gate_grad(s.dt, M, s.d, W.dy1, S.attn_out, P[0], G[0], W.ws, gws, st));
+    fork.side_after_main();                                                                    // dy1 ready
+    FF_TRY(gate_grad(s.dt, M, s.d, W.dy1, S.attn_out, P[0], G[0], ws2, gws, sd));
+    FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(W.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(ws2, gws, sd));
     FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(W.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
-    FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(W.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
     char* dK = (char*)W.dKV;
     char* dV = dK + (size_t)s.inner * s.es;
     FF_TRY(attention_bwd(xa_attn_desc(*d, s, false), S.Qs, S.KV, (const char*)S.KV + (size_t)s.inner * s.es, tt, S.O, W.dO, S.lse, W.dQs, dK,
                          dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
-    FF_TRY(Gemm(s.dt, s.inner, s.d, M).a(1, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, S.yn, G[4]).run(W.ws, gws, st));
+    fork.side_after_main();                                                                    // dQs, dKV ready
+    FF_TRY(Gemm(s.dt, s.inner, s.d, M).a(1, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, S.yn, G[4]).run(ws2, gws, sd));
+    FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(ws2, gws, sd));
+    if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(ws2, gws, sd));
     FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, P[4], W.dyn).run(W.ws, gws, st));
-    FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(W.ws, gws, st));
-    if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(W.ws, gws, st));
     return layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, W.dy1, G[2], G[3], W.ws, gws, st);
+    // ~Fork joins the side stream into `st`
 }
 
 }  // namespace ff

@@ -678,10 +678,10 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split) {
     const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;
     TilePlan p;
     const int ft = forced_tile();
-    if (ft == 128 || ft == 64) {
+    if (ft == 128 || ft == 64 || ft == 6412) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
-        const long long t = ft == 128 ? t128 : t64;
+        const long long t = ft == 128 ? t128 : ft == 64 ? t64 : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
         p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
         return p;
     }
@@ -722,13 +722,17 @@ template <int BM, int BN, int NS> static int dispatch_bf16_dma(const GemmParams&
     if (P.a_layout == 1 && P.b_layout == 0) return launch_bf16_dma<BM, BN, 1, 0, NS>(P, st);
     return launch_bf16_dma<BM, BN, 1, 1, NS>(P, st);
 }
+template <int BM, int BN> static int run_bf16_dma_tile(const GemmParams& P, int ns, hipStream_t st) {
+    return ns == 2 ? dispatch_bf16_dma<BM, BN, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<BM, BN, 4>(P, st) : dispatch_bf16_dma<BM, BN, 3>(P, st);
+}
 static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     static const int ns_env = env_int("FF_GEMM_STAGES", 0);
     // default 2 stages: 64 KiB (128x128) / 16 KiB (64x64) per workgroup, so several workgroups per CU overlap each other's
     // DMA-issue and barrier stalls - measured faster than deeper rings at lower occupancy (tools/gemm_bench.py --sweep)
     const int ns = g_force_stages > 0 ? g_force_stages : ns_env > 0 ? ns_env : 2;
-    if (big_tile(P)) return ns == 2 ? dispatch_bf16_dma<128, 128, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<128, 128, 4>(P, st) : dispatch_bf16_dma<128, 128, 3>(P, st);
-    return ns == 2 ? dispatch_bf16_dma<64, 64, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<64, 64, 4>(P, st) : dispatch_bf16_dma<64, 64, 3>(P, st);
+    if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
+    if (P.tile == 6412) return run_bf16_dma_tile<64, 128>(P, ns, st);
+    return run_bf16_dma_tile<64, 64>(P, ns, st);
 }
 
 int gemm_pick_split(int dtype, int M, int N, int K, int nz) {

@@ -1,0 +1,127 @@
+"""Parity at the geometry of every BASELINE.json config, and size-independent properties at config B's FULL size.
+
+Configs C/D/E are run at their real feature sizes with a reduced batch so the float64 oracle finishes in
+seconds; config B's full size (batch 32) is covered by properties that need no oracle:
+  * fp32-vs-bf16 self-consistency of the HIP path (the fp32 path is oracle-checked at smaller batch),
+  * backward linearity  bwd(a*g1 + b*g2) == a*bwd(g1) + b*bwd(g2),
+  * batch independence  f(x)[i] == f(x[i:i+1]) (samples never interact: no cross-sample reduction in any kernel).
+"""
+import numpy as np
+import pytest
+import torch
+
+from detgen import det, resampler_params, xattn_params
+from oracle import flamingo_oracle as O
+from test_hip_modules import build_block, build_resampler
+from util import TOL, as64, dev, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_block(dtype, dim, dv, b, L, N, ml, act="gelu", tag="cfg"):
+    p = xattn_params(dim, dv, 8, 64, 4, tag=tag)
+    m = build_block(p, dim, dv, 8, 64, 64, 4, act, dtype)
+    yd = dev(det((b, L, dim), tag + "y"), dtype).requires_grad_(True)
+    vfd = dev(det((b, N, 64, dv), tag + "vf"), dtype).requires_grad_(True)
+    dyd = dev(det((b, L, dim), tag + "dy"), dtype)
+    out, _ = m(yd, vfd, torch.as_tensor(ml).cuda())
+    out.backward(dyd)
+    p64 = {k: as64(v) for k, v in m.state_dict().items()}
+    outr, _, cache = O.gated_xattn_block_fwd(as64(yd), as64(vfd), ml, p64, act=act)
+    dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd), cache, p64, act=act)
+    t = TOL[dtype]
+    assert rel(out - yd, outr - as64(yd)) < t["out"] * 2
+    assert rel(yd.grad, dyr) < t["grad"] and rel(vfd.grad, dvfr) < t["grad"]
+    for k in ("attn.to_q.weight", "attn.to_kv.weight", "attn.to_out.weight", "ffw.1.weight", "ffw.3.weight", "attn.norm.weight", "ffw.0.bias"):
+        assert rel(dict(m.named_parameters())[k].grad, gr[k]) < t["grad"], k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_config_C_opt_1p3b_block(dtype):
+    """facebook/opt-1.3b geometry: dim 2048, dim_visual 1024, L = 32 (batch 2 of 32)."""
+    ml = np.zeros((2, 32), np.int64); ml[:, 0] = 1
+    _check_block(dtype, 2048, 1024, 2, 32, 1, ml, tag="C")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_config_E_opt_6p7b_fewshot_block(dtype):
+    """facebook/opt-6.7b geometry: dim 4096, 4 images, L = 1024 with tags at 0/256/512/768 (batch 1)."""
+    ml = np.zeros((1, 1024), np.int64); ml[0, [0, 256, 512, 768]] = 1
+    _check_block(dtype, 4096, 1024, 1, 1024, 4, ml, tag="E")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_config_D_video_resampler(dtype):
+    """video path: 4 frames x 257 CLIP-L tokens flattened into 1092 keys, num_time_embeds = 4, depth 6 (batch 1)."""
+    dim, depth = 1024, 6
+    p = resampler_params(dim, depth, 8, 64, 64, 4, 4, tag="D")
+    m = build_resampler(p, dim, depth, 8, 64, 64, 4, 4, "gelu", dtype)
+    xd = dev(det((1, 4, 257, dim), "D-x"), dtype).requires_grad_(True)
+    dyd = dev(det((1, 64, dim), "D-dy"), dtype)
+    y = m(xd)
+    y.backward(dyd)
+    p64 = {k: as64(v) for k, v in m.state_dict().items()}
+    yr, cache = O.resampler_fwd(as64(xd), p64)
+    dxr, gr = O.resampler_bwd(as64(dyd), cache, p64)
+    t = TOL[dtype]
+    f = 3 if dtype == torch.bfloat16 else 1          # six stacked bf16 layers: the reference's own bf16 error grows the same way
+    assert rel(y, yr) < t["out"] * f
+    assert rel(xd.grad, dxr) < t["grad"] * f
+    for k in ("time_pos_emb", "latents", "layers.0.0.to_k.weight", "layers.5.1.3.weight", "layers.2.0.norm_media.weight", "norm.bias"):
+        assert rel(dict(m.named_parameters())[k].grad, gr[k]) < t["grad"] * f, k
+    with pytest.raises(RuntimeError):                 # 5 frames > num_time_embeds (broadcast error in the reference, :166)
+        m(dev(det((1, 5, 10, dim), "D-x5"), dtype))
+
+
+def test_config_B_full_size_properties():
+    """flamingo-mini sizes, batch 32: resampler (32, 1, 257, 1024) depth 6 and one gpt2-large block (32, 32, 1280)."""
+    dim, dv, b, L = 1280, 1024, 32, 32
+    rp = resampler_params(dv, 6, 8, 64, 64, 4, 4, tag="B")
+    xp = xattn_params(dim, dv, 8, 64, 4, tag="B")
+    x = det((b, 1, 257, dv), "B-x")
+    y = det((b, L, dim), "B-y")
+    ml = torch.zeros(b, L, dtype=torch.long, device="cuda"); ml[:, 0] = 1
+    outs = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        rs = build_resampler(rp, dv, 6, 8, 64, 64, 4, 4, "gelu", dtype)
+        blk = build_block(xp, dim, dv, 8, 64, 64, 4, "gelu", dtype)
+        xd = dev(x, dtype).requires_grad_(True)
+        yd = dev(y, dtype).requires_grad_(True)
+        vf = rs(xd)
+        out, _ = blk(yd, vf.reshape(b, 1, 64, dv), ml)
+        g1, g2 = dev(det((b, L, dim), "B-g1"), dtype), dev(det((b, L, dim), "B-g2"), dtype)
+        grads = []
+        for g in (g1, g2, 0.5 * g1 - 2.0 * g2):
+            for t in (xd, yd, *rs.parameters(), *blk.parameters()):
+                t.grad = None
+            out.backward(g, retain_graph=True)
+            grads.append([xd.grad.clone(), yd.grad.clone(), rs.layers[3][0].to_k.weight.grad.clone(), rs.time_pos_emb.grad.clone(),
+                          blk.ffw[1].weight.grad.clone(), blk.alpha_attn.grad.clone()])
+        lin_tol = 1e-5 if dtype == torch.float32 else 2e-2
+        for a, c, comb in zip(*grads):                                            # backward is linear in the incoming gradient
+            assert rel(comb, 0.5 * a.float() - 2.0 * c.float()) < lin_tol
+        with torch.no_grad():                                                     # samples do not interact
+            vf1 = rs(xd[5:6])
+            out1, _ = blk(yd[5:6], vf1.reshape(1, 1, 64, dv), ml[5:6])
+        ind_tol = 1e-5 if dtype == torch.float32 else 1e-2        # not bitwise: batch 1 picks another tile / split-K plan
+        assert rel(vf1, vf[5:6]) < ind_tol and rel(out1 - yd[5:6], out[5:6] - yd[5:6]) < ind_tol * 2
+        outs[dtype] = (vf.detach().float(), (out - yd).detach().float(), grads[0][4].float())
+    f32, b16 = outs[torch.float32], outs[torch.bfloat16]
+    assert rel(b16[0], f32[0]) < 3e-2 and rel(b16[1], f32[1]) < 3e-2 and rel(b16[2], f32[2]) < 6e-2
+
+
+def test_repeated_calls_are_bitwise_deterministic():
+    p = xattn_params(1280, 1024, 8, 64, 4, tag="det")
+    blk = build_block(p, 1280, 1024, 8, 64, 64, 4, "gelu", torch.bfloat16)
+    y = dev(det((8, 32, 1280), "det-y"), torch.bfloat16).requires_grad_(True)
+    vf = dev(det((8, 2, 64, 1024), "det-vf"), torch.bfloat16).requires_grad_(True)
+    ml = torch.zeros(8, 32, dtype=torch.long, device="cuda"); ml[:, [0, 11]] = 1
+    res = []
+    for _ in range(2):
+        for t in (y, vf, *blk.parameters()):
+            t.grad = None
+        out, _ = blk(y, vf, ml)
+        out.backward(torch.ones_like(out))
+        res.append([out.detach().clone(), y.grad.clone(), vf.grad.clone(), blk.ffw[3].weight.grad.clone(), blk.alpha_ffw.grad.clone()])
+    for a, c in zip(*res):
+        assert torch.equal(a, c)

@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
     return ap.parse_args()
 
@@ -91,6 +92,26 @@ def gemm_profile_summary(lib, ffi, max_records):
             g["flops"] += 2.0 * r.M * r.N * r.K * r.nz
             g["launches"] += 1
     return groups, shapes
+
+
+def caption_leg(args, model, batch, device):
+    """Second half of the BASELINE metric: caption tokens/sec.  Prompt = 4 tokens with the media tag at position 0; step 1 runs
+    CLIP + resampler and fills the xattn K/V + LM caches, every later step feeds one token through the cached path."""
+    import torch
+    model.eval()
+    n_new = args.caption_tokens
+    ids, ml, am = batch["input_ids"][:, :4], batch["media_locations"][:, :4], batch["attention_mask"][:, :4]
+    with torch.no_grad():
+        model.greedy_generate(ids, ml, am, pixel_values=batch["pixel_values"], max_length=4 + 4)       # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model.greedy_generate(ids, ml, am, pixel_values=batch["pixel_values"], max_length=4 + n_new)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    model.train()
+    new = out.shape[1] - 4
+    return {"value": round(args.batch * new / dt, 1), "unit": "caption tokens/sec", "batch": args.batch, "new_tokens_per_image": new,
+            "ms_per_decode_step": round(dt / new * 1e3, 2), "note": "greedy, cached xattn K/V + LM cache, includes the prompt/CLIP/resampler step"}
 
 
 def cpu_baseline(args):
@@ -199,7 +220,8 @@ def main():
             is_bf16 = key[0] == ffi.DTYPE_BF16
             peak = MFMA_BF16_DENSE_PEAK_TFLOPS if is_bf16 else MFMA_F32_PEAK_TFLOPS
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            name = (f"gemm_bf16_kernel<{key[1]},{key[1]},{key[2]},{key[3]}>" if is_bf16 else f"gemm_f32_kernel<{key[2]},{key[3]}>")
+            tm, tn = (64, 128) if key[1] == 6412 else (key[1], key[1])
+            name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
             tot_ms = sum(v["ms"] for v in groups.values())
             tot_fl = sum(v["flops"] for v in groups.values())
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -221,6 +243,8 @@ def main():
                        "trainable_params": n_trainable, "loss": round(loss_val, 4)},
             "roofline": roofline,
         }
+        if world == 1 and args.caption_tokens > 0:
+            result["caption"] = caption_leg(args, model, batch, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(result), flush=True)

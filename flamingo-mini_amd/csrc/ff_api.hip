@@ -490,16 +490,19 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     hipStream_t sd = fork.side();
     void* ws2 = fork.active() ? W.ws2 : W.ws;
     // ---- y2 = y1 + tanh(alpha_ffw) * ffw(y1) ----
-    FF_TRY(gate_grad(s.dt, M, s.d, dy2, S.ffw_out, P[1], G[1], ws2, gws, sd));
     FF_TRY(Gemm(s.dt, s.d, s.ffi, M).a(1, pd).b(1, pF).c(pF).problem(dy2, S.Aact, G[10], nullptr, nullptr, nullptr, P[1]).run(ws2, gws, sd));
     FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(1, pF).c(pF).act_bwd(s.act).problem(dy2, P[10], W.dH, nullptr, S.Hpre, nullptr, P[1]).run(W.ws, gws, st));
     fork.side_after_main();                                                                    // dH ready
     FF_TRY(Gemm(s.dt, s.ffi, s.d, M).a(1, pF).b(1, pd).c(pd).problem(W.dH, S.xn_f, G[9]).run(ws2, gws, sd));
     FF_TRY(Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(1, pd).c(pd).problem(W.dH, P[9], W.dxn).run(W.ws, gws, st));
-    FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, W.dy1, dy2, G[7], G[8], W.ws, gws, st));
+    {   // LN(y1) backward -> dy1, with both gate gradients folded in: d alpha_ffw = sum(dy2 . ffw_out), d alpha_attn = sum(dy1 . attn_out)
+        LnDots dots;
+        dots.a = S.ffw_out; dots.alpha_a = P[1]; dots.out_a = G[1];
+        dots.b = S.attn_out; dots.alpha_b = P[0]; dots.out_b = G[0];
+        FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, W.dy1, dy2, G[7], G[8], W.ws, gws, st, &dots));
+    }
     // ---- y1 = y + tanh(alpha_attn) * to_out(attention) ----
     fork.side_after_main();                                                                    // dy1 ready
-    FF_TRY(gate_grad(s.dt, M, s.d, W.dy1, S.attn_out, P[0], G[0], ws2, gws, sd));
     FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(W.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(ws2, gws, sd));
     FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(W.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
     char* dK = (char*)W.dKV;

@@ -72,9 +72,15 @@ struct LnArgs {
 int layernorm_fwd(const LnArgs& a, const void* x, const void* add, const void* gamma, const void* beta, void* y,
                   float* mean, float* rstd, hipStream_t st);
 size_t layernorm_bwd_workspace(int rows, int cols);
+// Optional tanh-gate gradients fused into a LayerNorm backward (same shape / row map as dx):
+//   out_a = (1 - tanh(alpha_a)^2) * sum(dx_residual .* a),   out_b = (1 - tanh(alpha_b)^2) * sum(dx .* b)
+struct LnDots {
+    const void* a = nullptr; const void* alpha_a = nullptr; void* out_a = nullptr;
+    const void* b = nullptr; const void* alpha_b = nullptr; void* out_b = nullptr;
+};
 int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* add, const void* gamma, const float* mean,
                   const float* rstd, void* dx, const void* dx_residual, void* dgamma, void* dbeta, void* ws,
-                  size_t ws_bytes, hipStream_t st);
+                  size_t ws_bytes, hipStream_t st, const LnDots* dots = nullptr);
 size_t rows_reduce_workspace(int rows, int cols, int rows_per_batch, int rows_per_group);
 int rows_reduce(int dtype, int rows, int cols, RowMap x_map, int rows_per_batch, int rows_per_group, const void* x,
                 void* out, void* ws, size_t ws_bytes, hipStream_t st);

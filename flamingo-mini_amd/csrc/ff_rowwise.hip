@@ -150,6 +150,167 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnArgs a, const T*
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused LayerNorm backward: one pass produces dx (+ residual), per-block partial sums of d gamma / d beta, and
+// (optionally) the two tanh-gate dot products of a gated block:
+//     dot_a = sum(dx_residual .* A)   (d alpha of the branch whose output was added AFTER this LayerNorm's input)
+//     dot_b = sum(dx          .* B)   (d alpha of the branch added BEFORE it: dx is this kernel's own output)
+// partial[block][2*cols + 2]; ln_bwd_final_kernel reduces over blocks and applies (1 - tanh(alpha)^2).
+// A wave owns rows (statistics are lane-local + wave reductions), lanes own column chunks across the wave's rows.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a, const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ add, const T* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, T* dx,
+                                                           const T* dx_res, const T* __restrict__ dot_a, const T* __restrict__ dot_b,
+                                                           float* __restrict__ partial, int rows_per_block) {
+    extern __shared__ float sacc[];   // [2][cols]
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nchunk = a.cols / VEC;
+    float accg[NCH][VEC], accb[NCH][VEC];
+#pragma unroll
+    for (int i = 0; i < NCH; i++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) accg[i][e] = accb[i][e] = 0.f;
+    float da = 0.f, db = 0.f;
+    const int row_end = min(a.rows, (int)(blockIdx.x + 1) * rows_per_block);
+    for (int row = blockIdx.x * rows_per_block + w; row < row_end; row += 4) {
+        const T* xr = x + a.x_map.off(row);
+        const T* dyr = dy + a.y_map.off(row);
+        const T* ar = add ? add + (long long)((row % a.add_rows_per_seg) / a.add_div) * a.cols : nullptr;
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float v[VEC], d[VEC], g[VEC];
+                ld<T, VEC>(xr + c * VEC, v);
+                if (ar) {
+                    float t[VEC];
+                    ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) v[e] += t[e];
+                }
+                ld<T, VEC>(dyr + c * VEC, d);
+                ld<T, VEC>(gamma + c * VEC, g);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    const float dyh = d[e] * g[e];
+                    s1 += dyh;
+                    s2 += dyh * (v[e] - mu) * rs;
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)a.cols, m2 = wave_sum(s2) / (float)a.cols;
+        const long long doff = a.dx_map.off(row);
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float v[VEC], d[VEC], g[VEC], o[VEC];
+                ld<T, VEC>(xr + c * VEC, v);
+                if (ar) {
+                    float t[VEC];
+                    ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) v[e] += t[e];
+                }
+                ld<T, VEC>(dyr + c * VEC, d);
+                ld<T, VEC>(gamma + c * VEC, g);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    const float xh = (v[e] - mu) * rs;
+                    o[e] = rs * (d[e] * g[e] - m1 - xh * m2);
+                    accg[i][e] += d[e] * xh;
+                    accb[i][e] += d[e];
+                }
+                if (dx_res) {
+                    float q[VEC];
+                    ld<T, VEC>(dx_res + doff + c * VEC, q);
+                    if (dot_a) {
+                        float u[VEC];
+                        ld<T, VEC>(dot_a + doff + c * VEC, u);
+#pragma unroll
+                        for (int e = 0; e < VEC; e++) da += q[e] * u[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) o[e] += q[e];
+                }
+                if (dx) {
+                    float r[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) r[e] = to_f32(from_f32<T>(o[e]));   // the value the next kernel will read
+                    if (dot_b) {
+                        float u[VEC];
+                        ld<T, VEC>(dot_b + doff + c * VEC, u);
+#pragma unroll
+                        for (int e = 0; e < VEC; e++) db += r[e] * u[e];
+                    }
+                    st<T, VEC>(dx + doff + c * VEC, o);
+                }
+            }
+        }
+    }
+    // cross-wave accumulation of the column partials (waves take turns on the LDS image)
+    for (int ww = 0; ww < 4; ww++) {
+        if (w == ww) {
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int c = lane + 64 * i;
+                if (c < nchunk) {
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) {
+                        const int col = c * VEC + e;
+                        if (ww == 0) { sacc[col] = accg[i][e]; sacc[a.cols + col] = accb[i][e]; }
+                        else { sacc[col] += accg[i][e]; sacc[a.cols + col] += accb[i][e]; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const long long P = 2LL * a.cols + 2;
+    float* out = partial + (long long)blockIdx.x * P;
+    for (int i = threadIdx.x; i < 2 * a.cols; i += 256) out[i] = sacc[i];
+    da = block_sum<4>(da, red);
+    db = block_sum<4>(db, red);
+    if (threadIdx.x == 0) { out[2 * a.cols] = da; out[2 * a.cols + 1] = db; }
+}
+
+// out[idx] = sum over blocks of partial[block][idx]; 64 outputs x 4 block-lanes per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_final_kernel(int nblk, int cols, const float* __restrict__ partial, T* dgamma, T* dbeta,
+                                                           const T* alpha_a, T* out_a, const T* alpha_b, T* out_b) {
+    __shared__ float red[4][64];
+    const int P = 2 * cols + 2;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + tx;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (idx < P) {
+        int b = ty;
+        for (; b + 12 < nblk; b += 16) {
+            v0 += partial[(long long)b * P + idx];
+            v1 += partial[(long long)(b + 4) * P + idx];
+            v2 += partial[(long long)(b + 8) * P + idx];
+            v3 += partial[(long long)(b + 12) * P + idx];
+        }
+        for (; b < nblk; b += 4) v0 += partial[(long long)b * P + idx];
+    }
+    red[ty][tx] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (ty == 0 && idx < P) {
+        const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (idx < cols) { if (dgamma) dgamma[idx] = from_f32<T>(v); }
+        else if (idx < 2 * cols) { if (dbeta) dbeta[idx - cols] = from_f32<T>(v); }
+        else if (idx == 2 * cols) {
+            if (out_a) { const float t = tanhf(to_f32(alpha_a[0])); out_a[0] = from_f32<T>(v * (1.f - t * t)); }
+        } else if (out_b) { const float t = tanhf(to_f32(alpha_b[0])); out_b[0] = from_f32<T>(v * (1.f - t * t)); }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Column reductions.  Block = 64 column-threads (VEC columns each) x 4 row-lanes.
 //   MODE 0: out[g][c]  = sum_{rows of group g} x[r][c]
@@ -293,6 +454,9 @@ template <typename I> __global__ void text_time_kernel(int batch, int n, const I
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+int gate_grad(int dtype, int rows, int cols, const void* a, const void* b, const void* alpha, void* dalpha, void* ws,
+              size_t ws_bytes, hipStream_t st_);
+
 static bool vec_ok(int dtype, int cols, std::initializer_list<RowMap> maps, std::initializer_list<const void*> ptrs) {
     const int n = dtype == FF_DTYPE_BF16 ? 8 : 4;
     if (cols % n) return false;
@@ -342,14 +506,71 @@ static size_t col_reduce_ws(int n_rows_in_group, int cols, int ngroups, int nslo
     return (size_t)ns * ngroups * nslots * cols * sizeof(float);
 }
 
-size_t layernorm_bwd_workspace(int rows, int cols) { return col_reduce_ws(rows, cols, 1, 2); }
+
+// fused path: supported when the row fits NCH <= 8 chunks of 64 lanes and the partial image fits LDS
+static int ln_fused_blocks(int rows, int& rows_per_block) {
+    rows_per_block = std::max(4, (cdiv(rows, 256) + 3) / 4 * 4);
+    return cdiv(rows, rows_per_block);
+}
+static bool ln_fused_ok(int dtype, int cols, bool vec) {
+    if (!vec) return false;
+    const int n = dtype == FF_DTYPE_BF16 ? 8 : 4;
+    return cdiv(cols / n, 64) <= 8 && (size_t)2 * cols * sizeof(float) <= 96 * 1024;
+}
+size_t layernorm_bwd_workspace(int rows, int cols) {
+    int rpb;
+    const size_t fused = (size_t)ln_fused_blocks(rows, rpb) * (2 * (size_t)cols + 2) * sizeof(float);
+    return std::max(fused, col_reduce_ws(rows, cols, 1, 2));
+}
+
+template <typename T, int VEC>
+static int launch_ln_fused(const LnArgs& a, const void* dy, const void* x, const void* add, const void* gamma, const float* mean,
+                           const float* rstd, void* dx, const void* dx_res, const LnDots& dots, void* dgamma, void* dbeta, float* partial,
+                           hipStream_t st_) {
+    int rpb;
+    const int nblk = ln_fused_blocks(a.rows, rpb);
+    const int nch = cdiv(a.cols / VEC, 64);
+    const size_t lds = (size_t)2 * a.cols * sizeof(float);
+#define FF_LN_LAUNCH(NCH)                                                                                                                 \
+    do {                                                                                                                                  \
+        static bool attr = false;                                                                                                         \
+        if (!attr && lds > 48 * 1024) {                                                                                                   \
+            hipFuncSetAttribute((const void*)ln_bwd_fused_kernel<T, VEC, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);    \
+            attr = true;                                                                                                                  \
+        }                                                                                                                                 \
+        ln_bwd_fused_kernel<T, VEC, NCH><<<dim3(nblk), dim3(256), lds, st_>>>(a, (const T*)dy, (const T*)x, (const T*)add, (const T*)gamma, \
+                                                                              mean, rstd, (T*)dx, (const T*)dx_res, (const T*)dots.a,     \
+                                                                              (const T*)dots.b, partial, rpb);                            \
+    } while (0)
+    if (nch <= 2) FF_LN_LAUNCH(2);
+    else if (nch <= 4) FF_LN_LAUNCH(4);
+    else FF_LN_LAUNCH(8);
+#undef FF_LN_LAUNCH
+    FF_TRY(check_launch("ln_bwd_fused"));
+    const int P = 2 * a.cols + 2;
+    ln_bwd_final_kernel<T><<<dim3(cdiv(P, 64)), dim3(256), 0, st_>>>(nblk, a.cols, partial, (T*)dgamma, (T*)dbeta, (const T*)dots.alpha_a,
+                                                                     (T*)dots.out_a, (const T*)dots.alpha_b, (T*)dots.out_b);
+    return check_launch("ln_bwd_final");
+}
 
 int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* add, const void* gamma, const float* mean,
                   const float* rstd, void* dx, const void* dx_residual, void* dgamma, void* dbeta, void* ws, size_t ws_bytes,
-                  hipStream_t st_) {
+                  hipStream_t st_, const LnDots* dots_in) {
     FF_CHECK(a.rows > 0 && a.cols > 0 && dy && x && gamma && mean && rstd, FF_ERR_SHAPE, "layernorm_bwd: null/shape");
     FF_CHECK(!add || (a.add_rows_per_seg > 0 && a.add_div > 0), FF_ERR_SHAPE, "layernorm_bwd: addend needs add_rows_per_seg/add_div");
-    const bool v = vec_ok(a.dtype, a.cols, {a.x_map, a.y_map, a.dx_map}, {x, add, gamma, dy, dx, dx_residual});
+    const LnDots dots = dots_in ? *dots_in : LnDots{};
+    FF_CHECK(!dots.a || dx_residual, FF_ERR_SHAPE, "layernorm_bwd: dot_a is taken against dx_residual");
+    FF_CHECK(!dots.b || dx, FF_ERR_SHAPE, "layernorm_bwd: dot_b is taken against dx");
+    const bool v = vec_ok(a.dtype, a.cols, {a.x_map, a.y_map, a.dx_map}, {x, add, gamma, dy, dx, dx_residual, dots.a, dots.b});
+    if (ln_fused_ok(a.dtype, a.cols, v) && (dgamma || dots.a || dots.b)) {
+        FF_CHECK(!dgamma == !dbeta, FF_ERR_SHAPE, "layernorm_bwd: dgamma and dbeta come together");
+        int rpb;
+        const size_t need = (size_t)ln_fused_blocks(a.rows, rpb) * (2 * (size_t)a.cols + 2) * sizeof(float);
+        FF_CHECK(ws && ws_bytes >= need, FF_ERR_WORKSPACE, "layernorm_bwd workspace: need %zu have %zu", need, ws_bytes);
+        if (a.dtype == FF_DTYPE_BF16) return launch_ln_fused<bf16, 8>(a, dy, x, add, gamma, mean, rstd, dx, dx_residual, dots, dgamma, dbeta, (float*)ws, st_);
+        return launch_ln_fused<float, 4>(a, dy, x, add, gamma, mean, rstd, dx, dx_residual, dots, dgamma, dbeta, (float*)ws, st_);
+    }
+    if (dots.a) FF_TRY(gate_grad(a.dtype, a.rows, a.cols, dx_residual, dots.a, dots.alpha_a, dots.out_a, ws, ws_bytes, st_));   // unfused fallback (plain maps)
     if (dx) {
         const int grid = cdiv(a.rows, 4);
         FF_DISPATCH_T_VEC(a.dtype, v, ln_bwd_dx_kernel<T, VEC><<<dim3(grid), dim3(256), 0, st_>>>(a, (const T*)dy, (const T*)x, (const T*)add, (const T*)gamma, mean, rstd, (T*)dx, (const T*)dx_residual));
@@ -375,6 +596,7 @@ int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* ad
             hipLaunchKernelGGL(col_reduce_final_kernel<float>, dim3(grid), dim3(256), 0, st_, c.nsplit, 1, 2, a.cols, (const float*)ws, (float*)dgamma, (float*)dbeta);
         FF_TRY(check_launch("ln_bwd_param_final"));
     }
+    if (dots.b) FF_TRY(gate_grad(a.dtype, a.rows, a.cols, dx, dots.b, dots.alpha_b, dots.out_b, ws, ws_bytes, st_));
     return FF_OK;
 }
 
@@ -461,7 +683,7 @@ extern "C" int ff_layernorm_bwd(const ff_ln_desc* d, const void* dy, const void*
                                 const float* mean, const float* rstd, void* dx, const void* dx_residual, void* dgamma, void* dbeta,
                                 void* workspace, size_t workspace_bytes, ff_stream_t stream) {
     return ff::layernorm_bwd(to_args(d), dy, x, add, gamma, mean, rstd, dx, dx_residual, dgamma, dbeta, workspace, workspace_bytes,
-                             (hipStream_t)stream);
+                             (hipStream_t)stream, nullptr);
 }
 extern "C" size_t ff_rows_reduce_workspace_bytes(const ff_reduce_desc* d) {
     return ff::rows_reduce_workspace(d->rows, d->cols, d->rows_per_batch, d->rows_per_group);

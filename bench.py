@@ -224,8 +224,14 @@ def main():
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
             tot_ms = sum(v["ms"] for v in groups.values())
             tot_fl = sum(v["flops"] for v in groups.values())
+            traffic = None      # HBM bytes per launch of this kernel from the committed PMC passes (profiles/r01_pmc_traffic.json)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    traffic = json.load(f)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": None, "kernel": name, "launches": g["launches"],
+                        "traffic": traffic, "kernel": name, "launches": g["launches"],
                         "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
                         "avg_launch_gflop": round(g["flops"] / g["launches"] / 1e9, 3),
                         "all_fusion_gemms": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),

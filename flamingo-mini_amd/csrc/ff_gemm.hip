@@ -83,6 +83,11 @@ FF_DEV int xcd_remap(int bid, int nwg) {
 struct TileCoord {
     int z, split, tm, tn;
 };
+// blockIdx -> (problem, K split, tile).  The 8 XCDs have private L2s and workgroup b runs on XCD b % 8 (observed, used for
+// speed only), so the tile grid is cut into xcd_ms x xcd_ns sub-grids, one per XCD: an XCD then fetches only 1/ms of A's
+// row panels and 1/ns of B's column panels through its L2 (rocprofv3 FETCH_SIZE for 1024x5120x1280: 103 MB with one row
+// panel per XCD - every L2 pulled the whole weight matrix - vs 15.7 MB algorithmic).  The map is a bijection for any
+// grid size: positions are the concatenation of the 8 sub-grids, XCD x takes a contiguous chunk of positions.
 FF_DEV TileCoord tile_coord(const GemmParams& P, int tiles_m, int tiles_n) {
     const int per_z = tiles_m * tiles_n;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -90,9 +95,22 @@ FF_DEV TileCoord tile_coord(const GemmParams& P, int tiles_m, int tiles_n) {
     c.z = bid / (per_z * P.split_k);
     bid -= c.z * per_z * P.split_k;
     c.split = bid / per_z;
-    bid -= c.split * per_z;
-    c.tm = bid / tiles_n;
-    c.tn = bid - c.tm * tiles_n;
+    int p = bid - c.split * per_z;
+    const int ms = P.xcd_ms, ns = P.xcd_ns;
+    c.tm = 0; c.tn = 0;
+    for (int sgrid = 0; sgrid < ms * ns; sgrid++) {
+        const int sm = sgrid / ns, sn = sgrid - sm * ns;
+        const int r0 = sm * tiles_m / ms, r1 = (sm + 1) * tiles_m / ms;
+        const int c0 = sn * tiles_n / ns, c1 = (sn + 1) * tiles_n / ns;
+        const int cnt = (r1 - r0) * (c1 - c0);
+        if (p < cnt) {
+            const int cw = c1 - c0;
+            c.tm = r0 + p / cw;
+            c.tn = c0 + p - (p / cw) * cw;
+            break;
+        }
+        p -= cnt;
+    }
     return c;
 }
 
@@ -768,6 +786,21 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         FF_CHECK(workspace && ws_bytes >= need, FF_ERR_WORKSPACE, "gemm split-K workspace: need %zu have %zu", need, ws_bytes);
         FF_CHECK(P.N % 4 == 0, FF_ERR_UNSUPPORTED, "gemm split-K needs N %% 4 == 0 (N=%d)", P.N);
         P.partial = (float*)workspace;
+    }
+    {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
+        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 ? 128 : 64) : kFBM;
+        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 ? 64 : 128) : kFBM;
+        const int tiles_m = cdiv(P.M, tm_edge), tiles_n = cdiv(P.N, tn_edge);
+        double best = 1e300;
+        P.xcd_ms = 1; P.xcd_ns = 1;
+        for (int ms = 1; ms <= 8; ms *= 2) {
+            const int ns = 8 / ms;
+            if (ms > tiles_m || ns > tiles_n) continue;
+            const double cost = (double)P.M / ms + (double)P.N / ns;
+            if (cost < best) { best = cost; P.xcd_ms = ms; P.xcd_ns = ns; }
+        }
+        static const int disable = env_int("FF_GEMM_XCD2D", 1) == 0;
+        if (disable) { P.xcd_ms = 1; P.xcd_ns = 1; }
     }
     const int vec = dtype == FF_DTYPE_BF16 ? 8 : 4;
     auto map_ok = [&](const RowMap& m) { return m.ld % vec == 0 && (m.rows_per_seg <= 0 || m.seg_stride % vec == 0); };

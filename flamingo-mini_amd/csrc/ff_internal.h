@@ -23,7 +23,8 @@ struct GemmParams {
     float scale;
     int act, act_bwd;
     int split_k, k_per_split;
-    int tile;   // block tile edge chosen by the host (bf16: 64 or 128)
+    int tile;   // block tile chosen by the host (bf16: 128 = 128x128, 64 = 64x64, 6412 = 64x128)
+    int xcd_ms, xcd_ns;   // XCD partition of the tile grid (ms * ns sub-grids, one per XCD)
     float* partial;
     int a_vec_ok, b_vec_ok;
     int nz;

@@ -692,7 +692,7 @@ static int forced_tile() {
 // >= ~200 workgroups on the chip; long-K problems with few output tiles get there through split-K (fp32 partial slabs
 // + a reduce/epilogue kernel), short-K ones use 64x64 tiles.
 struct TilePlan { int tile, split; };
-static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split) {
+static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_layout = 0) {
     const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;
     TilePlan p;
     const int ft = forced_tile();
@@ -703,7 +703,10 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split) {
         p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
         return p;
     }
-    if (t128 >= 200) p = TilePlan{128, 1};
+    // 200..450 tiles of 128x128 leave most CUs with a single, latency-bound workgroup; 64x128 tiles (1.5x the operand traffic
+    // but 2-3 workgroups per CU) measured 10-25 % faster there when A is row-major (sweep in tools/gemm_bench.py)
+    if (t128 >= 200 && t128 < 450 && a_layout == 0 && (long long)cdiv(M, 64) * cdiv(N, 128) * nz >= 400) p = TilePlan{6412, 1};
+    else if (t128 >= 200) p = TilePlan{128, 1};
     else if (K >= 2048) {
         int s = (int)std::min<long long>(8, std::max<long long>(2, cdiv(384, t128)));
         while (s > 1 && K / (64 * s) < 8) s--;
@@ -773,7 +776,7 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
              P.M, P.N, P.K, P.nz);
     P.tile = kFBM;
     if (dtype == FF_DTYPE_BF16) {
-        const TilePlan plan = plan_bf16(P.M, P.N, P.K, P.nz, P.split_k);
+        const TilePlan plan = plan_bf16(P.M, P.N, P.K, P.nz, P.split_k, P.a_layout);
         P.tile = plan.tile;
         P.split_k = plan.split;
     } else if (P.split_k <= 0) P.split_k = gemm_pick_split(dtype, P.M, P.N, P.K, P.nz);

@@ -81,11 +81,7 @@ def text_time(media_locations: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------------
 # PerceiverResampler
 # ----------------------------------------------------------------------------------------------------
-class ResamplerCfg(tuple):
-    """(depth, heads, dim_head, num_latents, num_time_embeds, ff_mult, act)"""
-    __slots__ = ()
-
-
+# cfg = (depth, heads, dim_head, num_latents, num_time_embeds, ff_mult, act)
 def _resampler_desc(x_f: torch.Tensor, cfg) -> ffi.ResamplerDesc:
     depth, heads, dim_head, num_latents, nte, ff_mult, act = cfg
     b, T, v, d = x_f.shape

@@ -82,16 +82,23 @@ def gemm_profile_summary(lib, ffi, max_records):
     recs = (ffi.GemmProfileRecord * max_records)()
     n = lib.ff_gemm_profile_read(recs, max_records)
     lib.ff_gemm_profile_enable(0)
-    groups, shapes = {}, {}
+    groups, shapes, attn = {}, {}, {}
     for i in range(n):
         r = recs[i]
+        if r.tile < 0:      # attention core: algorithmic HBM bytes = each of Q, K, V, O (and their gradients) touched once
+            es = 2 if r.dtype == ffi.DTYPE_BF16 else 4
+            q_b, kv_b = r.nz * r.M * r.K * es, r.nz * r.N * r.K * es
+            nbytes = {-1: 2 * q_b + 2 * kv_b, -2: 4 * q_b + 2 * kv_b, -3: 2 * q_b + 4 * kv_b}[r.tile]
+            a = attn.setdefault({-1: "fwd", -2: "bwd_dq", -3: "bwd_dkv"}[r.tile], dict(ms=0.0, bytes=0.0, launches=0))
+            a["ms"] += r.ms; a["bytes"] += nbytes; a["launches"] += 1
+            continue
         key = (r.dtype, r.tile, r.a_layout, r.b_layout)
         for table, k in ((groups, key), (shapes, (r.M, r.N, r.K, r.nz, r.a_layout, r.b_layout, r.tile, r.split_k))):
             g = table.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
             g["ms"] += r.ms
             g["flops"] += 2.0 * r.M * r.N * r.K * r.nz
             g["launches"] += 1
-    return groups, shapes
+    return groups, shapes, attn
 
 
 def caption_leg(args, model, batch, device):
@@ -205,7 +212,7 @@ def main():
     loss_val = float(loss.float().item())
 
     if rank == 0:
-        groups, shapes = gemm_profile_summary(lib, ffi, max_rec)
+        groups, shapes, attn = gemm_profile_summary(lib, ffi, max_rec)
         if args.gemm_table:
             with open(args.gemm_table, "w") as f:
                 f.write("M N K nz aL bL tile splitK launches/step us/launch TF/s ms/step\n")
@@ -249,6 +256,12 @@ def main():
                        "trainable_params": n_trainable, "loss": round(loss_val, 4)},
             "roofline": roofline,
         }
+        if attn:    # north star: throughput of the softmax(QK^T)V core as a fraction of the HBM roofline (8 TB/s spec peak)
+            result["attention_roofline"] = {
+                k: {"bound": "hbm", "achieved": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 4), "launches": v["launches"],
+                    "avg_launch_us": round(v["ms"] / v["launches"] * 1e3, 2), "avg_launch_mb": round(v["bytes"] / v["launches"] / 1e6, 2)}
+                for k, v in attn.items()}
         if world == 1 and args.caption_tokens > 0:
             result["caption"] = caption_leg(args, model, batch, device)
         if world == 1 and not args.no_cpu_baseline:

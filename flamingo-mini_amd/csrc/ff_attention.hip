@@ -420,7 +420,9 @@ int attention_fwd(const ff_attn_desc& d, const void* Q, const void* K, const voi
     FF_TRY(check_desc(d, false));
     FF_CHECK(Q && K && V && O && (d.mode == FF_ATTN_DENSE || tt), FF_ERR_SHAPE, "attention_fwd: null argument");
     const dim3 grid(cdiv(d.n_q, kTile), d.heads, d.batch);
+    const int pid = profile_begin(d.dtype, -1, 0, 0, d.n_q, d.n_kv, d.dim_head, d.batch * d.heads, d.mode, st);
     FF_ATTN_DISPATCH(d, attn_fwd_kernel<T, DH><<<grid, dim3(256), 0, st>>>(d, (const T*)Q, (const T*)K, (const T*)V, tt, (T*)O, lse));
+    profile_end(pid, st);
     return check_launch("attn_fwd");
 }
 
@@ -434,9 +436,13 @@ int attention_bwd(const ff_attn_desc& d, const void* Q, const void* K, const voi
              attention_bwd_workspace(d), ws_bytes);
     float* Dsum = (float*)ws;
     const dim3 gq(cdiv(d.n_q, kTile), d.heads, d.batch), gk(cdiv(d.n_kv, kTile), d.heads, d.batch);
+    int pid = profile_begin(d.dtype, -2, 0, 0, d.n_q, d.n_kv, d.dim_head, d.batch * d.heads, d.mode, st);
     FF_ATTN_DISPATCH(d, attn_bwd_dq_kernel<T, DH><<<gq, dim3(256), 0, st>>>(d, (const T*)Q, (const T*)K, (const T*)V, tt, (const T*)O, (const T*)dO, lse, (T*)dQ, Dsum));
+    profile_end(pid, st);
     FF_TRY(check_launch("attn_bwd_dq"));
+    pid = profile_begin(d.dtype, -3, 0, 0, d.n_q, d.n_kv, d.dim_head, d.batch * d.heads, d.mode, st);
     FF_ATTN_DISPATCH(d, attn_bwd_dkv_kernel<T, DH><<<gk, dim3(256), 0, st>>>(d, (const T*)Q, (const T*)K, (const T*)V, tt, (const T*)dO, lse, (const float*)Dsum, (T*)dK, (T*)dV));
+    profile_end(pid, st);
     return check_launch("attn_bwd_dkv");
 }
 

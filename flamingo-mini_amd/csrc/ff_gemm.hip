@@ -2,9 +2,9 @@
 // data-gradient (dY W) and weight-gradient (dY^T X), with the elementwise neighbours fused into the epilogue
 // (activation, activation-backward, residual, tanh(alpha) gate, branch-output store).
 //
-//   bf16 : v_mfma_f32_16x16x32_bf16, 128x128x64 or 64x64x64 block tiles, 4 waves (2x2), LDS double buffer fed
-//          through registers (global loads of tile t+1 fly under the MFMAs of tile t).  Operands whose
-//          contraction index is the slow (strided) one are staged as-is and read with ds_read_b64_tr_b16.
+//   bf16 : v_mfma_f32_16x16x32_bf16, 128x128 / 64x128 / 64x64 block tiles x K 64, 4 waves (2x2), LDS ring fed by
+//          LDS-DMA (buffer_load ... lds).  Operands whose contraction index is the slow (strided) one are
+//          staged as-is and read with ds_read_b64_tr_b16.
 //   fp32 : v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) — the verification precision.
 //
 // Accumulators are kept transposed (D[n][m] = mfma(Bfrag, Afrag)) so a lane owns 4 consecutive n of one row m
@@ -118,177 +118,9 @@ FF_DEV TileCoord tile_coord(const GemmParams& P, int tiles_m, int tiles_n) {
 // bf16 kernel
 // ------------------------------------------------------------------------------------------------
 constexpr int kBK = 64;    // bf16 K tile
-constexpr int kMPad = 16;  // row padding (elements) of M-major LDS tiles
-
-template <int BR, int LAYOUT> struct TileGeom {  // one operand tile: BR rows (M or N) x kBK
-    static constexpr int elems = LAYOUT == 0 ? BR * kBK : kBK * (BR + kMPad);
-    static constexpr int nreg = BR / 32;  // 16-byte registers per thread per tile
-};
-
-// global -> registers.  LAYOUT 0: source rows are the BR tile rows, K contiguous.  LAYOUT 1: source rows are K.
-template <int BR, int LAYOUT>
-FF_DEV void tile_load(const bf16* __restrict__ base, const RowMap& map, int row_base, int row_lim, int k0, int k_end,
-                      const long long* row_off, uint4 (&reg)[BR / 32]) {
-    const int t = threadIdx.x;
-    if (LAYOUT == 0) {
-        const int chunk = t & 7;
-        const int k = k0 + chunk * 8;
-#pragma unroll
-        for (int p = 0; p < BR / 32; p++) {
-            const int row = p * 32 + (t >> 3);
-            uint4 v = {0, 0, 0, 0};
-            if (row_base + row < row_lim && k < k_end) v = *(const uint4*)(base + row_off[p] + k);
-            reg[p] = v;
-        }
-    } else {
-        constexpr int CPR = BR / 8;  // 16-byte chunks per k row
-        constexpr int RPP = 256 / CPR;
-        const int mc = t % CPR;
-        const int col = row_base + mc * 8;
-#pragma unroll
-        for (int p = 0; p < BR / 32; p++) {
-            const int kr = k0 + p * RPP + t / CPR;
-            uint4 v = {0, 0, 0, 0};
-            if (kr < k_end && col < row_lim) v = *(const uint4*)(base + map.off(kr) + col);
-            reg[p] = v;
-        }
-    }
-}
-
-template <int BR, int LAYOUT> FF_DEV void tile_store(bf16* s, const uint4 (&reg)[BR / 32]) {
-    const int t = threadIdx.x;
-    if (LAYOUT == 0) {
-        const int chunk = t & 7;
-#pragma unroll
-        for (int p = 0; p < BR / 32; p++) {
-            const int row = p * 32 + (t >> 3);
-            *(uint4*)(s + row * kBK + ((chunk ^ (row & 7)) << 3)) = reg[p];
-        }
-    } else {
-        constexpr int CPR = BR / 8;
-        constexpr int RPP = 256 / CPR;
-        const int mc = t % CPR;
-#pragma unroll
-        for (int p = 0; p < BR / 32; p++) {
-            const int kr = p * RPP + t / CPR;
-            *(uint4*)(s + kr * (BR + kMPad) + mc * 8) = reg[p];
-        }
-    }
-}
-
-// LDS -> MFMA fragment of 16 tile rows starting at r0, k-step ks (32 wide)
-template <int BR, int LAYOUT> FF_DEV bf16x8 frag_read(const bf16* s, int r0, int ks) {
-    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
-    if (LAYOUT == 0) {
-        const int row = r0 + c;
-        const int chunk = ks * 4 + g;
-        return *(const bf16x8*)(s + row * kBK + ((chunk ^ (row & 7)) << 3));
-    } else {
-        const int k = ks * 32 + g * 8 + (c >> 2);
-        const bf16* p = s + k * (BR + kMPad) + r0 + (c & 3) * 4;
-        return cat4(lds_read_tr16(p), lds_read_tr16(p + 4 * (BR + kMPad)));
-    }
-}
-
-template <int BM, int BN, int AL, int BL>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    typedef TileGeom<BM, AL> GA;
-    typedef TileGeom<BN, BL> GB;
-    constexpr int STAGE = GA::elems + GB::elems;
-    bf16* smem = (bf16*)smem_raw;
-    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
-
-    const int tiles_m = (P.M + BM - 1) / BM, tiles_n = (P.N + BN - 1) / BN;
-    const TileCoord tc = tile_coord(P, tiles_m, tiles_n);
-    const GemmProblem& pr = P.p[tc.z];
-    const int m_base = tc.tm * BM, n_base = tc.tn * BN;
-    const int k_begin = tc.split * P.k_per_split;
-    const int k_end = min(P.K, k_begin + P.k_per_split);
-    const bf16* A = (const bf16*)pr.A;
-    const bf16* B = (const bf16*)pr.B;
-
-    const int t = threadIdx.x, w = t >> 6, l = t & 63;
-    const int wm = w >> 1, wn = w & 1;
-
-    long long a_off[GA::nreg], b_off[GB::nreg];
-    if (AL == 0) {
-#pragma unroll
-        for (int p = 0; p < GA::nreg; p++) a_off[p] = P.a_map.off(min(m_base + p * 32 + (t >> 3), P.M - 1));
-    }
-    if (BL == 0) {
-#pragma unroll
-        for (int p = 0; p < GB::nreg; p++) b_off[p] = P.b_map.off(min(n_base + p * 32 + (t >> 3), P.N - 1));
-    }
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    uint4 ra[GA::nreg], rb[GB::nreg];
-    const int nk = (k_end - k_begin + kBK - 1) / kBK;
-    if (nk > 0) {
-        tile_load<BM, AL>(A, P.a_map, m_base, P.M, k_begin, k_end, a_off, ra);
-        tile_load<BN, BL>(B, P.b_map, n_base, P.N, k_begin, k_end, b_off, rb);
-        tile_store<BM, AL>(smem, ra);
-        tile_store<BN, BL>(smem + GA::elems, rb);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt++) {
-        const bf16* sA = smem + (kt & 1) * STAGE;
-        const bf16* sB = sA + GA::elems;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            const int k0 = k_begin + (kt + 1) * kBK;
-            tile_load<BM, AL>(A, P.a_map, m_base, P.M, k0, k_end, a_off, ra);
-            tile_load<BN, BL>(B, P.b_map, n_base, P.N, k0, k_end, b_off, rb);
-        }
-#pragma unroll
-        for (int ks = 0; ks < kBK / 32; ks++) {
-            bf16x8 fa[MT], fb[NT];
-#pragma unroll
-            for (int i = 0; i < MT; i++) fa[i] = frag_read<BM, AL>(sA, wm * WM + i * 16, ks);
-#pragma unroll
-            for (int j = 0; j < NT; j++) fb[j] = frag_read<BN, BL>(sB, wn * WN + j * 16, ks);
-#pragma unroll
-            for (int i = 0; i < MT; i++)
-#pragma unroll
-                for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
-        }
-        if (more) {
-            bf16* dA = smem + ((kt + 1) & 1) * STAGE;
-            tile_store<BM, AL>(dA, ra);
-            tile_store<BN, BL>(dA + GA::elems, rb);
-        }
-        __syncthreads();
-    }
-
-    // epilogue: lane owns row m = ..+(l&15), columns n = ..+(l>>4)*4 .. +3
-    const int c = l & 15, g = l >> 4;
-#pragma unroll
-    for (int i = 0; i < MT; i++) {
-        const int m = m_base + wm * WM + i * 16 + c;
-        if (m >= P.M) continue;
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int n = n_base + wn * WN + j * 16 + g * 4;
-            if (n >= P.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (P.split_k > 1) {
-                float* dst = P.partial + ((long long)(tc.z * P.split_k + tc.split) * P.M + m) * P.N + n;
-                *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};  // N % 4 == 0 checked on the host
-            } else {
-                epilogue4<bf16>(P, pr, m, n, v);
-            }
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
-// bf16 kernel v2: operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, no VGPR staging, no ds_write)
+// bf16 kernel: operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, no VGPR staging, no ds_write)
 // into an NS-deep ring; tiles t+1 .. t+NS-2 stay in flight across the single s_barrier of a k-step (counted vmcnt).
 // The LDS-DMA destination is lane-linear (wave base + lane*16 B), so the bank-conflict swizzles live on the SOURCE
 // address: LDS 16-byte slot (row, c') holds global chunk c' ^ swz(row); readers apply the same XOR.
@@ -617,28 +449,6 @@ template <typename T> __global__ __launch_bounds__(256) void gemm_splitk_epilogu
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int AL, int BL> static int launch_bf16(const GemmParams& P, hipStream_t st) {
-    constexpr size_t lds = 2 * (TileGeom<BM, AL>::elems + TileGeom<BN, BL>::elems) * sizeof(bf16);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, AL, BL>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm lds=%zu): %s", lds, hipGetErrorString(e));
-        }
-        attr_done = true;
-    }
-    const int tiles = cdiv(P.M, BM) * cdiv(P.N, BN);
-    const int grid = tiles * P.split_k * P.nz;
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AL, BL>), dim3(grid), dim3(256), lds, st, P);
-    return check_launch("gemm_bf16");
-}
-template <int BM, int BN> static int dispatch_bf16(const GemmParams& P, hipStream_t st) {
-    if (P.a_layout == 0 && P.b_layout == 0) return launch_bf16<BM, BN, 0, 0>(P, st);
-    if (P.a_layout == 0 && P.b_layout == 1) return launch_bf16<BM, BN, 0, 1>(P, st);
-    if (P.a_layout == 1 && P.b_layout == 0) return launch_bf16<BM, BN, 1, 0>(P, st);
-    return launch_bf16<BM, BN, 1, 1>(P, st);
-}
 static int dispatch_f32(const GemmParams& P, hipStream_t st) {
     const int grid = cdiv(P.M, kFBM) * cdiv(P.N, kFBM) * P.split_k * P.nz;
 #define FF_F32_LAUNCH(AL, BL) hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), dim3(grid), dim3(256), 0, st, P)
@@ -662,18 +472,22 @@ struct ProfState {
     ff_gemm_profile_record* rec = nullptr;
 } g_prof;
 }
-static int prof_begin(const GemmParams& P, int dtype, int bm, hipStream_t st) {
+int profile_begin(int dtype, int tile, int a_layout, int b_layout, int M, int N, int K, int nz, int split_k, hipStream_t st) {
     if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
     const int i = g_prof.n++;
     ff_gemm_profile_record& r = g_prof.rec[i];
-    r.dtype = dtype; r.tile = bm; r.a_layout = P.a_layout; r.b_layout = P.b_layout;
-    r.M = P.M; r.N = P.N; r.K = P.K; r.nz = P.nz; r.split_k = P.split_k; r.ms = 0.f;
+    r.dtype = dtype; r.tile = tile; r.a_layout = a_layout; r.b_layout = b_layout;
+    r.M = M; r.N = N; r.K = K; r.nz = nz; r.split_k = split_k; r.ms = 0.f;
     hipEventRecord(g_prof.ev[2 * i], st);
     return i;
 }
-static void prof_end(int i, hipStream_t st) {
+void profile_end(int i, hipStream_t st) {
     if (i >= 0) hipEventRecord(g_prof.ev[2 * i + 1], st);
 }
+static int prof_begin(const GemmParams& P, int dtype, int bm, hipStream_t st) {
+    return profile_begin(dtype, bm, P.a_layout, P.b_layout, P.M, P.N, P.K, P.nz, P.split_k, st);
+}
+static void prof_end(int i, hipStream_t st) { profile_end(i, st); }
 
 // FF_GEMM_TILE=64|128 forces the bf16 block tile (tuning / microbenchmarks only)
 static int g_force_tile = -1, g_force_stages = -1;
@@ -820,16 +634,15 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         FF_CHECK(P.a_vec_ok && P.b_vec_ok, FF_ERR_UNSUPPORTED,
                  "bf16 gemm needs 16-byte aligned operands with contiguous dims %% 8 == 0 (M=%d N=%d K=%d)", P.M, P.N, P.K);
         FF_CHECK(P.N % 4 == 0 && P.c_map.ld % 4 == 0, FF_ERR_UNSUPPORTED, "bf16 gemm needs N %% 4 == 0 (N=%d)", P.N);
-        static const int version = env_int("FF_GEMM_V", 2);
-        // v2 addresses operands through 32-bit buffer offsets: fall back to v1 for (never seen) spans >= 1 GiB elements
+        // operands are addressed through 32-bit buffer offsets
         auto span_ok = [&](const RowMap& m, int rows, int contig) {
             const long long last = (m.rows_per_seg > 0 ? (long long)((rows - 1) / m.rows_per_seg) * m.seg_stride + (long long)((rows - 1) % m.rows_per_seg) * m.ld
                                                       : (long long)(rows - 1) * m.ld) + contig;
             return last < (1LL << 30);
         };
-        const bool small = span_ok(P.a_map, P.a_layout == 0 ? P.M : P.K, a_contig) && span_ok(P.b_map, P.b_layout == 0 ? P.N : P.K, b_contig);
-        if (version >= 2 && small) rc = run_bf16_dma(P, st);
-        else rc = big_tile(P) ? dispatch_bf16<128, 128>(P, st) : dispatch_bf16<64, 64>(P, st);
+        FF_CHECK(span_ok(P.a_map, P.a_layout == 0 ? P.M : P.K, a_contig) && span_ok(P.b_map, P.b_layout == 0 ? P.N : P.K, b_contig),
+                 FF_ERR_UNSUPPORTED, "bf16 gemm operands must span < 2^30 elements (M=%d N=%d K=%d)", P.M, P.N, P.K);
+        rc = run_bf16_dma(P, st);
     } else {
         rc = dispatch_f32(P, st);
     }

@@ -61,6 +61,11 @@ struct Gemm {
     int run(void* ws, size_t ws_bytes, hipStream_t st) const { return gemm_launch(P, dtype, ws, ws_bytes, st); }
 };
 
+// launch timing hooks (ff_gemm_profile_*): tile < 0 marks the attention kernels (-1 fwd, -2 dQ, -3 dK/dV; M = n_q, N = n_kv,
+// K = dim_head, nz = batch * heads, split_k = mode)
+int profile_begin(int dtype, int tile, int a_layout, int b_layout, int M, int N, int K, int nz, int split_k, hipStream_t st);
+void profile_end(int i, hipStream_t st);
+
 // ---- row-wise kernels ------------------------------------------------------------------------
 struct LnArgs {
     int dtype;

@@ -1,0 +1,55 @@
+"""The drop-in boundary itself, without a GPU: the shared library loads, exports every function include/flamingo_fusion.h
+declares (and the ctypes table binds exactly those), reports its ABI, sizes its workspaces, and argument errors come back
+as negative codes + a message before anything touches a device."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "flamingo_fusion.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ff_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_exactly_the_header():
+    from flamingo_mini_amd import ffi
+    lib = ffi.lib()
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(ffi.EXPORTED_SYMBOLS) == names, set(ffi.EXPORTED_SYMBOLS) ^ set(names)
+    assert lib.ff_version() == ffi.ABI_VERSION and lib.ff_arch() == b"gfx950"
+
+
+def test_workspace_queries_and_error_codes_without_a_device():
+    from flamingo_mini_amd import ffi
+    lib = ffi.lib()
+    d = ffi.ResamplerDesc(ffi.DTYPE_BF16, 32, 1, 257, 1024, 6, 8, 64, 64, 4, 4, ffi.ACT_GELU)
+    saved, scratch = lib.ff_resampler_saved_bytes(d), lib.ff_resampler_scratch_bytes(d)
+    assert 0.5e9 < saved < 4e9 and 0.05e9 < scratch < 2e9          # config B: ~1 GB of saved activations
+    bad = ffi.ResamplerDesc(ffi.DTYPE_BF16, 32, 5, 257, 1024, 6, 8, 64, 64, 4, 4, ffi.ACT_GELU)   # 5 frames > 4 time embeddings
+    assert lib.ff_resampler_saved_bytes(bad) == 0
+    assert lib.ff_resampler_fwd(bad, None, None, None, None, 0, None, 0, None) == -1
+    assert b"num_time_embeds" in lib.ff_last_error()
+    x = ffi.XattnDesc(ffi.DTYPE_BF16, 32, 32, 1280, 1024, 1, 64, 8, 64, 4, ffi.ACT_GELU, 32, 0)
+    assert lib.ff_xattn_saved_bytes(x) > 0 and lib.ff_xattn_kv_offset(x) == 0
+    assert lib.ff_xattn_block_fwd(x, None, None, None, None, None, None, None, None, 0, None, 0, None) == -1     # null arguments
+    g = ffi.GemmDesc(ffi.DTYPE_BF16, 1024, 1280, 5120, 0, 0, ffi.rowmap(5120), ffi.rowmap(5120), ffi.rowmap(1280), 1.0, -1, -1, 0)
+    assert lib.ff_gemm_workspace_bytes(g) > 0                                                                      # long K, few tiles -> split-K
+    assert lib.ff_gemm(g, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.ff_text_time(0, 0, None, 8, None, None) == -1
+    a = ffi.AttnDesc(7, 1, 1, 64, 8, 8, 0, 0, 0, 0)                                                                # dtype 7 does not exist
+    assert lib.ff_attention_fwd(a, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), None, None) == -2
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from flamingo_mini_amd import ffi
+    monkeypatch.setattr(ffi, "_lib", None)
+    monkeypatch.setattr(ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(ffi.FusionLibraryError, match="no CPU/PyTorch fallback"):
+        ffi.lib()

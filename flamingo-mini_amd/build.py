@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion.so")
 SOURCES = ["ff_api.hip", "ff_gemm.hip", "ff_rowwise.hip", "ff_attention.hip"]
 HEADERS = ["ff_common.h", "ff_internal.h", os.path.join("..", "..", "include", "flamingo_fusion.h")]
 ARCH = "gfx950"
-FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("FF_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -719,3 +719,18 @@ extern "C" void ff_gemm_set_tuning(int tile, int stages) {   /* tuning / microbe
     ff::g_force_tile = tile > 0 ? tile : -1;
     ff::g_force_stages = stages > 0 ? stages : -1;
 }
+
+extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_k) {   /* introspection: the tile / split-K the launcher would use */
+    using namespace ff;
+    FF_CHECK(d && bm && bn && split_k, FF_ERR_SHAPE, "ff_gemm_plan: null argument");
+    if (d->dtype == FF_DTYPE_BF16) {
+        const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout);
+        *bm = p.tile == 128 ? 128 : 64;
+        *bn = p.tile == 64 ? 64 : 128;
+        *split_k = p.split;
+    } else {
+        *bm = *bn = kFBM;
+        *split_k = d->split_k > 0 ? d->split_k : gemm_pick_split(d->dtype, d->M, d->N, d->K, 1);
+    }
+    return FF_OK;
+}

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "ff_gemm_profile_enable": (_I, [_I]),
     "ff_gemm_profile_read": (_I, [C.POINTER(GemmProfileRecord), _I]),
     "ff_gemm_set_tuning": (None, [_I, _I]),
+    "ff_gemm_plan": (_I, [C.POINTER(GemmDesc), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "ff_layernorm_fwd": (_I, [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "ff_layernorm_bwd_workspace_bytes": (_SZ, [C.POINTER(LnDesc)]),
     "ff_layernorm_bwd": (_I, [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -82,8 +82,11 @@ typedef struct ff_gemm_profile_record {
 } ff_gemm_profile_record;
 int ff_gemm_profile_enable(int max_records);
 int ff_gemm_profile_read(ff_gemm_profile_record* out, int max_records);
-/* Tuning aid: force the bf16 block tile (64 / 128) and LDS ring depth (2..4); 0 = automatic choice. */
+/* Tuning aid: force the bf16 block tile (128 = 128x128, 6412 = 64x128, 64 = 64x64; 0 = automatic) and the LDS ring depth
+ * (2..4; 0 = default 2). */
 void ff_gemm_set_tuning(int tile, int stages);
+/* Introspection: block tile and split-K factor ff_gemm would choose for this problem (no device access). */
+int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_k);
 
 /* ------------------------------------------------------------------------------------------------------
  * LayerNorm over the last axis (eps inside the sqrt, biased variance: torch.nn.LayerNorm).

@@ -27,6 +27,27 @@ def test_gemm_layouts(dtype, al, bl, M, N, K):
     assert rel(C, ref) < TOL[dtype]["out"] * 0.5
 
 
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_every_instantiated_tile(al, bl):
+    """Force each bf16 block tile (ff_gemm_set_tuning) on a ragged problem: partial tiles in M and N, a K tail, split-K."""
+    from flamingo_mini_amd import ffi
+    M, N, K = 408, 424, 328
+    A = dev(rnd((M, K) if al == 0 else (K, M), 11), torch.bfloat16)
+    B = dev(rnd((N, K) if bl == 0 else (K, N), 12), torch.bfloat16)
+    a, b = as64(A), as64(B)
+    ref = (a if al == 0 else a.T) @ (b.T if bl == 0 else b)
+    lib = ffi.lib()
+    try:
+        for tile in (128, 6412, 64):
+            for stages in (2, 3, 4):
+                lib.ff_gemm_set_tuning(tile, stages)
+                for split in (1, 2):
+                    C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split)
+                    assert rel(C, ref) < 1e-2, (tile, stages, split)
+    finally:
+        lib.ff_gemm_set_tuning(0, 0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("split_k", [0, 3])
 def test_gemm_epilogues(dtype, split_k):

@@ -58,7 +58,7 @@ def main():
     lib = ffi.lib()
     configs = [(0, 0, 0)]
     if args.sweep:
-        configs += [(128, 2, 1), (6412, 2, 1), (6412, 3, 1), (6412, 2, 2), (64, 2, 1), (128, 2, 4), (6412, 2, 4)]
+        configs += [(128, 2, 1), (6412, 2, 1), (64, 2, 1), (128, 2, 2), (128, 2, 4), (6412, 2, 2), (64, 2, 2)]
     print(f"{'shape':13s} {'M':>6s} {'N':>6s} {'K':>6s} L | " + " ".join(f"t{t}/s{s}/k{k}".rjust(12) for t, s, k in configs) + " | blaslt(wall)")
     for name, M, N, K, al, bl in SHAPES:
         if args.only and args.only not in name:

@@ -53,3 +53,13 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(ffi.FusionLibraryError, match="no CPU/PyTorch fallback"):
         ffi.lib()
+
+
+def test_media_locations_from_known_ids():
+    """flamingo_processor.py:53-61,120-121 of the reference: '<' is 27 / ' <' is 1279 for GPT-2, 51552 / 28696 for OPT."""
+    import torch
+    from flamingo_mini_amd.flamingo_processor import KNOWN_LEQ_IDS, FlamingoProcessor
+    assert KNOWN_LEQ_IDS == {"gpt2": (27, 1279), "facebook/opt": (51552, 28696)}
+    ids = torch.tensor([[50256, 27, 9060, 29, 257, 1279, 27], [1, 2, 3, 4, 5, 6, 7]])
+    ml = FlamingoProcessor.media_locations_from_ids(ids, KNOWN_LEQ_IDS["gpt2"])
+    assert ml.tolist() == [[0, 1, 0, 0, 0, 1, 1], [0] * 7] and ml.dtype == ids.dtype

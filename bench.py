@@ -131,7 +131,7 @@ def cpu_baseline(args):
         cores = max(i["num_threads"] for i in threadpoolctl.threadpool_info() if i.get("user_api") == "blas")
     except Exception:
         cores = os.cpu_count() or 1
-    b, L, d, dv, n_blocks_timed, n_blocks = 2, args.seq_len, 1280, 1024, 2, 36
+    b, L, d, dv, n_blocks_timed, n_blocks = 8, args.seq_len, 1280, 1024, 6, 36      # sized for roughly 10-20 s of CPU work
     f32 = np.float32
     rp = {k: v.astype(f32) for k, v in resampler_params(dv, 6, 8, 64, 64, 4, 4, tag="cpu").items()}
     xp = {k: v.astype(f32) for k, v in xattn_params(d, dv, 8, 64, 4, tag="cpu").items()}

@@ -1,9 +1,9 @@
 """torch.autograd.Function wrappers around the C ABI (one Function per fwd/bwd pair) plus thin wrappers of the
 primitive kernels used by the parity tests.
 
-Nothing here computes: every op below is a call into libflamingo_fusion.so on the current HIP stream.
-`set_checker_backend()` exists for CPU *plumbing tests only* (tests inject the oracle there); the product never
-sets it and CPU tensors raise.
+Nothing here computes: every op below is a call into libflamingo_fusion.so on the current HIP stream; CPU tensors or a
+missing library raise FusionLibraryError.  (The CPU plumbing tests monkeypatch `resampler`, `xattn_block` and
+`text_time` of this module from tests/oracle_backend.py - there is no alternative path in the package itself.)
 """
 from __future__ import annotations
 
@@ -12,15 +12,6 @@ from typing import Callable, Optional, Sequence, Tuple
 import torch
 
 from . import ffi
-
-_checker_backend = None  # tests only: object with .resampler(x_f, params, cfg) and .xattn_block(...)
-
-
-def set_checker_backend(backend) -> None:
-    """TESTS ONLY.  Route CPU tensors to a checker (the oracle) so HF plumbing can be exercised without a GPU."""
-    global _checker_backend
-    _checker_backend = backend
-
 
 _grad_ready_callbacks: list = []   # called with the flat gradient buffer of a fused module right after its backward is enqueued
 
@@ -62,10 +53,7 @@ def _same_dtype(ref: torch.Tensor, tensors: Sequence[torch.Tensor], what: str) -
 # ----------------------------------------------------------------------------------------------------
 def text_time(media_locations: torch.Tensor) -> torch.Tensor:
     """cumsum(media_locations, -1) as int32 (gated_cross_attention.py:97), computed once per step."""
-    if not media_locations.is_cuda:
-        if _checker_backend is not None:
-            return media_locations.to(torch.int64).cumsum(-1).to(torch.int32)
-        ffi.require_cuda(media_locations)
+    ffi.require_cuda(media_locations)
     ml = media_locations
     if ml.dtype == torch.bool:
         ml = ml.view(torch.uint8)
@@ -125,8 +113,6 @@ class _ResamplerFn(torch.autograd.Function):
 
 def resampler(x_f: torch.Tensor, params: Sequence[torch.Tensor], cfg) -> torch.Tensor:
     """x_f (b, T, v, d) -> (b, num_latents, d).  `params` in the order documented in flamingo_fusion.h."""
-    if not x_f.is_cuda and _checker_backend is not None:
-        return _checker_backend.resampler(x_f, params, cfg)
     ffi.require_cuda(x_f, *params)
     _same_dtype(x_f, params, "PerceiverResampler")
     assert len(params) == ffi.RESAMPLER_GLOBAL_PARAMS + ffi.RESAMPLER_LAYER_PARAMS * cfg[0]
@@ -198,8 +184,6 @@ def xattn_block(y: torch.Tensor, visual_features: Optional[torch.Tensor], tt: to
                 n_visual: int, previous_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, output_kv: bool = False):
     """GatedCrossAttentionBlock forward.  cfg = (heads, dim_head, ff_mult, act); tt = text_time int32 (b, L_total).
     Returns (y_out, (k, v) or None)."""
-    if not y.is_cuda and _checker_backend is not None:
-        return _checker_backend.xattn_block(y, visual_features, tt, params, cfg, n_visual, previous_kv, output_kv)
     ffi.require_cuda(y, tt, *params)
     _same_dtype(y, params, "GatedCrossAttentionBlock")
     heads, dim_head = cfg[0], cfg[1]

@@ -1,6 +1,6 @@
-"""TESTS ONLY: lets the drop-in modules run on CPU by routing the two fused ops to the numpy oracle (forward and its
-hand-written backward) behind torch.autograd.Function.  Installed with functional.set_checker_backend(); the product
-never does this — without it CPU tensors raise."""
+"""TESTS ONLY: lets the drop-in modules run on CPU for HF-plumbing checks by MONKEYPATCHING the three entry points of
+flamingo_mini_amd.functional (resampler, xattn_block, text_time) with the numpy oracle (forward and its hand-written
+backward) behind torch.autograd.Function.  The product package has no such path: without this patch CPU tensors raise."""
 import numpy as np
 import torch
 
@@ -80,3 +80,26 @@ class OracleBackend:
         out, _, _ = O.gated_xattn_block_fwd(_np(y), None, ml, p, heads=heads, dim_head=dim_head, act=act, n_visual=n_visual,
                                             previous_kv=(_np(previous_kv[0]), _np(previous_kv[1])))
         return torch.from_numpy(out).to(y.dtype), (previous_kv if output_kv else None)
+
+
+_saved = {}
+
+
+def install():
+    """Patch flamingo_mini_amd.functional to run on the oracle (CPU).  Undo with uninstall()."""
+    from flamingo_mini_amd import functional as F
+    if _saved:
+        return
+    backend = OracleBackend()
+    _saved.update(resampler=F.resampler, xattn_block=F.xattn_block, text_time=F.text_time)
+    F.resampler = lambda x_f, params, cfg: backend.resampler(x_f, params, cfg)
+    F.xattn_block = lambda y, vf, tt, params, cfg, n_visual, previous_kv=None, output_kv=False: \
+        backend.xattn_block(y, vf, tt, params, cfg, n_visual, previous_kv, output_kv)
+    F.text_time = lambda ml: ml.to(torch.int64).cumsum(-1).to(torch.int32)
+
+
+def uninstall():
+    from flamingo_mini_amd import functional as F
+    for k, v in _saved.items():
+        setattr(F, k, v)
+    _saved.clear()

@@ -24,10 +24,9 @@ def _build_tiny():
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    from flamingo_mini_amd import functional
-    from oracle_backend import OracleBackend
+    import oracle_backend
     from test_model_plumbing import build
-    functional.set_checker_backend(OracleBackend())     # CPU ranks: fused ops run on the oracle (tests only)
+    oracle_backend.install()                            # CPU ranks: fused entry points patched to the oracle (tests only)
     model, z = build(torch.float64, "cpu")
     return model.train(), z
 

@@ -1,7 +1,7 @@
 """The drop-in FlamingoModel (HF backbones + LM-layer interleave hooks) against a tiny FULL reference model
 (tests/golden/full_opt_tiny.npz: reference FlamingoModel, OPT-backed, fp64): the reference state_dict must load by name,
 and logits / loss / trainable gradients / cached decode must agree.
-  * CPU (`not gpu`): the fused ops are routed to the numpy oracle (tests-only checker backend) -> pure plumbing check.
+  * CPU (`not gpu`): the fused entry points are monkeypatched to the numpy oracle (tests/oracle_backend.py) -> pure plumbing check.
   * GPU: the same model on the HIP kernels in fp32 (logits within 1e-3 rel is the stated target; we assert 1e-4)."""
 import os
 
@@ -66,17 +66,16 @@ def run_checks(model, z, device, dtype, tol_out, tol_grad):
 
 
 def test_full_model_plumbing_cpu_with_oracle_checker():
-    from flamingo_mini_amd import functional
-    from oracle_backend import OracleBackend
-    functional.set_checker_backend(OracleBackend())
+    import oracle_backend
+    oracle_backend.install()
     try:
         model, z = build(torch.float64, "cpu")
         run_checks(model, z, "cpu", torch.float64, 1e-9, 1e-8)
     finally:
-        functional.set_checker_backend(None)
+        oracle_backend.uninstall()
 
 
-def test_cpu_tensors_raise_without_checker():
+def test_cpu_tensors_raise_in_the_product_path():
     from flamingo_mini_amd import PerceiverResampler, ffi
     m = PerceiverResampler(dim=64, depth=1, heads=2, dim_head=16, num_latents=8)
     with pytest.raises(ffi.FusionLibraryError):

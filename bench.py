@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--clip", default="openai/clip-vit-large-patch14")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"], help="fused = ff_adamw_step (this library), torch = torch.optim.AdamW(fused=True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
@@ -177,7 +178,13 @@ def main():
     batch = synthetic_batch(args, cfg, device, dtype, rank)
     params = [p for p in model.parameters_trainable()]
     n_trainable = sum(p.numel() for p in params)
-    opt = None if args.no_optimizer else torch.optim.AdamW(params, lr=1e-4, fused=True)
+    if args.no_optimizer:
+        opt = None
+    elif args.optimizer == "fused":
+        from flamingo_mini_amd import FusedAdamW
+        opt = FusedAdamW(params, lr=1e-4)
+    else:
+        opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
     reducer = GradientAllReducer(model)
 
     def step():
@@ -251,7 +258,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"flamingo-mini ({args.lm} + {args.clip}), 1 image (224x224) + {args.seq_len} tokens per sequence, "
                                    f"per-GPU batch {args.batch}; step = fwd + bwd + grad all-reduce"
-                                   + ("" if args.no_optimizer else " + fused AdamW") + "; random-init weights, gates alpha=0.5",
+                                   + ("" if args.no_optimizer else f" + AdamW ({args.optimizer})") + "; random-init weights, gates alpha=0.5",
                        "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                        "trainable_params": n_trainable, "loss": round(loss_val, 4)},
             "roofline": roofline,

@@ -1,0 +1,102 @@
+// Fused multi-tensor AdamW for the trainable parameters (resampler, gated xattn blocks, token embedding): SURVEY.md 8f2.
+// One pass over param / grad / exp_avg / exp_avg_sq per step, fp32 math, 16-byte vector streams, up to 32 tensors per launch
+// (the table travels in the kernel argument).  Semantics = torch.optim.AdamW (decoupled weight decay, bias correction):
+//     p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// Reference training recipe: `--optim adamw_torch`, lr 1e-4 (training/train.sh:10-13).  HBM-bound: 7 streams per element.
+#include "ff_common.h"
+#include "ff_internal.h"
+
+namespace ff {
+
+constexpr int kAdamTensors = 32;
+constexpr int kAdamChunk = 256 * 32;   // elements per workgroup
+
+struct AdamTable {
+    void* p[kAdamTensors];
+    const void* g[kAdamTensors];
+    void* m[kAdamTensors];
+    void* v[kAdamTensors];
+    long long n[kAdamTensors];
+    int block_start[kAdamTensors + 1];
+    int count;
+    float lr, beta1, beta2, eps, decay, bc1, bc2_sqrt, grad_scale;
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
+    int ti = 0;
+#pragma unroll 1
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.block_start[ti + 1]) ti++;
+    const long long n = t.n[ti];
+    const long long base = (long long)((int)blockIdx.x - t.block_start[ti]) * kAdamChunk;
+    T* p = (T*)t.p[ti];
+    const T* g = (const T*)t.g[ti];
+    T* m = (T*)t.m[ti];
+    T* v = (T*)t.v[ti];
+    const float step_size = t.lr / t.bc1, keep = 1.f - t.lr * t.decay;
+    const bool vec = VEC > 1 && n % VEC == 0 && ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0;
+    for (long long i = base + (long long)threadIdx.x * VEC; i < min(n, base + kAdamChunk); i += 256 * VEC) {
+        float pf[VEC], gf[VEC], mf[VEC], vf[VEC];
+        if (vec) {
+            Vec<T>::load(p + i, pf); Vec<T>::load(g + i, gf); Vec<T>::load(m + i, mf); Vec<T>::load(v + i, vf);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                const bool ok = i + e < n;
+                pf[e] = ok ? to_f32(p[i + e]) : 0.f; gf[e] = ok ? to_f32(g[i + e]) : 0.f;
+                mf[e] = ok ? to_f32(m[i + e]) : 0.f; vf[e] = ok ? to_f32(v[i + e]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const float gr = gf[e] * t.grad_scale;
+            pf[e] *= keep;
+            mf[e] = t.beta1 * mf[e] + (1.f - t.beta1) * gr;
+            vf[e] = t.beta2 * vf[e] + (1.f - t.beta2) * gr * gr;
+            pf[e] -= step_size * mf[e] / (sqrtf(vf[e]) / t.bc2_sqrt + t.eps);
+        }
+        if (vec) {
+            Vec<T>::store(p + i, pf); Vec<T>::store(m + i, mf); Vec<T>::store(v + i, vf);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; e++)
+                if (i + e < n) { p[i + e] = from_f32<T>(pf[e]); m[i + e] = from_f32<T>(mf[e]); v[i + e] = from_f32<T>(vf[e]); }
+        }
+    }
+}
+
+}  // namespace ff
+
+extern "C" int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const void* const* grads, void* const* exp_avg,
+                             void* const* exp_avg_sq, const long long* numels, ff_stream_t stream) {
+    using namespace ff;
+    FF_CHECK(d && params && grads && exp_avg && exp_avg_sq && numels, FF_ERR_SHAPE, "ff_adamw_step: null argument");
+    FF_CHECK(d->dtype == FF_DTYPE_F32 || d->dtype == FF_DTYPE_BF16, FF_ERR_UNSUPPORTED, "ff_adamw_step: dtype %d", d->dtype);
+    FF_CHECK(d->n_tensors >= 0 && d->step >= 1, FF_ERR_SHAPE, "ff_adamw_step: n_tensors=%d step=%d", d->n_tensors, d->step);
+    AdamTable t;
+    t.lr = d->lr; t.beta1 = d->beta1; t.beta2 = d->beta2; t.eps = d->eps; t.decay = d->weight_decay;
+    t.bc1 = 1.f - powf(d->beta1, (float)d->step);
+    t.bc2_sqrt = sqrtf(1.f - powf(d->beta2, (float)d->step));
+    t.grad_scale = d->grad_scale == 0.f ? 1.f : d->grad_scale;
+    int i = 0;
+    while (i < d->n_tensors) {
+        int cnt = 0, blocks = 0;
+        while (i < d->n_tensors && cnt < kAdamTensors) {
+            if (numels[i] > 0) {
+                FF_CHECK(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i], FF_ERR_SHAPE, "ff_adamw_step: tensor %d has a null pointer", i);
+                t.p[cnt] = params[i]; t.g[cnt] = grads[i]; t.m[cnt] = exp_avg[i]; t.v[cnt] = exp_avg_sq[i]; t.n[cnt] = numels[i];
+                t.block_start[cnt] = blocks;
+                blocks += cdiv(numels[i], kAdamChunk);
+                cnt++;
+            }
+            i++;
+        }
+        if (!cnt) break;
+        t.block_start[cnt] = blocks;
+        t.count = cnt;
+        if (d->dtype == FF_DTYPE_BF16) adamw_kernel<bf16, 8><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(t);
+        else adamw_kernel<float, 4><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(t);
+        FF_TRY(check_launch("adamw"));
+    }
+    return FF_OK;
+}

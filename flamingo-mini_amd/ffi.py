@@ -73,6 +73,11 @@ class ResamplerDesc(C.Structure):
                 ("ff_mult", C.c_int), ("act", C.c_int)]
 
 
+class AdamWDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("n_tensors", C.c_int), ("step", C.c_int), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float)]
+
+
 class XattnDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("batch", C.c_int), ("n_tokens", C.c_int), ("dim", C.c_int), ("dim_visual", C.c_int),
                 ("n_media", C.c_int), ("n_visual", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int), ("ff_mult", C.c_int),
@@ -110,6 +115,7 @@ _SIGNATURES = {
     "ff_xattn_scratch_bytes": (_SZ, [C.POINTER(XattnDesc)]),
     "ff_xattn_kv_offset": (_SZ, [C.POINTER(XattnDesc)]),
     "ff_xattn_block_fwd": (_I, [C.POINTER(XattnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
+    "ff_adamw_step": (_I, [C.POINTER(AdamWDesc), _P, _P, _P, _P, _P, _P]),
     "ff_xattn_block_bwd": (_I, [C.POINTER(XattnDesc), _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -12,6 +12,7 @@
  *   ff_xattn_block_fwd/bwd   GatedCrossAttentionBlock.forward + autograd  flamingo_mini/gated_cross_attention.py:160-184
  *                            (MaskedCrossAttention.forward :42-131, cached K/V path :88-92,102-104)
  *   ff_text_time             media_locations.cumsum(dim=-1)               flamingo_mini/gated_cross_attention.py:97
+ *   ff_adamw_step            torch AdamW over parameters_trainable()      training/train.sh:10-13, modeling_flamingo.py:132-138
  * The primitive entry points (ff_gemm, ff_layernorm_*, ff_attention_*, ff_rows_reduce, ff_gate_grad) are the
  * kernels those are built from; they are exported so each can be parity-tested on its own.
  */
@@ -220,6 +221,22 @@ int ff_xattn_block_bwd(const ff_xattn_desc* d, const void* y, const void* visual
                        const void* const* params, const void* dy_out, const void* saved, size_t saved_bytes,
                        void* const* grads, void* dy, void* dvisual_features, void* scratch, size_t scratch_bytes,
                        ff_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW over the trainable parameters (the reference trains with `--optim adamw_torch`,
+ * training/train.sh:10-13; parameters_trainable() modeling_flamingo.py:132-138).  All tensors of one call share `dtype`
+ * (params, grads and both moment buffers); math is fp32.  step is the 1-based step count AFTER incrementing
+ * (bias corrections 1 - beta^step).  grad_scale multiplies every gradient first (0 = 1.0; e.g. 1/world after a SUM all-reduce).
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct ff_adamw_desc {
+    int dtype;
+    int n_tensors;
+    int step;
+    float lr, beta1, beta2, eps, weight_decay, grad_scale;
+} ff_adamw_desc;
+int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const void* const* grads, void* const* exp_avg,
+                  void* const* exp_avg_sq, const long long* numels, ff_stream_t stream);
 
 #ifdef __cplusplus
 }

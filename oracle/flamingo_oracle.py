@@ -345,3 +345,16 @@ def xattn_block_flops_fwd(b, L, d, dv, N=1, q=64, h=8, dh=64, ff_mult=4):
     inner = h * dh
     per = 2 * L * d * inner + 4 * N * q * dv * inner + 4 * h * L * N * q * dh + 2 * L * inner * d + 4 * L * d * ff_mult * d
     return b * per
+
+
+# ----------------------------------------------------------------------------------------
+# AdamW (the reference trains with HF Trainer `--optim adamw_torch`, training/train.sh:10-13): torch.optim.AdamW's rule
+# ----------------------------------------------------------------------------------------
+def adamw_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2):
+    """One decoupled-weight-decay Adam step on numpy arrays; returns new (p, m, v).  `step` is 1-based."""
+    p = p * (1.0 - lr * weight_decay)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    p = p - (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + eps)
+    return p, m, v

@@ -217,6 +217,51 @@ def xattn_block(y: torch.Tensor, visual_features: Optional[torch.Tensor], tt: to
 
 
 # ----------------------------------------------------------------------------------------------------
+# shifted cross-entropy (modeling_flamingo.py:288-298)
+# ----------------------------------------------------------------------------------------------------
+class _ShiftedCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        lib = ffi.lib()
+        logits = logits.contiguous()
+        labels = labels.contiguous().to(torch.int64)
+        b, L, V = logits.shape
+        rows = torch.empty(b * (L - 1), dtype=torch.float32, device=logits.device)
+        lse = torch.empty_like(rows)
+        ffi.check(lib.ff_shifted_ce_fwd(ffi.dtype_code(logits.dtype), b, L, V, logits.data_ptr(), labels.data_ptr(), ignore_index,
+                                        rows.data_ptr(), lse.data_ptr(), ffi.stream_handle(logits.device)), "ff_shifted_ce_fwd")
+        ctx.ignore_index = ignore_index
+        ctx.save_for_backward(logits, labels, lse)
+        return rows
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        lib = ffi.lib()
+        logits, labels, lse = ctx.saved_tensors
+        b, L, V = logits.shape
+        dlogits = torch.empty_like(logits)
+        g = grad_rows.contiguous().float()
+        ffi.check(lib.ff_shifted_ce_bwd(ffi.dtype_code(logits.dtype), b, L, V, logits.data_ptr(), labels.data_ptr(), ctx.ignore_index,
+                                        lse.data_ptr(), g.data_ptr(), dlogits.data_ptr(), ffi.stream_handle(logits.device)), "ff_shifted_ce_bwd")
+        return dlogits, None, None
+
+
+def shifted_cross_entropy(logits: torch.Tensor, labels: torch.Tensor, reduction: str = "mean", ignore_index: int = -100) -> torch.Tensor:
+    """F.cross_entropy(logits[..., :-1, :].reshape(-1, V), labels[..., 1:].reshape(-1), reduction=reduction) in two fused passes
+    (fp32 math).  logits (b, L, V) float32 / bfloat16 on the GPU, labels (b, L) integer."""
+    ffi.require_cuda(logits, labels)
+    rows = _ShiftedCEFn.apply(logits, labels, ignore_index)
+    if reduction == "none":
+        return rows
+    if reduction == "sum":
+        return rows.sum()
+    if reduction == "mean":
+        count = (labels[..., 1:] != ignore_index).sum().clamp_min(1)
+        return rows.sum() / count
+    raise ValueError(f"unknown reduction {reduction}")
+
+
+# ----------------------------------------------------------------------------------------------------
 # primitive wrappers (parity tests / micro-benchmarks): thin, allocation + one C call each
 # ----------------------------------------------------------------------------------------------------
 def gemm(A, B, *, a_layout=0, b_layout=0, scale=1.0, act=None, act_bwd=None, aux_in=None, residual=None, gate=None,

@@ -150,13 +150,14 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
         new_xattn_past = [hook.kv_output for hook in self.get_modified_layers()] if use_cache else None
 
         loss = None
-        if labels is not None:   # tokens < n predict n
-            shift_logits = logits[..., :-1, :].contiguous()
-            shift_labels = labels[..., 1:].contiguous()
-            flat = shift_logits.view(-1, shift_logits.size(-1))
-            if flat.dtype in (torch.bfloat16, torch.float16):
-                flat = flat.float()      # log-softmax over ~50k classes in fp32 (the reference stays in the autocast dtype)
-            loss = TF.cross_entropy(flat, shift_labels.view(-1), reduction=loss_reduction)
+        if labels is not None:   # tokens < n predict n (reference :288-298)
+            if logits.is_cuda and logits.dtype in (torch.float32, torch.bfloat16) and logits.ndim == 3 and seq_length > 1:
+                loss = F.shifted_cross_entropy(logits, labels, reduction=loss_reduction)      # two fused passes over the logits
+            else:   # host-side / exotic dtypes: the stock op (the loss is not part of the accelerated fusion path)
+                flat = logits[..., :-1, :].contiguous().view(-1, logits.size(-1))
+                if flat.dtype in (torch.bfloat16, torch.float16):
+                    flat = flat.float()
+                loss = TF.cross_entropy(flat, labels[..., 1:].contiguous().view(-1), reduction=loss_reduction)
 
         return CausalLMOutputWithPast(
             loss=loss, logits=logits,

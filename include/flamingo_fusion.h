@@ -12,6 +12,7 @@
  *   ff_xattn_block_fwd/bwd   GatedCrossAttentionBlock.forward + autograd  flamingo_mini/gated_cross_attention.py:160-184
  *                            (MaskedCrossAttention.forward :42-131, cached K/V path :88-92,102-104)
  *   ff_text_time             media_locations.cumsum(dim=-1)               flamingo_mini/gated_cross_attention.py:97
+ *   ff_shifted_ce_fwd/bwd    shifted F.cross_entropy on the logits        flamingo_mini/modeling_flamingo.py:288-298
  *   ff_adamw_step            torch AdamW over parameters_trainable()      training/train.sh:10-13, modeling_flamingo.py:132-138
  * The primitive entry points (ff_gemm, ff_layernorm_*, ff_attention_*, ff_rows_reduce, ff_gate_grad) are the
  * kernels those are built from; they are exported so each can be parity-tested on its own.
@@ -237,6 +238,19 @@ typedef struct ff_adamw_desc {
 } ff_adamw_desc;
 int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const void* const* grads, void* const* exp_avg,
                   void* const* exp_avg_sq, const long long* numels, ff_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------------------
+ * Shifted next-token cross-entropy (modeling_flamingo.py:288-298): position i predicts labels[i+1].
+ * logits (batch, seq, vocab) contiguous; labels (batch, seq) int64; rows = batch * (seq - 1).
+ * fwd: loss_row[r] = logsumexp(logits[b,i,:]) - logits[b,i,labels[b,i+1]] (0 where the label == ignore_index), lse[r] saved.
+ * bwd: dlogits[b,i,:] = (softmax - onehot) * grad_row[r];  dlogits[b,seq-1,:] = 0.   The reduction (mean over the
+ * non-ignored rows / sum / none) is applied by the caller on the `rows` values.
+ * ------------------------------------------------------------------------------------------------------ */
+int ff_shifted_ce_fwd(int dtype, int batch, int seq, int vocab, const void* logits, const long long* labels, long long ignore_index,
+                      float* loss_row, float* lse, ff_stream_t stream);
+int ff_shifted_ce_bwd(int dtype, int batch, int seq, int vocab, const void* logits, const long long* labels, long long ignore_index,
+                      const float* lse, const float* grad_row, void* dlogits, ff_stream_t stream);
 
 #ifdef __cplusplus
 }

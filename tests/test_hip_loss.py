@@ -1,0 +1,28 @@
+"""Fused shifted cross-entropy (ff_shifted_ce_fwd/bwd) against torch's F.cross_entropy on shifted logits (float64 on CPU)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from util import dev, rel, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+def test_shifted_cross_entropy_matches_torch(dtype, reduction):
+    from flamingo_mini_amd import functional as F
+    b, L, V = 3, 9, 50258                                        # gpt2 vocabulary + <EOC>: rows are not 16-byte aligned
+    logits = dev(rnd((b, L, V), 1, 3.0), dtype).requires_grad_(True)
+    labels = torch.from_numpy(np.random.default_rng(2).integers(0, V, (b, L))).cuda()
+    labels[1, 4] = -100                                          # ignored position
+    loss = F.shifted_cross_entropy(logits, labels, reduction=reduction)
+    w = dev(rnd(tuple(loss.shape), 3)) if reduction == "none" else None
+    (loss * w).sum().backward() if w is not None else loss.backward()
+    ref_logits = logits.detach().double().cpu().requires_grad_(True)
+    ref = TF.cross_entropy(ref_logits[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1).cpu(), reduction=reduction)
+    (ref * w.double().cpu()).sum().backward() if w is not None else ref.backward()
+    assert rel(loss, ref.detach()) < (1e-6 if dtype == torch.float32 else 1e-5)          # fp32 math on the same (rounded) logits
+    assert rel(logits.grad, ref_logits.grad) < (1e-5 if dtype == torch.float32 else 8e-3)   # gradient is stored in the logits dtype
+    assert float(logits.grad[:, -1].abs().max()) == 0.0 and float(logits.grad[1, 3].abs().max()) == 0.0

@@ -8,6 +8,8 @@ def category(name):
     if "ff::gemm_bf16" in name or "ff16gemm" in name or "gemm_f32" in name: return "fusion: GEMM main kernels (hand-written MFMA)"
     if "gemm_splitk" in name: return "fusion: split-K reduce + epilogue"
     if "attn_fwd_kernel" in name or "attn_bwd" in name: return "fusion: attention core (fwd, dQ, dK/dV)"
+    if "adamw_kernel" in name: return "fusion: multi-tensor AdamW (ff_adamw_step)"
+    if "shifted_ce" in name: return "fusion: shifted cross-entropy (fwd + bwd)"
     if "ff::" in name or "_ZN2ff" in name: return "fusion: LayerNorm / reductions / gates"
     if name.startswith("Cijk_"): return "stock: hipBLASLt GEMMs (CLIP, GPT-2, lm_head)"
     if "multi_tensor_apply" in name: return "stock: fused AdamW"

@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"], help="fused = ff_adamw_step (this library), torch = torch.optim.AdamW(fused=True)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a captured HIP graph (auto = on for 1 GPU; the all-reduce of N > 1 is not captured)")
+    ap.add_argument("--profile-steps", type=int, default=3, help="instrumented eager steps after the timed region (roofline objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
@@ -178,16 +181,17 @@ def main():
     batch = synthetic_batch(args, cfg, device, dtype, rank)
     params = [p for p in model.parameters_trainable()]
     n_trainable = sum(p.numel() for p in params)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     if args.no_optimizer:
         opt = None
     elif args.optimizer == "fused":
         from flamingo_mini_amd import FusedAdamW
-        opt = FusedAdamW(params, lr=1e-4)
+        opt = FusedAdamW(params, lr=1e-4, capturable=use_graph)
     else:
-        opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
+        opt = torch.optim.AdamW(params, lr=1e-4, fused=True, capturable=use_graph)
     reducer = GradientAllReducer(model)
 
-    def step():
+    def eager_step():
         model.zero_grad(set_to_none=True)
         out = model(**batch)
         out.loss.backward()
@@ -196,12 +200,16 @@ def main():
             opt.step()
         return out.loss
 
+    if use_graph:       # forward + backward + optimizer captured once, one graph launch per step (flamingo_mini_amd/graphs.py)
+        from flamingo_mini_amd import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1))
+        step = graphed
+    else:
+        step = eager_step
+
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    max_rec = 4096 * max(args.steps, 1)
-    if rank == 0:
-        lib.ff_gemm_profile_enable(max_rec)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -216,16 +224,31 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # Roofline leg: HIP events cannot be recorded inside a replayed graph and cost ~2 ms/step when they bracket every launch, so
+    # the per-launch durations come from `--profile-steps` eager steps of the same workload right after the timed region.
+    prof_steps = max(args.profile_steps, 0)
+    max_rec = 4096 * max(prof_steps, 1)
+    eager_ms = None
+    if prof_steps:
+        if rank == 0:
+            lib.ff_gemm_profile_enable(max_rec)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            loss = eager_step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t1) / prof_steps * 1e3
     loss_val = float(loss.float().item())
 
     if rank == 0:
-        groups, shapes, attn = gemm_profile_summary(lib, ffi, max_rec)
+        groups, shapes, attn = gemm_profile_summary(lib, ffi, max_rec) if prof_steps else ({}, {}, {})
         if args.gemm_table:
             with open(args.gemm_table, "w") as f:
                 f.write("M N K nz aL bL tile splitK launches/step us/launch TF/s ms/step\n")
                 for k, g in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
-                    f.write(" ".join(map(str, k)) + f" {g['launches'] / args.steps:.1f} {g['ms'] / g['launches'] * 1e3:.1f} "
-                            f"{g['flops'] / (g['ms'] * 1e-3) / 1e12:.1f} {g['ms'] / args.steps:.3f}\n")
+                    f.write(" ".join(map(str, k)) + f" {g['launches'] / prof_steps:.1f} {g['ms'] / g['launches'] * 1e3:.1f} "
+                            f"{g['flops'] / (g['ms'] * 1e-3) / 1e12:.1f} {g['ms'] / prof_steps:.3f}\n")
         ms_per_step = elapsed / args.steps * 1e3
         images = args.batch * world * args.steps
         roofline = None
@@ -249,8 +272,10 @@ def main():
                         "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
                         "avg_launch_gflop": round(g["flops"] / g["launches"] / 1e9, 3),
                         "all_fusion_gemms": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                             "ms_per_step": round(tot_ms / args.steps, 3),
-                                             "share_of_step": round(tot_ms / args.steps / ms_per_step, 3)}}
+                                             "ms_per_step": round(tot_ms / prof_steps, 3),
+                                             "share_of_step": round(tot_ms / prof_steps / ms_per_step, 3)},
+                        "measured": f"HIP events around every launch in {prof_steps} eager steps of the same workload run right after the "
+                                    f"timed region ({eager_ms:.2f} ms/step with the instrumentation)"}
         result = {
             "metric": "images/sec (fwd+bwd) flamingo-mini bs=32",
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -258,9 +283,10 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"flamingo-mini ({args.lm} + {args.clip}), 1 image (224x224) + {args.seq_len} tokens per sequence, "
                                    f"per-GPU batch {args.batch}; step = fwd + bwd + grad all-reduce"
-                                   + ("" if args.no_optimizer else f" + AdamW ({args.optimizer})") + "; random-init weights, gates alpha=0.5",
+                                   + ("" if args.no_optimizer else f" + AdamW ({args.optimizer})")
+                                   + ("; step replayed from a captured HIP graph" if use_graph else "; eager launches") + "; random-init weights, gates alpha=0.5",
                        "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
-                       "trainable_params": n_trainable, "loss": round(loss_val, 4)},
+                       "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph},
             "roofline": roofline,
         }
         if attn:    # north star: throughput of the softmax(QK^T)V core as a fraction of the HBM roofline (8 TB/s spec peak)

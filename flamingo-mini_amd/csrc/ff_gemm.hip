@@ -9,6 +9,7 @@
 //
 // Accumulators are kept transposed (D[n][m] = mfma(Bfrag, Afrag)) so a lane owns 4 consecutive n of one row m
 // and the epilogue issues 8/16-byte row-contiguous loads and stores.
+#include <type_traits>
 #include "ff_common.h"
 #include <stdlib.h>
 #include "ff_internal.h"
@@ -74,6 +75,125 @@ FF_DEV void epilogue4(const GemmParams& P, const GemmProblem& pr, int m, int n, 
     store4(pr.C, v);
 }
 
+// 8 consecutive columns [n, n + nv) of output row m: scale -> aux_out -> tanh-gate -> act -> act'(aux_in) -> + residual -> C.
+// `vec`: all of C / aux / residual may be touched with 16-byte accesses (host flag c_vec8) and nv == 8.  `gate` = tanh(*gate) or 1.
+// F < 0: which steps exist is decided at run time; F >= 0: bit mask of kEpi* (the branches fold away, see tile_epilogue_bf16).
+constexpr int kEpiAux = 1, kEpiGate = 2, kEpiAct = 4, kEpiActBwd = 8, kEpiRes = 16;
+template <typename T, int F = -1>
+FF_DEV void epilogue8(const GemmParams& P, const GemmProblem& pr, int m, int n, int nv, bool vec, float gate, float (&v)[8]) {
+    constexpr int VN = Vec<T>::N;   // 8 bf16 or 4 floats per 16 bytes
+    const bool has_aux = F < 0 ? pr.aux_out != nullptr : (F & kEpiAux) != 0, has_gate = F < 0 || (F & kEpiGate);
+    const bool has_act = F < 0 ? P.act >= 0 : (F & kEpiAct) != 0, has_act_bwd = F < 0 ? P.act_bwd >= 0 : (F & kEpiActBwd) != 0;
+    const bool has_res = F < 0 ? pr.residual != nullptr : (F & kEpiRes) != 0;
+    auto load8 = [&](const void* base, long long at, float (&o)[8]) {
+        const T* p = (const T*)base + at;
+        if (vec) {
+            if constexpr (VN == 8) Vec<T>::load(p, o);
+            else {
+                float a[VN], b[VN];
+                Vec<T>::load(p, a); Vec<T>::load(p + VN, b);
+#pragma unroll
+                for (int e = 0; e < VN; e++) { o[e] = a[e]; o[e + 4] = b[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = e < nv ? to_f32(p[e]) : 0.f;
+        }
+    };
+    auto store8 = [&](void* base, long long at, const float (&o)[8]) {
+        T* p = (T*)base + at;
+        if (vec) {
+            if constexpr (VN == 8) Vec<T>::store(p, o);
+            else {
+                float a[VN], b[VN];
+#pragma unroll
+                for (int e = 0; e < VN; e++) { a[e] = o[e]; b[e] = o[e + 4]; }
+                Vec<T>::store(p, a); Vec<T>::store(p + VN, b);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (e < nv) p[e] = from_f32<T>(o[e]);
+        }
+    };
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] *= P.scale;
+    const long long off = P.c_map.off(m) + n;
+    if (has_aux) store8(pr.aux_out, off, v);
+    if (has_gate) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] *= gate;
+    }
+    if (has_act) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = act_fwd(v[e], P.act);
+    }
+    if (has_act_bwd) {
+        float h[8];
+        load8(pr.aux_in, off, h);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] *= act_grad(h[e], P.act_bwd);
+    }
+    if (has_res) {
+        float q[8];
+        load8(pr.residual, P.r_map.off(m) + n, q);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] += q[e];
+    }
+    store8(pr.C, off, v);
+}
+
+// Epilogue of one bf16 output tile parked in LDS as fp32 (see gemm_bf16_dma_kernel): thread -> 8 consecutive columns of a row,
+// rows strided over the 256 threads in a rolled loop, so the code exists once and every global access is a 16-byte piece of a row.
+template <int BM, int BN>
+FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const float* ct, int m_base, int n_base) {
+    constexpr int TPR = BN / 8, RPP = 256 / TPR;
+    const int t = threadIdx.x, tr = t / TPR, col = (t % TPR) * 8, n = n_base + col;
+    if (n >= P.N) return;
+    const int nv = min(8, P.N - n);
+    const bool vec = P.c_vec8 && nv == 8;
+    const float gate = pr.gate ? tanhf(to_f32(*(const bf16*)pr.gate)) : 1.f;
+    auto rows = [&](auto feat) {   // branch-free row loop for one feature combination, 4 rows in flight
+        constexpr int F = decltype(feat)::value;
+#pragma unroll 4
+        for (int r = tr; r < BM; r += RPP) {
+            const int m = m_base + r;
+            if (m >= P.M) break;
+            const int ch = col >> 2, sw = r & 15;
+            const f32x4 lo = *(const f32x4*)(ct + r * BN + ((ch ^ sw) << 2)), hi = *(const f32x4*)(ct + r * BN + (((ch + 1) ^ sw) << 2));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            epilogue8<bf16, F>(P, pr, m, n, nv, vec, gate, v);
+        }
+    };
+    const int feat = (pr.aux_out ? kEpiAux : 0) | (pr.gate ? kEpiGate : 0) | (P.act >= 0 ? kEpiAct : 0) | (P.act_bwd >= 0 ? kEpiActBwd : 0) |
+                     (pr.residual ? kEpiRes : 0);
+    if (feat == 0) rows(std::integral_constant<int, 0>());                                                      // plain projection / weight gradient
+    else if (feat == kEpiRes) rows(std::integral_constant<int, kEpiRes>());                                         // attention / ff output + skip
+    else if (feat == (kEpiRes | kEpiGate)) rows(std::integral_constant<int, kEpiRes | kEpiGate>());            // ... tanh-gated (xattn block)
+    else if (feat == (kEpiAux | kEpiAct)) rows(std::integral_constant<int, kEpiAux | kEpiAct>());              // ff up-projection
+    else if (feat == kEpiActBwd) rows(std::integral_constant<int, kEpiActBwd>());                              // its dgrad
+    else if (feat == (kEpiActBwd | kEpiGate)) rows(std::integral_constant<int, kEpiActBwd | kEpiGate>());
+    else rows(std::integral_constant<int, -1>());
+}
+
+// Kernel arguments live in HBM and a scalar load that misses costs ~0.7 us; left to itself the compiler fetches them lazily in
+// dependent groups (five of them, 2.4 us, before the first operand load of the MFMA kernel, another one in its epilogue).
+// FF_GEMM_ARGS fetches everything a kernel will ever need in one batch into Q / pr and pins it in SGPRs.
+#define FF_PIN(x) asm volatile("" : "+s"(x))
+#define FF_GEMM_ARGS(Q, pr, P)                                                                                                        \
+    GemmParams Q;                                                                                                                     \
+    Q.M = P.M; Q.N = P.N; Q.K = P.K; Q.split_k = P.split_k; Q.k_per_split = P.k_per_split; Q.nz = P.nz;                              \
+    Q.xcd_ms = P.xcd_ms; Q.xcd_ns = P.xcd_ns; Q.a_map = P.a_map; Q.b_map = P.b_map; Q.c_map = P.c_map; Q.r_map = P.r_map;             \
+    Q.scale = P.scale; Q.act = P.act; Q.act_bwd = P.act_bwd; Q.c_vec8 = P.c_vec8; Q.partial = P.partial;                              \
+    GemmProblem pr = P.p[0];                                                                                                          \
+    FF_PIN(Q.M); FF_PIN(Q.N); FF_PIN(Q.K); FF_PIN(Q.split_k); FF_PIN(Q.k_per_split); FF_PIN(Q.nz); FF_PIN(Q.xcd_ms); FF_PIN(Q.xcd_ns); \
+    FF_PIN(Q.a_map.ld); FF_PIN(Q.a_map.seg_stride); FF_PIN(Q.a_map.rows_per_seg);                                                     \
+    FF_PIN(Q.b_map.ld); FF_PIN(Q.b_map.seg_stride); FF_PIN(Q.b_map.rows_per_seg);                                                     \
+    FF_PIN(Q.c_map.ld); FF_PIN(Q.c_map.seg_stride); FF_PIN(Q.c_map.rows_per_seg);                                                     \
+    FF_PIN(Q.r_map.ld); FF_PIN(Q.r_map.seg_stride); FF_PIN(Q.r_map.rows_per_seg);                                                     \
+    FF_PIN(Q.scale); FF_PIN(Q.act); FF_PIN(Q.act_bwd); FF_PIN(Q.c_vec8); FF_PIN(Q.partial);                                           \
+    FF_PIN(pr.A); FF_PIN(pr.B); FF_PIN(pr.C); FF_PIN(pr.aux_out); FF_PIN(pr.aux_in); FF_PIN(pr.residual); FF_PIN(pr.gate)
+
 // XCD-aware tile order: consecutive logical tiles (same A row panel) land on the same XCD / L2.
 FF_DEV int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -83,30 +203,38 @@ FF_DEV int xcd_remap(int bid, int nwg) {
 struct TileCoord {
     int z, split, tm, tn;
 };
+// a / b for 0 <= a < 2^20, 0 < b: one v_rcp + fix-up instead of the ~35-instruction integer division sequence
+FF_DEV int fast_div(int a, int b) {
+    int q = (int)(__fdividef((float)a, (float)b));
+    if (q * b > a) q--;
+    else if ((q + 1) * b <= a) q++;
+    return q;
+}
 // blockIdx -> (problem, K split, tile).  The 8 XCDs have private L2s and workgroup b runs on XCD b % 8 (observed, used for
-// speed only), so the tile grid is cut into xcd_ms x xcd_ns sub-grids, one per XCD: an XCD then fetches only 1/ms of A's
-// row panels and 1/ns of B's column panels through its L2 (rocprofv3 FETCH_SIZE for 1024x5120x1280: 103 MB with one row
-// panel per XCD - every L2 pulled the whole weight matrix - vs 15.7 MB algorithmic).  The map is a bijection for any
-// grid size: positions are the concatenation of the 8 sub-grids, XCD x takes a contiguous chunk of positions.
-FF_DEV TileCoord tile_coord(const GemmParams& P, int tiles_m, int tiles_n) {
+// speed only), so the tile grid is cut into xcd_ms x xcd_ns sub-grids (powers of two, ms * ns = 8 or 1), one per XCD: an XCD
+// then fetches only 1/ms of A's row panels and 1/ns of B's column panels through its L2 (rocprofv3 FETCH_SIZE for
+// 1024x5120x1280: 103 MB with one row panel per XCD - every L2 pulled the whole weight matrix - vs 15.7 MB algorithmic).
+// The map is a bijection for any grid size: positions are the concatenation of the sub-grids, XCD x takes a contiguous chunk
+// of positions.  Everything here is on the critical path of a ~20 us kernel: shifts and one reciprocal, no integer division.
+FF_DEV TileCoord tile_coord(int nz, int split_k, int ms, int ns, int tiles_m, int tiles_n) {
     const int per_z = tiles_m * tiles_n;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blockIdx.x, per_z * split_k * nz);   // == gridDim.x, without the hidden-argument load
     TileCoord c;
-    c.z = bid / (per_z * P.split_k);
-    bid -= c.z * per_z * P.split_k;
-    c.split = bid / per_z;
-    int p = bid - c.split * per_z;
-    const int ms = P.xcd_ms, ns = P.xcd_ns;
+    c.z = 0; c.split = 0;
+    if (nz > 1) { c.z = fast_div(bid, per_z * split_k); bid -= c.z * per_z * split_k; }
+    if (split_k > 1) { c.split = fast_div(bid, per_z); bid -= c.split * per_z; }
+    int p = bid;
+    const int lm = __builtin_ctz(ms), ln = __builtin_ctz(ns);
     c.tm = 0; c.tn = 0;
     for (int sgrid = 0; sgrid < ms * ns; sgrid++) {
-        const int sm = sgrid / ns, sn = sgrid - sm * ns;
-        const int r0 = sm * tiles_m / ms, r1 = (sm + 1) * tiles_m / ms;
-        const int c0 = sn * tiles_n / ns, c1 = (sn + 1) * tiles_n / ns;
-        const int cnt = (r1 - r0) * (c1 - c0);
+        const int sm = sgrid >> ln, sn = sgrid & (ns - 1);
+        const int r0 = (sm * tiles_m) >> lm, r1 = ((sm + 1) * tiles_m) >> lm;
+        const int c0 = (sn * tiles_n) >> ln, c1 = ((sn + 1) * tiles_n) >> ln;
+        const int cw = c1 - c0, cnt = (r1 - r0) * cw;
         if (p < cnt) {
-            const int cw = c1 - c0;
-            c.tm = r0 + p / cw;
-            c.tn = c0 + p - (p / cw) * cw;
+            const int q = fast_div(p, cw);
+            c.tm = r0 + q;
+            c.tn = c0 + p - q * cw;
             break;
         }
         p -= cnt;
@@ -137,16 +265,15 @@ template <int BR> FF_DEV int mswz(int k) {      // chunk XOR of k-row `k` in an 
 }
 
 template <int BR, int LAYOUT>
-FF_DEV void dma_tile(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const RowMap& map, int row_base, int row_lim, int k0, int k_end,
-                     const unsigned* row_off_bytes, int w, int l) {
+FF_DEV void dma_tile(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const RowMap& map, int row_base, int row_lim, int k0, int k_end, int w, int l) {
     if (LAYOUT == 0) {   // wave instruction = 8 rows x 128 B
         const int cp = l & 7;
 #pragma unroll
         for (int p = 0; p < BR / 32; p++) {
             const int row = p * 32 + w * 8 + (l >> 3);
             const int k = k0 + ((cp ^ (row & 7)) << 3);
-            unsigned off = row_off_bytes[p] + (unsigned)k * 2u;
-            if (row_base + row >= row_lim || k >= k_end) off = kOobOffset;
+            unsigned off = kOobOffset;
+            if (row_base + row < row_lim && k < k_end) off = (unsigned)(map.off(row_base + row) + k) * 2u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + (p * 32 + w * 8) * kBK), 16, off, 0, 0, 0);
         }
     } else {             // wave instruction = 1 KiB of consecutive k-rows (BR*2 bytes each)
@@ -210,38 +337,37 @@ template <int BR, int LAYOUT> FF_DEV bf16x8 frag_read2(const bf16* s, int r0, in
     }
 }
 
+#ifdef FF_GEMM_TIMELINE   // debug build: per-workgroup phase timestamps (100 MHz constant clock), read with ff_debug_timeline_read
+__device__ unsigned long long g_timeline[16384 * 8];
+#define FF_TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FF_TL(i) do { } while (0)
+#endif
+
 template <int N> FF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BM, int BN, int AL, int BL, int NS>
 __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;
+    FF_TL(0);
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
     constexpr int PER_TILE = (AL == 0 ? BM / 32 : BM / 32) + (BL == 0 ? BN / 32 : BN / 32);   // DMA instructions per wave per k-step
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
 
-    const int tiles_m = (P.M + BM - 1) / BM, tiles_n = (P.N + BN - 1) / BN;
-    const TileCoord tc = tile_coord(P, tiles_m, tiles_n);
-    const GemmProblem& pr = P.p[tc.z];
+    FF_GEMM_ARGS(Q, pr, P);
+    const int tiles_m = (Q.M + BM - 1) / BM, tiles_n = (Q.N + BN - 1) / BN;
+    const TileCoord tc = tile_coord(Q.nz, Q.split_k, Q.xcd_ms, Q.xcd_ns, tiles_m, tiles_n);
+    if (tc.z > 0) pr = P.p[tc.z];   // grouped launches only: one more round trip
     const int m_base = tc.tm * BM, n_base = tc.tn * BN;
-    const int k_begin = tc.split * P.k_per_split;
-    const int k_end = min(P.K, k_begin + P.k_per_split);
+    const int k_begin = tc.split * Q.k_per_split;
+    const int k_end = min(Q.K, k_begin + Q.k_per_split);
     const int t = threadIdx.x, l = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pr.A, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)pr.B, 0, 0x7fffffff, 0x00020000);
-
-    unsigned a_off[BM / 32], b_off[BN / 32];
-    if (AL == 0) {
-#pragma unroll
-        for (int p = 0; p < BM / 32; p++) a_off[p] = (unsigned)P.a_map.off(min(m_base + p * 32 + w * 8 + (l >> 3), P.M - 1)) * 2u;
-    }
-    if (BL == 0) {
-#pragma unroll
-        for (int p = 0; p < BN / 32; p++) b_off[p] = (unsigned)P.b_map.off(min(n_base + p * 32 + w * 8 + (l >> 3), P.N - 1)) * 2u;
-    }
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -251,19 +377,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) 
 
     const int nk = (k_end - k_begin + kBK - 1) / kBK;
     unsigned va[BM / 32], vb[BN / 32];
-    dma_prepare<BM, AL>(P.a_map, m_base, P.M, w, l, va);
-    dma_prepare<BN, BL>(P.b_map, n_base, P.N, w, l, vb);
-    const bool a_plain = AL == 0 || P.a_map.rows_per_seg <= 0, b_plain = BL == 0 || P.b_map.rows_per_seg <= 0;
-    const unsigned a_step = AL == 0 ? 2u : (unsigned)P.a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)P.b_map.ld * 2u;   // bytes per unit of k
+    dma_prepare<BM, AL>(Q.a_map, m_base, Q.M, w, l, va);
+    dma_prepare<BN, BL>(Q.b_map, n_base, Q.N, w, l, vb);
+    const bool a_plain = AL == 0 || Q.a_map.rows_per_seg <= 0, b_plain = BL == 0 || Q.b_map.rows_per_seg <= 0;
+    const unsigned a_step = AL == 0 ? 2u : (unsigned)Q.a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)Q.b_map.ld * 2u;   // bytes per unit of k
     auto issue = [&](int tile) {
         bf16* st = smem + (tile % NS) * STAGE;
         const int k0 = k_begin + tile * kBK;
         const bool full = k0 + kBK <= k_end;       // wave-uniform
         if (full && a_plain) dma_tile_fast<BM, AL>(ra, st, va, (unsigned)k0 * a_step, w);
-        else dma_tile<BM, AL>(ra, st, P.a_map, m_base, P.M, k0, k_end, a_off, w, l);
+        else dma_tile<BM, AL>(ra, st, Q.a_map, m_base, Q.M, k0, k_end, w, l);
         if (full && b_plain) dma_tile_fast<BN, BL>(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, w);
-        else dma_tile<BN, BL>(rb, st + A_ELEMS, P.b_map, n_base, P.N, k0, k_end, b_off, w, l);
+        else dma_tile<BN, BL>(rb, st + A_ELEMS, Q.b_map, n_base, Q.N, k0, k_end, w, l);
     };
+    FF_TL(1);
 #pragma unroll
     for (int s = 0; s < NS - 1; s++)
         if (s < nk) issue(s);
@@ -275,6 +402,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) 
         else if (NS >= 3 && younger >= 1) wait_vmcnt<PER_TILE>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // everyone's pieces of tile kt are in LDS; stage (kt-1)%NS is free
+#ifdef FF_GEMM_TIMELINE
+        if (kt == 0) FF_TL(2);
+#endif
         if (kt + NS - 1 < nk) issue(kt + NS - 1);
         const bf16* sA = smem + (kt % NS) * STAGE;
         const bf16* sB = sA + A_ELEMS;
@@ -292,24 +422,41 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) 
         }
     }
 
+    FF_TL(3);
     const int c = l & 15, g = l >> 4;
+    if (Q.split_k > 1) {   // fp32 partial slab; gemm_splitk_epilogue_kernel reduces the slabs and applies the epilogue
 #pragma unroll
-    for (int i = 0; i < MT; i++) {
-        const int m = m_base + wm * WM + i * 16 + c;
-        if (m >= P.M) continue;
+        for (int i = 0; i < MT; i++) {
+            const int m = m_base + wm * WM + i * 16 + c;
+            if (m >= Q.M) continue;
 #pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int n = n_base + wn * WN + j * 16 + g * 4;
-            if (n >= P.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (P.split_k > 1) {
-                float* dst = P.partial + ((long long)(tc.z * P.split_k + tc.split) * P.M + m) * P.N + n;
-                *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                epilogue4<bf16>(P, pr, m, n, v);
+            for (int j = 0; j < NT; j++) {
+                const int n = n_base + wn * WN + j * 16 + g * 4;
+                if (n >= Q.N) continue;
+                *(f32x4*)(Q.partial + ((long long)(tc.z * Q.split_k + tc.split) * Q.M + m) * Q.N + n) = acc[i][j];
             }
         }
+        return;
     }
+    // The operand ring is dead: park the fp32 tile in it (16-byte chunks XOR-swizzled by row) and let one rolled loop apply the
+    // epilogue on row-contiguous 8-element pieces.  Applying it per accumulator fragment inlined the activation code 64 times
+    // (15 k instructions, far beyond the instruction cache: ~8 us per workgroup) and stored 8-byte pieces.
+    static_assert(BM * BN * 4 <= NS * STAGE * 2, "fp32 tile must fit the operand ring");
+    __syncthreads();
+    float* ct = (float*)smem_raw;
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int ml = wm * WM + i * 16 + c;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int ch = ((wn * WN + j * 16) >> 2) + g;
+            *(f32x4*)(ct + ml * BN + ((ch ^ c) << 2)) = acc[i][j];
+        }
+    }
+    __syncthreads();
+    FF_TL(4);
+    tile_epilogue_bf16<BM, BN>(Q, pr, ct, m_base, n_base);
+    FF_TL(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -367,7 +514,7 @@ template <int AL, int BL> __global__ __launch_bounds__(256) void gemm_f32_kernel
     __shared__ __attribute__((aligned(16))) float sA[kFBK * kFLd];
     __shared__ __attribute__((aligned(16))) float sB[kFBK * kFLd];
     const int tiles_m = (P.M + kFBM - 1) / kFBM, tiles_n = (P.N + kFBM - 1) / kFBM;
-    const TileCoord tc = tile_coord(P, tiles_m, tiles_n);
+    const TileCoord tc = tile_coord(P.nz, P.split_k, P.xcd_ms, P.xcd_ns, tiles_m, tiles_n);
     const GemmProblem& pr = P.p[tc.z];
     const int m_base = tc.tm * kFBM, n_base = tc.tn * kFBM;
     const int k_begin = tc.split * P.k_per_split;
@@ -426,24 +573,39 @@ template <int AL, int BL> __global__ __launch_bounds__(256) void gemm_f32_kernel
     }
 }
 
-// split-K: sum the fp32 partial slabs, then the same epilogue
+// split-K: sum the fp32 partial slabs, then the same epilogue.  One thread = 8 consecutive columns of one row (one item per
+// thread, no grid-stride loop); the slabs are read as 16-byte pieces, two splits in flight.
 template <typename T> __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const GemmParams P) {
-    const int n4 = (P.N + 3) / 4;
-    const long long total = (long long)P.nz * P.M * n4;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int nq = (int)(idx % n4);
-        const long long rest = idx / n4;
-        const int m = (int)(rest % P.M), z = (int)(rest / P.M);
-        const int n = nq * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < P.split_k; s++) {
-            const float* src = P.partial + ((long long)(z * P.split_k + s) * P.M + m) * P.N + n;
+    FF_GEMM_ARGS(Q, pr, P);
+    const unsigned n8 = (unsigned)(Q.N + 7) / 8u;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned row = idx / n8, nq = idx - row * n8;        // row = z * M + m
+    if (row >= (unsigned)(Q.nz * Q.M)) return;
+    const int z = Q.nz > 1 ? (int)(row / (unsigned)Q.M) : 0, m = (int)row - z * Q.M, n = (int)nq * 8;
+    if (z > 0) pr = P.p[z];
+    const int nv = min(8, Q.N - n);                             // 4 or 8: the host requires N % 4 == 0 for split-K
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* src = Q.partial + ((long long)z * Q.split_k * Q.M + m) * Q.N + n;
+    const long long slab = (long long)Q.M * Q.N;
+    int sp = 0;
+    for (; sp + 1 < Q.split_k; sp += 2) {
+        const f32x4 a0 = *(const f32x4*)(src + sp * slab), b0 = *(const f32x4*)(src + (sp + 1) * slab);
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, b1 = a1;
+        if (nv == 8) { a1 = *(const f32x4*)(src + sp * slab + 4); b1 = *(const f32x4*)(src + (sp + 1) * slab + 4); }
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (n + r < P.N) v[r] += src[r];
-        }
-        epilogue4<T>(P, P.p[z], m, n, v);
+        for (int e = 0; e < 4; e++) { v[e] += a0[e]; v[e + 4] += a1[e]; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[e + 4] += b1[e]; }
     }
+    if (sp < Q.split_k) {
+        const f32x4 a0 = *(const f32x4*)(src + sp * slab);
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+        if (nv == 8) a1 = *(const f32x4*)(src + sp * slab + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[e] += a0[e]; v[e + 4] += a1[e]; }
+    }
+    const float gate = pr.gate ? tanhf(to_f32(*(const T*)pr.gate)) : 1.f;
+    epilogue8<T>(Q, pr, m, n, nv, Q.c_vec8 && nv == 8, gate, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,6 +790,9 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.a_vec_ok = P.a_vec_ok && ((uintptr_t)P.p[z].A % 16 == 0);
         P.b_vec_ok = P.b_vec_ok && ((uintptr_t)P.p[z].B % 16 == 0);
     }
+    P.c_vec8 = P.N % vec == 0 && map_ok(P.c_map) && map_ok(P.r_map);   // 8-column pieces of C / aux / residual as 16-byte accesses
+    for (int z = 0; z < P.nz; z++)
+        P.c_vec8 = P.c_vec8 && ((uintptr_t)P.p[z].C | (uintptr_t)P.p[z].aux_out | (uintptr_t)P.p[z].aux_in | (uintptr_t)P.p[z].residual) % 16 == 0;
     int rc;
     const int prof_id = prof_begin(P, dtype, P.tile, st);
     if (dtype == FF_DTYPE_BF16) {
@@ -649,8 +814,9 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
     prof_end(prof_id, st);   // the record covers the MFMA main kernel only (what rocprofv3 lists under the same name)
     FF_TRY(rc);
     if (P.split_k > 1) {
-        const long long total = (long long)P.nz * P.M * ((P.N + 3) / 4);
-        const int grid = (int)std::min<long long>((total + 255) / 256, 2048);
+        const long long total = (long long)P.nz * P.M * ((P.N + 7) / 8);
+        FF_CHECK(total < (1LL << 31), FF_ERR_UNSUPPORTED, "gemm split-K output too large (M=%d N=%d nz=%d)", P.M, P.N, P.nz);
+        const int grid = (int)((total + 255) / 256);
         if (dtype == FF_DTYPE_BF16) hipLaunchKernelGGL(gemm_splitk_epilogue_kernel<bf16>, dim3(grid), dim3(256), 0, st, P);
         else hipLaunchKernelGGL(gemm_splitk_epilogue_kernel<float>, dim3(grid), dim3(256), 0, st, P);
         FF_TRY(check_launch("gemm_splitk_epilogue"));
@@ -659,6 +825,12 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
 }
 
 }  // namespace ff
+
+#ifdef FF_GEMM_TIMELINE
+extern "C" int ff_debug_timeline_read(unsigned long long* out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff::g_timeline), sizeof(unsigned long long) * 8 * n_blocks);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // C ABI

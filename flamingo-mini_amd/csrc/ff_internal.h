@@ -27,6 +27,7 @@ struct GemmParams {
     int xcd_ms, xcd_ns;   // XCD partition of the tile grid (ms * ns sub-grids, one per XCD)
     float* partial;
     int a_vec_ok, b_vec_ok;
+    int c_vec8;   // bf16 epilogue may use 16-byte accesses on C / aux / residual
     int nz;
     GemmProblem p[kGemmMaxZ];
 };

@@ -3,6 +3,7 @@
 // (the table travels in the kernel argument).  Semantics = torch.optim.AdamW (decoupled weight decay, bias correction):
 //     p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // Reference training recipe: `--optim adamw_torch`, lr 1e-4 (training/train.sh:10-13).  HBM-bound: 7 streams per element.
+#include <algorithm>
 #include "ff_common.h"
 #include "ff_internal.h"
 
@@ -20,6 +21,7 @@ struct AdamTable {
     int block_start[kAdamTensors + 1];
     int count;
     float lr, beta1, beta2, eps, decay, bc1, bc2_sqrt, grad_scale;
+    const float* step_dev;   // capturable mode: the step count lives on the device (HIP-graph replays cannot change kernel arguments)
 };
 
 template <typename T, int VEC>
@@ -33,7 +35,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
     const T* g = (const T*)t.g[ti];
     T* m = (T*)t.m[ti];
     T* v = (T*)t.v[ti];
-    const float step_size = t.lr / t.bc1, keep = 1.f - t.lr * t.decay;
+    float bc1 = t.bc1, bc2_sqrt = t.bc2_sqrt;
+    if (t.step_dev) {
+        const float step = *t.step_dev;
+        bc1 = 1.f - powf(t.beta1, step);
+        bc2_sqrt = sqrtf(1.f - powf(t.beta2, step));
+    }
+    const float step_size = t.lr / bc1, keep = 1.f - t.lr * t.decay;
     const bool vec = VEC > 1 && n % VEC == 0 && ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0;
     for (long long i = base + (long long)threadIdx.x * VEC; i < min(n, base + kAdamChunk); i += 256 * VEC) {
         float pf[VEC], gf[VEC], mf[VEC], vf[VEC];
@@ -53,7 +61,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
             pf[e] *= keep;
             mf[e] = t.beta1 * mf[e] + (1.f - t.beta1) * gr;
             vf[e] = t.beta2 * vf[e] + (1.f - t.beta2) * gr * gr;
-            pf[e] -= step_size * mf[e] / (sqrtf(vf[e]) / t.bc2_sqrt + t.eps);
+            pf[e] -= step_size * mf[e] / (sqrtf(vf[e]) / bc2_sqrt + t.eps);
         }
         if (vec) {
             Vec<T>::store(p + i, pf); Vec<T>::store(m + i, mf); Vec<T>::store(v + i, vf);
@@ -72,11 +80,12 @@ extern "C" int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const 
     using namespace ff;
     FF_CHECK(d && params && grads && exp_avg && exp_avg_sq && numels, FF_ERR_SHAPE, "ff_adamw_step: null argument");
     FF_CHECK(d->dtype == FF_DTYPE_F32 || d->dtype == FF_DTYPE_BF16, FF_ERR_UNSUPPORTED, "ff_adamw_step: dtype %d", d->dtype);
-    FF_CHECK(d->n_tensors >= 0 && d->step >= 1, FF_ERR_SHAPE, "ff_adamw_step: n_tensors=%d step=%d", d->n_tensors, d->step);
+    FF_CHECK(d->n_tensors >= 0 && (d->step >= 1 || d->step_dev), FF_ERR_SHAPE, "ff_adamw_step: n_tensors=%d step=%d", d->n_tensors, d->step);
     AdamTable t;
     t.lr = d->lr; t.beta1 = d->beta1; t.beta2 = d->beta2; t.eps = d->eps; t.decay = d->weight_decay;
-    t.bc1 = 1.f - powf(d->beta1, (float)d->step);
-    t.bc2_sqrt = sqrtf(1.f - powf(d->beta2, (float)d->step));
+    t.step_dev = d->step_dev;
+    t.bc1 = 1.f - powf(d->beta1, (float)std::max(d->step, 1));
+    t.bc2_sqrt = sqrtf(1.f - powf(d->beta2, (float)std::max(d->step, 1)));
     t.grad_scale = d->grad_scale == 0.f ? 1.f : d->grad_scale;
     int i = 0;
     while (i < d->n_tensors) {

@@ -75,7 +75,7 @@ class ResamplerDesc(C.Structure):
 
 class AdamWDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("n_tensors", C.c_int), ("step", C.c_int), ("lr", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float)]
+                ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("step_dev", C.c_void_p)]
 
 
 class XattnDesc(C.Structure):

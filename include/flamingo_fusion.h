@@ -235,6 +235,8 @@ typedef struct ff_adamw_desc {
     int n_tensors;
     int step;
     float lr, beta1, beta2, eps, weight_decay, grad_scale;
+    const float* step_dev;   /* optional device scalar holding the step count (>= 1): used instead of `step`, so the launch can be
+                              * replayed from a captured HIP graph while the caller advances the counter on the device */
 } ff_adamw_desc;
 int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const void* const* grads, void* const* exp_avg,
                   void* const* exp_avg_sq, const long long* numels, ff_stream_t stream);

@@ -35,3 +35,46 @@ def test_fused_adamw_matches_oracle_and_torch(dtype):
         assert rel(a, b) < tol, SHAPES[i]                                   # and torch's own fused AdamW
     sd = opt_a.state_dict()                                                 # same state layout as torch.optim.AdamW
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
+
+
+def test_fused_adamw_capturable_and_graph_replay():
+    """capturable=True keeps the step count on the device: (a) eager steps equal the host-step mode (device powf vs host powf: ulps),
+    (b) a captured HIP graph replayed n times equals n eager steps, (c) state_dict() reports the device step count."""
+    from flamingo_mini_amd import FusedAdamW
+    shapes = [(129,), (64, 40), (8191,)]
+
+    def make():
+        ps = [torch.nn.Parameter(dev(rnd(s, 10 + i))) for i, s in enumerate(shapes)]
+        gs = [dev(rnd(s, 20 + i, 0.1)) for i, s in enumerate(shapes)]
+        return ps, gs
+
+    p_host, grads = make()
+    p_cap, _ = make()
+    p_graph, _ = make()
+    o_host = FusedAdamW(p_host, lr=1e-2, weight_decay=0.1)
+    o_cap = FusedAdamW(p_cap, lr=1e-2, weight_decay=0.1, capturable=True)
+    o_graph = FusedAdamW(p_graph, lr=1e-2, weight_decay=0.1, capturable=True)
+    for ps in (p_host, p_cap, p_graph):
+        for p, g in zip(ps, grads):
+            p.grad = g.clone()
+    for _ in range(4):
+        o_host.step(); o_cap.step()
+    for a, b in zip(p_host, p_cap):
+        assert rel(a, b) < 1e-6
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        o_graph.step()                                # step 1 eagerly (allocates the state), steps 2..4 from the graph
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o_graph.step()                                # capture does not execute
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(p_host, p_graph):
+        assert rel(a, b) < 1e-6
+    steps = {float(s["step"]) for s in o_graph.state_dict()["state"].values()}
+    assert steps == {4.0}
+    assert "_step_dev" not in o_graph.state_dict()["param_groups"][0]

@@ -182,9 +182,11 @@ FF_DEV void block_range(int lo, int hi, int* sh, int& blo, int& bhi) {
 // forward
 // =====================================================================================================
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const ff_attn_desc d, const T* __restrict__ Q, const T* __restrict__ K,
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const ff_attn_desc d_in, const T* __restrict__ Q, const T* __restrict__ K,
                                                        const T* __restrict__ V, const int* __restrict__ tt, T* __restrict__ O,
                                                        float* __restrict__ lse) {
+    const ff_attn_desc d = fetch_args(d_in);
+    pin_args(Q, K, V, tt, O, lse);
     constexpr int LD = DH + AttnCfg<T>::pad;
     __shared__ __attribute__((aligned(16))) T sK[kTile * LD];
     __shared__ __attribute__((aligned(16))) T sV[kTile * LD];
@@ -258,10 +260,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const ff_attn_desc d, con
 // backward, dQ (own rows = queries).  Also emits Dsum[b][h][q] = sum_d dO*O for the dK/dV kernel.
 // =====================================================================================================
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const ff_attn_desc d, const T* __restrict__ Q, const T* __restrict__ K,
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const ff_attn_desc d_in, const T* __restrict__ Q, const T* __restrict__ K,
                                                           const T* __restrict__ V, const int* __restrict__ tt, const T* __restrict__ O,
                                                           const T* __restrict__ dO, const float* __restrict__ lse, T* __restrict__ dQ,
                                                           float* __restrict__ Dsum) {
+    const ff_attn_desc d = fetch_args(d_in);
+    pin_args(Q, K, V, tt, O, dO, lse, dQ, Dsum);
     constexpr int LD = DH + AttnCfg<T>::pad;
     __shared__ __attribute__((aligned(16))) T sK[kTile * LD];
     __shared__ __attribute__((aligned(16))) T sV[kTile * LD];
@@ -317,10 +321,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const ff_attn_desc d, 
 // backward, dK / dV (own rows = keys)
 // =====================================================================================================
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const ff_attn_desc d, const T* __restrict__ Q, const T* __restrict__ K,
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const ff_attn_desc d_in, const T* __restrict__ Q, const T* __restrict__ K,
                                                            const T* __restrict__ V, const int* __restrict__ tt, const T* __restrict__ dO,
                                                            const float* __restrict__ lse, const float* __restrict__ Dsum,
                                                            T* __restrict__ dK, T* __restrict__ dV) {
+    const ff_attn_desc d = fetch_args(d_in);
+    pin_args(Q, K, V, tt, dO, lse, Dsum, dK, dV);
     constexpr int LD = DH + AttnCfg<T>::pad;
     __shared__ __attribute__((aligned(16))) T sQ[kTile * LD];
     __shared__ __attribute__((aligned(16))) T sDO[kTile * LD];

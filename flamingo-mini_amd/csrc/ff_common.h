@@ -99,6 +99,25 @@ template <int NW> FF_DEV float block_sum(float v, float* red) {
     return s;
 }
 
+// ---- kernel-argument fetch ------------------------------------------------------------------
+// Kernel arguments sit in HBM: a scalar load that misses costs ~0.7 us, and the compiler fetches arguments lazily, where they
+// are first needed - typically 3-5 *dependent* groups before the first vector load of a kernel that itself runs 5-30 us
+// (tools/gemm_timeline.py).  fetch_args copies a small argument struct with one batch of scalar loads and pins every dword in
+// an SGPR; pin_args does the same for pointer / scalar parameters.
+template <typename P> FF_DEV void pin1(P& p) { asm volatile("" : "+s"(p)); }
+template <typename... P> FF_DEV void pin_args(P&... p) { (pin1(p), ...); }
+template <typename T> FF_DEV T fetch_args(const T& a) {
+    static_assert(sizeof(T) % 4 == 0 && sizeof(T) <= 320, "argument struct too large to pin");
+    constexpr int N = sizeof(T) / 4;
+    unsigned w[N];
+    __builtin_memcpy(w, &a, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < N; i++) pin1(w[i]);
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+}
+
 // ---- activations (flamingo_mini/utils.py:26-30) ------------------------------------------
 FF_DEV float act_fwd(float h, int act) {
     if (act == FF_ACT_GELU) return 0.5f * h * (1.f + erff(h * 0.70710678118654752440f));

@@ -31,6 +31,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void shifted_ce_fwd_kernel(int L, int V, const T* __restrict__ logits, const long long* __restrict__ labels,
                                                              long long ignore_index, float* __restrict__ loss_row, float* __restrict__ lse) {
     __shared__ float sm[4], ss[4];
+    pin_args(L, V, logits, labels, ignore_index, loss_row, lse);
     const int r = blockIdx.x, b = r / (L - 1), i = r - b * (L - 1);
     const T* row = logits + ((long long)b * L + i) * V;
     float m = -INFINITY, s = 0.f;
@@ -64,6 +65,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void shifted_ce_bwd_kernel(int L, int V, const T* __restrict__ logits, const long long* __restrict__ labels,
                                                              long long ignore_index, const float* __restrict__ lse, const float* __restrict__ g,
                                                              T* __restrict__ dlogits) {
+    pin_args(L, V, logits, labels, ignore_index, lse, g, dlogits);
     const int b = blockIdx.x / L, i = blockIdx.x - b * L;
     const long long off = ((long long)b * L + i) * V;
     constexpr int N = Vec<T>::N;

@@ -21,9 +21,11 @@ template <typename T, int VEC> FF_DEV void st(T* p, const float (&o)[VEC]) {
 // gated_cross_attention.py:74; utils.py:46).  Two-pass statistics in fp32 like torch.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a, const T* __restrict__ x, const T* __restrict__ add,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a_in, const T* __restrict__ x, const T* __restrict__ add,
                                                      const T* __restrict__ gamma, const T* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd) {
+    const LnArgs a = fetch_args(a_in);
+    pin_args(x, add, gamma, beta, y, mean, rstd);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
@@ -93,10 +95,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a, const T* __
 // dyh = dy * gamma.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnArgs a, const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnArgs a_in, const T* __restrict__ dy, const T* __restrict__ x,
                                                         const T* __restrict__ add, const T* __restrict__ gamma,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd, T* dx,
                                                         const T* dx_res) {
+    const LnArgs a = fetch_args(a_in);
+    pin_args(dy, x, add, gamma, mean, rstd, dx, dx_res);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
@@ -160,11 +164,13 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnArgs a, const T*
 // A wave owns rows (statistics are lane-local + wave reductions), lanes own column chunks across the wave's rows.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int VEC, int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a, const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ add, const T* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, T* dx,
                                                            const T* dx_res, const T* __restrict__ dot_a, const T* __restrict__ dot_b,
                                                            float* __restrict__ partial, int rows_per_block) {
+    const LnArgs a = fetch_args(a_in);
+    pin_args(dy, x, add, gamma, mean, rstd, dx, dx_res, dot_a, dot_b, partial, rows_per_block);
     extern __shared__ float sacc[];   // [2][cols]
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a, const
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_final_kernel(int nblk, int cols, const float* __restrict__ partial, T* dgamma, T* dbeta,
                                                            const T* alpha_a, T* out_a, const T* alpha_b, T* out_b) {
+    pin_args(nblk, cols, partial, dgamma, dbeta, alpha_a, out_a, alpha_b, out_b);
     __shared__ float red[4][64];
     const int P = 2 * cols + 2;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -326,9 +333,11 @@ struct ColReduceArgs {
 };
 
 template <typename T, int VEC, int MODE>
-__global__ __launch_bounds__(256) void col_reduce_kernel(const ColReduceArgs a, const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void col_reduce_kernel(const ColReduceArgs a_in, const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ add, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* __restrict__ partial) {
+    const ColReduceArgs a = fetch_args(a_in);
+    pin_args(x, dy, add, mean, rstd, partial);
     constexpr int NS = MODE == 1 ? 2 : 1;
     __shared__ float red[4][NS][64 * VEC];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -389,6 +398,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColReduceArgs a, 
 template <typename T>
 __global__ __launch_bounds__(256) void col_reduce_final_kernel(int nsplit, int ngroups, int nslots, int cols,
                                                                const float* __restrict__ partial, T* out0, T* out1) {
+    pin_args(nsplit, ngroups, nslots, cols, partial, out0, out1);
     const long long total = (long long)ngroups * nslots * cols;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;     // independent chains: keep 4+ loads in flight per thread
@@ -415,6 +425,7 @@ __global__ __launch_bounds__(256) void col_reduce_final_kernel(int nsplit, int n
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void dot_partial_kernel(long long n, const T* __restrict__ a, const T* __restrict__ b,
                                                           float* __restrict__ partial) {
+    pin_args(n, a, b, partial);
     __shared__ float red[4];
     float s = 0.f;
     const long long nchunk = n / VEC;
@@ -430,6 +441,7 @@ __global__ __launch_bounds__(256) void dot_partial_kernel(long long n, const T* 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void gate_grad_final_kernel(int nblk, const float* __restrict__ partial, const T* alpha, T* dalpha) {
+    pin_args(nblk, partial, alpha, dalpha);
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];

@@ -115,6 +115,8 @@ _SIGNATURES = {
     "ff_xattn_scratch_bytes": (_SZ, [C.POINTER(XattnDesc)]),
     "ff_xattn_kv_offset": (_SZ, [C.POINTER(XattnDesc)]),
     "ff_xattn_block_fwd": (_I, [C.POINTER(XattnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
+    "ff_quick_gelu_fwd": (_I, [_I, C.c_longlong, _P, _P, _P]),
+    "ff_quick_gelu_bwd": (_I, [_I, C.c_longlong, _P, _P, _P, _P]),
     "ff_shifted_ce_fwd": (_I, [_I, _I, _I, _I, _P, _P, C.c_longlong, _P, _P, _P]),
     "ff_shifted_ce_bwd": (_I, [_I, _I, _I, _I, _P, _P, C.c_longlong, _P, _P, _P, _P]),
     "ff_adamw_step": (_I, [C.POINTER(AdamWDesc), _P, _P, _P, _P, _P, _P]),

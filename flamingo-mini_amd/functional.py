@@ -217,6 +217,35 @@ def xattn_block(y: torch.Tensor, visual_features: Optional[torch.Tensor], tt: to
 
 
 # ----------------------------------------------------------------------------------------------------
+# QuickGELU of the CLIP tower
+# ----------------------------------------------------------------------------------------------------
+class _QuickGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ffi.check(ffi.lib().ff_quick_gelu_fwd(ffi.dtype_code(x.dtype), x.numel(), x.data_ptr(), y.data_ptr(), ffi.stream_handle(x.device)),
+                  "ff_quick_gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        ffi.check(ffi.lib().ff_quick_gelu_bwd(ffi.dtype_code(x.dtype), x.numel(), x.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                                              ffi.stream_handle(x.device)), "ff_quick_gelu_bwd")
+        return dx
+
+
+def quick_gelu(x: torch.Tensor) -> torch.Tensor:
+    """x * sigmoid(1.702 x) in one pass (float32 / bfloat16 on the GPU)."""
+    ffi.require_cuda(x)
+    return _QuickGeluFn.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------------
 # shifted cross-entropy (modeling_flamingo.py:288-298)
 # ----------------------------------------------------------------------------------------------------
 class _ShiftedCEFn(torch.autograd.Function):

@@ -12,6 +12,7 @@
  *   ff_xattn_block_fwd/bwd   GatedCrossAttentionBlock.forward + autograd  flamingo_mini/gated_cross_attention.py:160-184
  *                            (MaskedCrossAttention.forward :42-131, cached K/V path :88-92,102-104)
  *   ff_text_time             media_locations.cumsum(dim=-1)               flamingo_mini/gated_cross_attention.py:97
+ *   ff_quick_gelu_fwd/bwd    CLIP MLP activation (QuickGELU)               transformers CLIPMLP via modeling_flamingo.py:70-78
  *   ff_shifted_ce_fwd/bwd    shifted F.cross_entropy on the logits        flamingo_mini/modeling_flamingo.py:288-298
  *   ff_adamw_step            torch AdamW over parameters_trainable()      training/train.sh:10-13, modeling_flamingo.py:132-138
  * The primitive entry points (ff_gemm, ff_layernorm_*, ff_attention_*, ff_rows_reduce, ff_gate_grad) are the
@@ -253,6 +254,13 @@ int ff_shifted_ce_fwd(int dtype, int batch, int seq, int vocab, const void* logi
                       float* loss_row, float* lse, ff_stream_t stream);
 int ff_shifted_ce_bwd(int dtype, int batch, int seq, int vocab, const void* logits, const long long* labels, long long ignore_index,
                       const float* lse, const float* grad_row, void* dlogits, ff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * QuickGELU of the CLIP vision tower, y = x * sigmoid(1.702 x) (transformers.activations.QuickGELUActivation, selected by
+ * the openai/clip-vit-* configs the reference loads in modeling_flamingo.py:70-78), and its derivative; n contiguous elements.
+ * ------------------------------------------------------------------------------------------------------ */
+int ff_quick_gelu_fwd(int dtype, long long n, const void* x, void* y, ff_stream_t stream);
+int ff_quick_gelu_bwd(int dtype, long long n, const void* x, const void* dy, void* dx, ff_stream_t stream);
 
 #ifdef __cplusplus
 }

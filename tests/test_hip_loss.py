@@ -26,3 +26,18 @@ def test_shifted_cross_entropy_matches_torch(dtype, reduction):
     assert rel(loss, ref.detach()) < (1e-6 if dtype == torch.float32 else 1e-5)          # fp32 math on the same (rounded) logits
     assert rel(logits.grad, ref_logits.grad) < (1e-5 if dtype == torch.float32 else 8e-3)   # gradient is stored in the logits dtype
     assert float(logits.grad[:, -1].abs().max()) == 0.0 and float(logits.grad[1, 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("n", [1, 7, 4096 * 257 + 3])
+def test_quick_gelu_matches_torch(dtype, n):
+    from flamingo_mini_amd import functional as F
+    x = dev(rnd((n,), 5, 2.0), dtype).requires_grad_(True)
+    w = dev(rnd((n,), 6), dtype)
+    y = F.quick_gelu(x)
+    (y * w).sum().backward()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    yr = xr * torch.sigmoid(1.702 * xr)
+    (yr * w.double().cpu()).sum().backward()
+    tol = 2e-6 if dtype == torch.float32 else 6e-3
+    assert rel(y, yr.detach()) < tol and rel(x.grad, xr.grad) < tol

@@ -14,12 +14,19 @@ lib = ffi.lib()
 rd = C.CDLL(ffi.LIB_PATH).ff_debug_timeline_read
 rd.argtypes = [C.c_void_p, C.c_int]
 
-CASES = [("tiny 4x8 K=64", 512, 1024, 64, 0, 0, 128, 1), ("4x8 K=1024", 512, 1024, 1024, 0, 0, 128, 1),
-         ("xa.ff1.fwd", 1024, 5120, 1280, 0, 0, 128, 1), ("xa.ff2.wgrad", 1280, 5120, 1024, 1, 1, 128, 1),
-         ("xa.ff2.fwd split4", 1024, 1280, 5120, 0, 0, 128, 4), ("xa.q.fwd 64", 1024, 512, 1280, 0, 0, 64, 1),
-         ("16x48 K=64", 2048, 6144, 64, 0, 0, 128, 1)]
-for name, M, N, K, al, bl, tile, split in CASES:
-    lib.ff_gemm_set_tuning(tile, 2)
+CASES = [("tiny 4x8 K=64", 512, 1024, 64, 0, 0, 128, 1, 2), ("4x8 K=1024", 512, 1024, 1024, 0, 0, 128, 1, 2),
+         ("xa.ff1.fwd", 1024, 5120, 1280, 0, 0, 128, 1, 2), ("xa.ff1.fwd ns3", 1024, 5120, 1280, 0, 0, 128, 1, 3),
+         ("xa.ff1.fwd 6412", 1024, 5120, 1280, 0, 0, 6412, 1, 2), ("xa.ff1.fwd 6412 ns3", 1024, 5120, 1280, 0, 0, 6412, 1, 3),
+         ("xa.ff1.fwd 6412 ns4", 1024, 5120, 1280, 0, 0, 6412, 1, 4),
+         ("xa.ff2.wgrad", 1280, 5120, 1024, 1, 1, 128, 1, 2), ("xa.ff2.wgrad ns3", 1280, 5120, 1024, 1, 1, 128, 1, 3),
+         ("xa.ff2.fwd split5", 1024, 1280, 5120, 0, 0, 128, 5, 2), ("xa.ff2.fwd split5 ns3", 1024, 1280, 5120, 0, 0, 128, 5, 3),
+         ("xa.q.fwd 64 s2", 1024, 512, 1280, 0, 0, 64, 2, 2), ("xa.q.fwd 64 s2 ns3", 1024, 512, 1280, 0, 0, 64, 2, 3),
+         ("xa.q.fwd 64 s2 ns4", 1024, 512, 1280, 0, 0, 64, 2, 4), ("xa.q.fwd 64 s1 ns4", 1024, 512, 1280, 0, 0, 64, 1, 4),
+         ("xa.kv.fwd 64", 2048, 1024, 1024, 0, 0, 64, 1, 2), ("xa.kv.fwd 64 ns4", 2048, 1024, 1024, 0, 0, 64, 1, 4),
+         ("xa.kv.fwd 128 ns3", 2048, 1024, 1024, 0, 0, 128, 1, 3),
+         ("xa.q.wgrad 64 s2", 512, 1280, 1024, 1, 1, 64, 2, 2), ("xa.q.wgrad 64 s2 ns4", 512, 1280, 1024, 1, 1, 64, 2, 4)]
+for name, M, N, K, al, bl, tile, split, stages in CASES:
+    lib.ff_gemm_set_tuning(tile, stages)
     A = torch.randn((M, K) if al == 0 else (K, M), device="cuda", dtype=torch.bfloat16)
     B = torch.randn((N, K) if bl == 0 else (K, N), device="cuda", dtype=torch.bfloat16)
     run = lambda: F.gemm(A, B, a_layout=al, b_layout=bl, split_k=split)

@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph (auto = on for 1 GPU; the all-reduce of N > 1 is not captured)")
     ap.add_argument("--profile-steps", type=int, default=3, help="instrumented eager steps after the timed region (roofline objects)")
+    ap.add_argument("--stock-tuning", default="on", choices=["on", "off"],
+                    help="load the pre-tuned hipBLASLt solution file for the stock CLIP / GPT-2 GEMMs (PyTorch TunableOp, tuning off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
@@ -177,6 +179,10 @@ def main():
     from flamingo_mini_amd.data_parallel import GradientAllReducer
     lib = ffi.lib()                                            # aborts loudly if the HIP library is missing
 
+    stock_tuned = False
+    if args.stock_tuning == "on" and args.dtype == "bf16":
+        from flamingo_mini_amd.backbones import load_stock_gemm_tuning
+        stock_tuned = load_stock_gemm_tuning()
     model, cfg = build_model(args, device, dtype)
     batch = synthetic_batch(args, cfg, device, dtype, rank)
     params = [p for p in model.parameters_trainable()]
@@ -286,7 +292,7 @@ def main():
                                    + ("" if args.no_optimizer else f" + AdamW ({args.optimizer})")
                                    + ("; step replayed from a captured HIP graph" if use_graph else "; eager launches") + "; random-init weights, gates alpha=0.5",
                        "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
-                       "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph},
+                       "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph, "stock_gemm_tuning_file": stock_tuned},
             "roofline": roofline,
         }
         if attn:    # north star: throughput of the softmax(QK^T)V core as a fraction of the HBM roofline (8 TB/s spec peak)

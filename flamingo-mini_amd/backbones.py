@@ -74,6 +74,25 @@ def _tune_gpt2(model):
     return model
 
 
+def load_stock_gemm_tuning(path: str = None) -> bool:
+    """Point PyTorch's TunableOp at a pre-tuned hipBLASLt / rocBLAS solution file for the GEMM shapes of the *stock* backbones
+    (tools/tune_stock_gemms.py writes it; tuning itself stays off, so nothing is measured or written at run time).  hipBLASLt's
+    default heuristic picks e.g. a 52 us kernel for GPT-2-large's 1024x1280x5120 MLP projection where a 37 us one exists.
+    Returns False (and changes nothing) when the file is missing or was made for another PyTorch / ROCm / GPU."""
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950_configB.csv")
+    if not (torch.cuda.is_available() and os.path.exists(path)):
+        return False
+    tun = torch.cuda.tunable
+    tun.enable(True)
+    tun.tuning_enable(False)
+    ok = bool(tun.read_file(path))
+    if not ok:
+        tun.enable(False)
+    return ok
+
+
 def want_random_init(config) -> bool:
     return bool(getattr(config, "random_init_backbones", False)) or os.environ.get("FLAMINGO_RANDOM_INIT_BACKBONES", "0") == "1"
 

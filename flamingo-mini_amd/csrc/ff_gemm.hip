@@ -666,7 +666,9 @@ static int forced_tile() {
 // Block tile and split-K factor for a bf16 problem.  Measured on MI355X (tools/gemm_bench.py --sweep): a k-step's cost
 // is the L2 -> LDS traffic of its operand tiles, so 128x128 (64 FLOP/B) beats 64x64 (32 FLOP/B) whenever it can put
 // >= ~200 workgroups on the chip; long-K problems with few output tiles get there through split-K (fp32 partial slabs
-// + a reduce/epilogue kernel), short-K ones use 64x64 tiles.
+// + a reduce/epilogue kernel), short-K ones use 64x64 tiles.  Re-checked in-model after the fixed-cost work (same box, graph replay,
+// 43.74 ms/step): no split for the small 64-tile GEMMs +0.5 ms, one-workgroup-per-CU split counts +0.7 ms, no 64x128 rule +0.5 ms -
+// in-model the operands arrive cold from HBM and more workgroups in flight hide that better than isolated timings suggest.
 struct TilePlan { int tile, split; };
 static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_layout = 0) {
     const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;

@@ -155,10 +155,10 @@ FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const
     const float gate = pr.gate ? tanhf(to_f32(*(const bf16*)pr.gate)) : 1.f;
     auto rows = [&](auto feat) {   // branch-free row loop for one feature combination, 4 rows in flight
         constexpr int F = decltype(feat)::value;
+        const int nrows = min(BM, P.M - m_base);          // loop bound instead of a break: lets the 4 rows' LDS reads go out together
 #pragma unroll 4
-        for (int r = tr; r < BM; r += RPP) {
+        for (int r = tr; r < nrows; r += RPP) {
             const int m = m_base + r;
-            if (m >= P.M) break;
             const int ch = col >> 2, sw = r & 15;
             const f32x4 lo = *(const f32x4*)(ct + r * BN + ((ch ^ sw) << 2)), hi = *(const f32x4*)(ct + r * BN + (((ch + 1) ^ sw) << 2));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};

@@ -188,6 +188,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
         const T* ar = add ? add + (long long)((row % a.add_rows_per_seg) / a.add_div) * a.cols : nullptr;
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
+        constexpr bool KEEP = NCH <= 4;                 // x-hat and dy of the row stay in registers between the two passes
+        float xk[KEEP ? NCH : 1][VEC], dk[KEEP ? NCH : 1][VEC];
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
             const int c = lane + 64 * i;
@@ -204,9 +206,10 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
                 ld<T, VEC>(gamma + c * VEC, g);
 #pragma unroll
                 for (int e = 0; e < VEC; e++) {
-                    const float dyh = d[e] * g[e];
+                    const float dyh = d[e] * g[e], xh = (v[e] - mu) * rs;
                     s1 += dyh;
-                    s2 += dyh * (v[e] - mu) * rs;
+                    s2 += dyh * xh;
+                    if (KEEP) { xk[i][e] = xh; dk[i][e] = d[e]; }
                 }
             }
         }
@@ -216,21 +219,28 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
         for (int i = 0; i < NCH; i++) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
-                float v[VEC], d[VEC], g[VEC], o[VEC];
-                ld<T, VEC>(xr + c * VEC, v);
-                if (ar) {
-                    float t[VEC];
-                    ld<T, VEC>(ar + c * VEC, t);
+                float xh[VEC], d[VEC], g[VEC], o[VEC];
+                if (KEEP) {
 #pragma unroll
-                    for (int e = 0; e < VEC; e++) v[e] += t[e];
+                    for (int e = 0; e < VEC; e++) { xh[e] = xk[i][e]; d[e] = dk[i][e]; }
+                } else {
+                    float v[VEC];
+                    ld<T, VEC>(xr + c * VEC, v);
+                    if (ar) {
+                        float t[VEC];
+                        ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+                        for (int e = 0; e < VEC; e++) v[e] += t[e];
+                    }
+                    ld<T, VEC>(dyr + c * VEC, d);
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) xh[e] = (v[e] - mu) * rs;
                 }
-                ld<T, VEC>(dyr + c * VEC, d);
                 ld<T, VEC>(gamma + c * VEC, g);
 #pragma unroll
                 for (int e = 0; e < VEC; e++) {
-                    const float xh = (v[e] - mu) * rs;
-                    o[e] = rs * (d[e] * g[e] - m1 - xh * m2);
-                    accg[i][e] += d[e] * xh;
+                    o[e] = rs * (d[e] * g[e] - m1 - xh[e] * m2);
+                    accg[i][e] += d[e] * xh[e];
                     accb[i][e] += d[e];
                 }
                 if (dx_res) {
@@ -286,30 +296,32 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
     if (threadIdx.x == 0) { out[2 * a.cols] = da; out[2 * a.cols + 1] = db; }
 }
 
-// out[idx] = sum over blocks of partial[block][idx]; 64 outputs x 4 block-lanes per workgroup
+// out[idx] = sum over blocks of partial[block][idx]; 16 outputs x 16 block-lanes per workgroup, 8 loads in flight per thread
+// (the first version - 64 x 4, 4 in flight - spent 7 us on 16 dependent round trips to read 2.6 MB)
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_final_kernel(int nblk, int cols, const float* __restrict__ partial, T* dgamma, T* dbeta,
                                                            const T* alpha_a, T* out_a, const T* alpha_b, T* out_b) {
     pin_args(nblk, cols, partial, dgamma, dbeta, alpha_a, out_a, alpha_b, out_b);
-    __shared__ float red[4][64];
+    __shared__ float red[16][17];
     const int P = 2 * cols + 2;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + tx;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + tx;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (idx < P) {
         int b = ty;
-        for (; b + 12 < nblk; b += 16) {
-            v0 += partial[(long long)b * P + idx];
-            v1 += partial[(long long)(b + 4) * P + idx];
-            v2 += partial[(long long)(b + 8) * P + idx];
-            v3 += partial[(long long)(b + 12) * P + idx];
+        for (; b + 7 * 16 < nblk; b += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] += partial[(long long)(b + 16 * u) * P + idx];
         }
-        for (; b < nblk; b += 4) v0 += partial[(long long)b * P + idx];
+        for (; b < nblk; b += 16) v[0] += partial[(long long)b * P + idx];
     }
-    red[ty][tx] = (v0 + v1) + (v2 + v3);
+    red[ty][tx] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     __syncthreads();
     if (ty == 0 && idx < P) {
-        const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; u++) s += red[u][tx];
+        const float v = s;
         if (idx < cols) { if (dgamma) dgamma[idx] = from_f32<T>(v); }
         else if (idx < 2 * cols) { if (dbeta) dbeta[idx - cols] = from_f32<T>(v); }
         else if (idx == 2 * cols) {
@@ -560,7 +572,7 @@ static int launch_ln_fused(const LnArgs& a, const void* dy, const void* x, const
 #undef FF_LN_LAUNCH
     FF_TRY(check_launch("ln_bwd_fused"));
     const int P = 2 * a.cols + 2;
-    ln_bwd_final_kernel<T><<<dim3(cdiv(P, 64)), dim3(256), 0, st_>>>(nblk, a.cols, partial, (T*)dgamma, (T*)dbeta, (const T*)dots.alpha_a,
+    ln_bwd_final_kernel<T><<<dim3(cdiv(P, 16)), dim3(256), 0, st_>>>(nblk, a.cols, partial, (T*)dgamma, (T*)dbeta, (const T*)dots.alpha_a,
                                                                      (T*)dots.out_a, (const T*)dots.alpha_b, (T*)dots.out_b);
     return check_launch("ln_bwd_final");
 }

@@ -10,8 +10,9 @@ def category(name):
     if "attn_fwd_kernel" in name or "attn_bwd" in name: return "fusion: attention core (fwd, dQ, dK/dV)"
     if "adamw_kernel" in name: return "fusion: multi-tensor AdamW (ff_adamw_step)"
     if "shifted_ce" in name: return "fusion: shifted cross-entropy (fwd + bwd)"
+    if "quick_gelu" in name: return "fusion: QuickGELU of the CLIP MLPs"
     if "ff::" in name or "_ZN2ff" in name: return "fusion: LayerNorm / reductions / gates"
-    if name.startswith("Cijk_"): return "stock: hipBLASLt GEMMs (CLIP, GPT-2, lm_head)"
+    if "Cijk_" in name: return "stock: hipBLASLt GEMMs (CLIP, GPT-2, lm_head)"
     if "multi_tensor_apply" in name: return "stock: fused AdamW"
     if name in ("attn_fwd", "bwd_kernel_fuse", "bwd_kernel_dk_dv", "bwd_kernel_dq") or "attn" in name.lower(): return "stock: SDPA attention (CLIP, GPT-2)"
     if "elementwise" in name or "reduce_kernel" in name or "layer_norm" in name or "softmax" in name.lower() or "index" in name or "nll" in name: return "stock: elementwise / norm / loss"

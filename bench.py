@@ -12,9 +12,14 @@ Synthetic data (N(0,1) pixels, uniform token ids, media tag at position 0), rand
 architectures (no network), gates alpha = 0.5 (zero gates would make the fusion path an identity with zero gradients).
 The resampler / xattn blocks run in libflamingo_fusion (hand-written HIP); the run aborts if that library is missing.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live: every GEMM launch of the fusion library inside the timed
-steps is bracketed by HIP events on its stream (ff_gemm_profile_*); the dominant kernel variant is reported against the
-dense bf16 MFMA peak.  `cpu_baseline` times the numpy oracle of the same hot path on this box's host cores.
+At N = 1 the step (forward + backward + optimizer) is captured once into a HIP graph and the timed region replays it
+(`--graph off`: eager launches, as at N > 1 where the RCCL all-reduce is not captured).  The stock CLIP / GPT-2 GEMMs use
+the pre-tuned hipBLASLt solutions in flamingo-mini_amd/tuning/ (`--stock-tuning off` for hipBLASLt's default heuristic).
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live: right after the timed region `--profile-steps` eager steps of
+the same workload run with every GEMM / attention launch of the fusion library bracketed by HIP events on its stream
+(ff_gemm_profile_*; events cannot be recorded inside a replayed graph); the dominant GEMM variant is reported against
+the dense bf16 MFMA peak.  `cpu_baseline` times the numpy oracle of the same hot path on this box's host cores.
 """
 from __future__ import annotations
 

@@ -670,7 +670,7 @@ static int forced_tile() {
 // 43.74 ms/step): no split for the small 64-tile GEMMs +0.5 ms, one-workgroup-per-CU split counts +0.7 ms, no 64x128 rule +0.5 ms -
 // in-model the operands arrive cold from HBM and more workgroups in flight hide that better than isolated timings suggest.
 struct TilePlan { int tile, split; };
-static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_layout = 0) {
+static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_layout = 0, int b_layout = 0) {
     const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;
     TilePlan p;
     const int ft = forced_tile();
@@ -754,7 +754,7 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
              P.M, P.N, P.K, P.nz);
     P.tile = kFBM;
     if (dtype == FF_DTYPE_BF16) {
-        const TilePlan plan = plan_bf16(P.M, P.N, P.K, P.nz, P.split_k, P.a_layout);
+        const TilePlan plan = plan_bf16(P.M, P.N, P.K, P.nz, P.split_k, P.a_layout, P.b_layout);
         P.tile = plan.tile;
         P.split_k = plan.split;
     } else if (P.split_k <= 0) P.split_k = gemm_pick_split(dtype, P.M, P.N, P.K, P.nz);

@@ -151,6 +151,7 @@ class _XattnBlockFn(torch.autograd.Function):
         ctx.cfg, ctx.n_visual = cfg, n_visual
         ctx.save_for_backward(y, vf, tt, saved, *params)
         ctx.mark_non_differentiable(saved)
+        ctx.set_materialize_grads(False)     # no zero-filled "gradient" of the saved-activation buffer (a multi-MB uint8 fill per block)
         return out, saved
 
     @staticmethod
@@ -159,7 +160,7 @@ class _XattnBlockFn(torch.autograd.Function):
         y, vf, tt, saved, *params = ctx.saved_tensors
         desc = _xattn_desc(y, vf.shape[1], ctx.n_visual, vf.shape[3], ctx.cfg, tt)
         dev = y.device
-        dout = dout.contiguous()
+        dout = torch.zeros_like(y) if dout is None else dout.contiguous()
         flat, grads = _flat_grads(params)
         dy = torch.empty_like(y)
         dvf = torch.empty_like(vf) if ctx.needs_input_grad[1] else None

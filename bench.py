@@ -242,6 +242,8 @@ def main():
     max_rec = 4096 * max(prof_steps, 1)
     eager_ms = None
     if prof_steps:
+        if use_graph:
+            loss = eager_step()         # the eager allocator pool is cold after the graph's private pool: one untimed step
         if rank == 0:
             lib.ff_gemm_profile_enable(max_rec)
         torch.cuda.synchronize()

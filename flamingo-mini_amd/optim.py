@@ -29,34 +29,59 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = ffi.lib()
-        for group in self.param_groups:
-            buckets = {}
+        for gi, group in enumerate(self.param_groups):
             capturable = group.get("capturable", False)
             if capturable:
                 self._advance_device_steps(group)
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                ffi.require_cuda(p, p.grad)
-                if p.grad.dtype != p.dtype or not p.is_contiguous():
-                    raise ffi.FusionLibraryError("FusedAdamW needs contiguous parameters with gradients of the same dtype")
-                st = self.state[p]
-                if not st:
-                    st["step"] = torch.zeros((), dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not capturable:
-                    st["step"] += 1
-                buckets.setdefault((p.dtype, p.device, 0 if capturable else int(st["step"])), []).append((p, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"]))
-            for (dtype, device, step), items in buckets.items():
-                n = len(items)
-                desc = ffi.AdamWDesc(ffi.dtype_code(dtype), n, step, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
-                                     group["weight_decay"], group["grad_scale"],
-                                     group["_step_dev"][device].data_ptr() if capturable else None)
-                cols = [ffi.ptr_array([it[k] for it in items]) for k in range(4)]
-                numels = (C.c_longlong * n)(*[it[0].numel() for it in items])
-                ffi.check(lib.ff_adamw_step(desc, cols[0], cols[1], cols[2], cols[3], numels, ffi.stream_handle(device)), "ff_adamw_step")
+            for bucket in self._buckets(gi, group):
+                params, grad_ptrs, n = bucket["params"], bucket["grad_ptrs"], len(bucket["params"])
+                for i, p in enumerate(params):           # only the gradient addresses change from step to step
+                    g = p.grad
+                    if g.dtype != p.dtype or not g.is_contiguous():
+                        raise ffi.FusionLibraryError("FusedAdamW needs contiguous gradients of the parameter's dtype")
+                    grad_ptrs[i] = g.data_ptr()
+                if capturable:
+                    step, step_dev = 0, group["_step_dev"][bucket["device"]].data_ptr()
+                else:
+                    bucket["step"] += 1                   # the per-parameter `step` entries are refreshed lazily (_sync_host_steps)
+                    step, step_dev = bucket["step"], None
+                desc = ffi.AdamWDesc(bucket["dtype_code"], n, step, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
+                                     group["weight_decay"], group["grad_scale"], step_dev)
+                ffi.check(lib.ff_adamw_step(desc, bucket["param_ptrs"], grad_ptrs, bucket["m_ptrs"], bucket["v_ptrs"], bucket["numels"],
+                                            ffi.stream_handle(bucket["device"])), "ff_adamw_step")
         return loss
+
+    def _buckets(self, gi, group):
+        """Parameters with a gradient, grouped by (dtype, device, step count); the pointer tables of everything that does not
+        change between steps (parameters, moments, sizes) are built once and reused while the same parameters have gradients."""
+        active = [p for p in group["params"] if p.grad is not None]
+        cache = self.__dict__.setdefault("_bucket_cache", {})
+        key = tuple(id(p) for p in active)
+        hit = cache.get(gi)
+        if hit is not None and hit[0] == key and all(b["param_ptrs"][0] == b["params"][0].data_ptr() for b in hit[1]):
+            return hit[1]
+        self._sync_host_steps()
+        table = {}
+        for p in active:
+            ffi.require_cuda(p, p.grad)
+            if not p.is_contiguous():
+                raise ffi.FusionLibraryError("FusedAdamW needs contiguous parameters")
+            st = self.state[p]
+            if not st:
+                st["step"] = torch.zeros((), dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            table.setdefault((p.dtype, p.device, int(st["step"])), []).append(p)
+        buckets = []
+        for (dtype, device, step), params in table.items():
+            n = len(params)
+            buckets.append(dict(params=params, device=device, dtype_code=ffi.dtype_code(dtype), step=step,
+                                param_ptrs=ffi.ptr_array(params), grad_ptrs=(C.c_void_p * n)(),
+                                m_ptrs=ffi.ptr_array([self.state[p]["exp_avg"] for p in params]),
+                                v_ptrs=ffi.ptr_array([self.state[p]["exp_avg_sq"] for p in params]),
+                                numels=(C.c_longlong * n)(*[p.numel() for p in params])))
+        cache[gi] = (key, buckets)
+        return buckets
 
     # ------------------------------------------------------------------ capturable mode
     def _advance_device_steps(self, group):
@@ -69,7 +94,22 @@ class FusedAdamW(torch.optim.Optimizer):
         for counter in counters.values():
             counter += 1
 
+    def _sync_host_steps(self):
+        """Write the step counts kept per bucket (host mode) back into the per-parameter state entries."""
+        for gi, group in enumerate(self.param_groups):
+            if group.get("capturable", False):
+                continue
+            hit = self.__dict__.get("_bucket_cache", {}).get(gi)
+            for bucket in (hit[1] if hit else ()):
+                for p in bucket["params"]:
+                    self.state[p]["step"] = torch.tensor(float(bucket["step"]), dtype=torch.float32)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__.pop("_bucket_cache", None)       # moments were replaced: rebuild the pointer tables
+
     def state_dict(self):
+        self._sync_host_steps()
         for group in self.param_groups:      # capturable: bring the host-side `step` entries up to date before serialising
             for device, counter in group.get("_step_dev", {}).items():
                 step = float(counter)

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) 
     FF_TL(0);
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
-    constexpr int PER_TILE = (AL == 0 ? BM / 32 : BM / 32) + (BL == 0 ? BN / 32 : BN / 32);   // DMA instructions per wave per k-step
+    constexpr int PER_TILE = BM / 32 + BN / 32;   // DMA instructions per wave per k-step
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
 
     FF_GEMM_ARGS(Q, pr, P);

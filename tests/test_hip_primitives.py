@@ -50,8 +50,9 @@ def test_gemm_every_instantiated_tile(al, bl):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("split_k", [0, 3])
-def test_gemm_epilogues(dtype, split_k):
-    M, N, K = 136, 264, 1024
+@pytest.mark.parametrize("N", [264, 132], ids=["n264", "n132-ragged"])      # 132: N % 8 == 4 -> element-wise epilogue pieces
+def test_gemm_epilogues(dtype, split_k, N):
+    M, K = 136, 1024
     A, B = dev(rnd((M, K), 3, 0.5), dtype), dev(rnd((N, K), 4, 0.05), dtype)
     R, H = dev(rnd((M, N), 5), dtype), dev(rnd((M, N), 6), dtype)
     gate = dev(np.array([0.7]), dtype)

@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion.so")
 SOURCES = ["ff_api.hip", "ff_gemm.hip", "ff_rowwise.hip", "ff_attention.hip", "ff_optim.hip", "ff_loss.hip", "ff_elementwise.hip"]
 HEADERS = ["ff_common.h", "ff_internal.h", os.path.join("..", "..", "include", "flamingo_fusion.h")]
 ARCH = "gfx950"
-FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("FF_EXTRA_FLAGS", "").split()
+# kernarg preload: leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+); kernels fall back to loads on old firmware
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + os.environ.get("FF_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -155,8 +155,9 @@ FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const
     const float gate = pr.gate ? tanhf(to_f32(*(const bf16*)pr.gate)) : 1.f;
     auto rows = [&](auto feat) {   // branch-free row loop for one feature combination, 4 rows in flight
         constexpr int F = decltype(feat)::value;
-        const int nrows = min(BM, P.M - m_base);          // loop bound instead of a break: lets the 4 rows' LDS reads go out together
-#pragma unroll 4
+        constexpr int UNROLL = (F < 0 || (F & (kEpiAct | kEpiActBwd))) ? 2 : 4;   // the erf-based activations are ~40 instructions per element
+        const int nrows = min(BM, P.M - m_base);          // loop bound instead of a break: lets the rows' LDS reads go out together
+#pragma unroll UNROLL
         for (int r = tr; r < nrows; r += RPP) {
             const int m = m_base + r;
             const int ch = col >> 2, sw = r & 15;
@@ -346,8 +347,14 @@ __device__ unsigned long long g_timeline[16384 * 8];
 
 template <int N> FF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// The leading scalar arguments are the ones the path to the first operand load needs; they are declared as plain kernel
+// parameters (not inside the by-value struct) so the hardware can preload them into SGPRs at wave launch
+// (-mllvm -amdgpu-kernarg-preload-count, see build.py) instead of a ~0.7 us scalar-load round trip.  Everything else is fetched in
+// one batch *after* the first operand tiles are in flight.   h_xcd = xcd_ms | xcd_ns << 8;  h_seg != 0: an operand row map is
+// segmented (rare: the full maps are then read from P up front).
 template <int BM, int BN, int AL, int BL, int NS>
-__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) {
+__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
+                                                            int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;
     FF_TL(0);
@@ -356,18 +363,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) 
     constexpr int PER_TILE = BM / 32 + BN / 32;   // DMA instructions per wave per k-step
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
 
-    FF_GEMM_ARGS(Q, pr, P);
-    const int tiles_m = (Q.M + BM - 1) / BM, tiles_n = (Q.N + BN - 1) / BN;
-    const TileCoord tc = tile_coord(Q.nz, Q.split_k, Q.xcd_ms, Q.xcd_ns, tiles_m, tiles_n);
-    if (tc.z > 0) pr = P.p[tc.z];   // grouped launches only: one more round trip
+    RowMap a_map{h_ald, 0, 0}, b_map{h_bld, 0, 0};
+    if (h_seg) { a_map = P.a_map; b_map = P.b_map; }
+    const void* opA = hA;
+    const void* opB = hB;
+    const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
+    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd & 255, h_xcd >> 8, tiles_m, tiles_n);
+    if (tc.z > 0) { opA = P.p[tc.z].A; opB = P.p[tc.z].B; }   // grouped launches only: one kernarg round trip
     const int m_base = tc.tm * BM, n_base = tc.tn * BN;
-    const int k_begin = tc.split * Q.k_per_split;
-    const int k_end = min(Q.K, k_begin + Q.k_per_split);
+    const int k_begin = tc.split * h_kps;
+    const int k_end = min(hK, k_begin + h_kps);
     const int t = threadIdx.x, l = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pr.A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)pr.B, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)opB, 0, 0x7fffffff, 0x00020000);
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -377,23 +387,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams P) 
 
     const int nk = (k_end - k_begin + kBK - 1) / kBK;
     unsigned va[BM / 32], vb[BN / 32];
-    dma_prepare<BM, AL>(Q.a_map, m_base, Q.M, w, l, va);
-    dma_prepare<BN, BL>(Q.b_map, n_base, Q.N, w, l, vb);
-    const bool a_plain = AL == 0 || Q.a_map.rows_per_seg <= 0, b_plain = BL == 0 || Q.b_map.rows_per_seg <= 0;
-    const unsigned a_step = AL == 0 ? 2u : (unsigned)Q.a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)Q.b_map.ld * 2u;   // bytes per unit of k
+    dma_prepare<BM, AL>(a_map, m_base, hM, w, l, va);
+    dma_prepare<BN, BL>(b_map, n_base, hN, w, l, vb);
+    const bool a_plain = AL == 0 || a_map.rows_per_seg <= 0, b_plain = BL == 0 || b_map.rows_per_seg <= 0;
+    const unsigned a_step = AL == 0 ? 2u : (unsigned)a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)b_map.ld * 2u;   // bytes per unit of k
     auto issue = [&](int tile) {
         bf16* st = smem + (tile % NS) * STAGE;
         const int k0 = k_begin + tile * kBK;
         const bool full = k0 + kBK <= k_end;       // wave-uniform
         if (full && a_plain) dma_tile_fast<BM, AL>(ra, st, va, (unsigned)k0 * a_step, w);
-        else dma_tile<BM, AL>(ra, st, Q.a_map, m_base, Q.M, k0, k_end, w, l);
+        else dma_tile<BM, AL>(ra, st, a_map, m_base, hM, k0, k_end, w, l);
         if (full && b_plain) dma_tile_fast<BN, BL>(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, w);
-        else dma_tile<BN, BL>(rb, st + A_ELEMS, Q.b_map, n_base, Q.N, k0, k_end, w, l);
+        else dma_tile<BN, BL>(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, w, l);
     };
     FF_TL(1);
 #pragma unroll
     for (int s = 0; s < NS - 1; s++)
         if (s < nk) issue(s);
+    FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
+    if (tc.z > 0) pr = P.p[tc.z];
 
     for (int kt = 0; kt < nk; kt++) {
         // tile kt must have landed; the up to NS-2 younger tiles may stay in flight across the barrier
@@ -712,7 +724,9 @@ template <int BM, int BN, int AL, int BL, int NS> static int launch_bf16_dma(con
         attr_done = true;
     }
     const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
-    gemm_bf16_dma_kernel<BM, BN, AL, BL, NS><<<dim3(grid), dim3(256), lds, st>>>(P);
+    const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
+    gemm_bf16_dma_kernel<BM, BN, AL, BL, NS><<<dim3(grid), dim3(256), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split, P.nz,
+                                                                           P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld, (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_dma");
 }
 template <int BM, int BN, int NS> static int dispatch_bf16_dma(const GemmParams& P, hipStream_t st) {

@@ -90,7 +90,11 @@ def load_stock_gemm_tuning(path: str = None) -> bool:
     ok = bool(tun.read_file(path))
     if not ok:
         tun.enable(False)
-    return ok
+        return False
+    import tempfile
+    # TunableOp dumps its table to `get_filename()` at interpreter exit: keep that out of the working directory
+    tun.set_filename(os.path.join(tempfile.gettempdir(), f"ff_tunableop_{os.getpid()}.csv"))
+    return True
 
 
 def want_random_init(config) -> bool:

@@ -63,3 +63,25 @@ def test_media_locations_from_known_ids():
     ids = torch.tensor([[50256, 27, 9060, 29, 257, 1279, 27], [1, 2, 3, 4, 5, 6, 7]])
     ml = FlamingoProcessor.media_locations_from_ids(ids, KNOWN_LEQ_IDS["gpt2"])
     assert ml.tolist() == [[0, 1, 0, 0, 0, 1, 1], [0] * 7] and ml.dtype == ids.dtype
+
+
+def test_gemm_plan_for_the_benchmark_shapes():
+    """ff_gemm_plan (host only) pins the measured tile / split-K plan of DESIGN.md section 4 for config B's GEMM shapes."""
+    import ctypes as C
+    from flamingo_mini_amd import ffi
+    lib = ffi.lib()
+
+    def plan(M, N, K, al=0, bl=0):
+        d = ffi.GemmDesc(ffi.DTYPE_BF16, M, N, K, al, bl, ffi.rowmap(K if al == 0 else M), ffi.rowmap(K if bl == 0 else N), ffi.rowmap(N),
+                         1.0, ffi.ACT_NONE, ffi.ACT_NONE, 0)
+        bm, bn, sk = C.c_int(), C.c_int(), C.c_int()
+        assert lib.ff_gemm_plan(d, bm, bn, sk) == 0
+        return bm.value, bn.value, sk.value
+
+    assert plan(1024, 5120, 1280) == (64, 128, 1)            # FFW up-projection: 320 tiles of 128^2 -> 64x128 tiles, 2-3 workgroups per CU
+    assert plan(1280, 5120, 1024, 1, 1) == (128, 128, 1)     # its weight gradient (transposed A): 400 tiles of 128^2
+    assert plan(1024, 1280, 5120) == (128, 128, 5)           # FFW down-projection: 80 output tiles, long K -> split-K
+    assert plan(1024, 512, 1280) == (64, 64, 2)              # q projection: small, 64^2 tiles + 2 splits
+    assert plan(4096, 4096, 4096) == (128, 128, 1)
+    bm, bn, sk = plan(512, 1024, 10272, 1, 1)                # resampler dWk/dWv: 32 tiles, K = 10272
+    assert (bm, bn) == (128, 128) and sk >= 4

@@ -60,7 +60,7 @@ def parse():
                     help="load the pre-tuned hipBLASLt solution file for the stock CLIP / GPT-2 GEMMs (PyTorch TunableOp, tuning off)")
     ap.add_argument("--debug-phases", action="store_true", help="print host-side issue time of each phase of 5 eager steps and exit")
     ap.add_argument("--hoist-kv", default="env", choices=["env", "on", "off"],
-                    help="project K / V of all cross-attention layers up front in grouped launches (env = FF_HOIST_KV, default off)")
+                    help="project K / V of all cross-attention layers up front in grouped launches (env = FF_HOIST_KV, default on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")

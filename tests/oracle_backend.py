@@ -65,6 +65,33 @@ class _Xa(torch.autograd.Function):
         return (torch.from_numpy(dy).to(ydt), torch.from_numpy(dvf).to(ydt), None, None, None) + _emit_flat(g, XA_KEYS, like)
 
 
+class _KvProj(torch.autograd.Function):
+    """What ff_kv_project_fwd / _bwd compute, with the product's gradient plumbing: all d to_kv.weight in ONE flat buffer that is
+    announced to the grad-ready callbacks (the data-parallel reducer's bucket)."""
+
+    @staticmethod
+    def forward(ctx, vf, *weights):
+        rows = vf.reshape(vf.shape[0], vf.shape[1] * vf.shape[2], vf.shape[3])
+        ctx.save_for_backward(vf, *weights)
+        ctx.set_materialize_grads(False)
+        return tuple(rows @ w.t() for w in weights)
+
+    @staticmethod
+    def backward(ctx, *dkvs):
+        from flamingo_mini_amd import functional as F
+        vf, *weights = ctx.saved_tensors
+        rows = vf.reshape(-1, vf.shape[3])
+        flat, views = F._flat_grads(weights)
+        dvf = torch.zeros_like(rows)
+        for view, w, g in zip(views, weights, dkvs):
+            g2 = torch.zeros(rows.shape[0], w.shape[0], dtype=vf.dtype) if g is None else g.reshape(-1, w.shape[0])
+            view.copy_(g2.t() @ rows)
+            dvf += g2 @ w
+        for cb in F._grad_ready_callbacks:
+            cb(flat)
+        return (dvf.reshape(vf.shape), *views)
+
+
 class _XaHoisted(torch.autograd.Function):
     """_Xa with projected K / V as the "visual features" and an identity to_kv (params[5]); `real_w` only keeps the real weight
     in the graph with a None gradient, like the product's _XattnBlockKvFn."""
@@ -93,9 +120,7 @@ class OracleBackend:
         return _Rs.apply(x_f, tuple(cfg), *params)
 
     def kv_project(self, vf, weights):
-        """Plain torch (autograd does the backward): what ff_kv_project_fwd / _bwd compute."""
-        flat = vf.reshape(vf.shape[0], vf.shape[1] * vf.shape[2], vf.shape[3])
-        return tuple(flat @ w.t() for w in weights)
+        return _KvProj.apply(vf, *weights)
 
     def xattn_block(self, y, vf, tt, params, cfg, n_visual, previous_kv, output_kv, hoisted_kv=None):
         if previous_kv is None and hoisted_kv is not None:

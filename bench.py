@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--stock-tuning", default="on", choices=["on", "off"],
                     help="load the pre-tuned hipBLASLt solution file for the stock CLIP / GPT-2 GEMMs (PyTorch TunableOp, tuning off)")
     ap.add_argument("--debug-phases", action="store_true", help="print host-side issue time of each phase of 5 eager steps and exit")
+    ap.add_argument("--hoist-kv", default="env", choices=["env", "on", "off"],
+                    help="project K / V of all cross-attention layers up front in grouped launches (env = FF_HOIST_KV, default on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
@@ -191,6 +193,8 @@ def main():
         stock_tuned = load_stock_gemm_tuning()
     model, cfg = build_model(args, device, dtype)
     batch = synthetic_batch(args, cfg, device, dtype, rank)
+    if args.hoist_kv != "env":
+        model.flamingo.hoist_kv = args.hoist_kv == "on"
     params = [p for p in model.parameters_trainable()]
     n_trainable = sum(p.numel() for p in params)
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
@@ -324,7 +328,7 @@ def main():
                                    + ("" if args.no_optimizer else f" + AdamW ({args.optimizer})")
                                    + ("; step replayed from a captured HIP graph" if use_graph else "; eager launches") + "; random-init weights, gates alpha=0.5",
                        "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
-                       "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph, "stock_gemm_tuning_file": stock_tuned},
+                       "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph, "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned},
             "roofline": roofline,
         }
         if attn:    # north star: throughput of the softmax(QK^T)V core as a fraction of the HBM roofline (8 TB/s spec peak)

@@ -469,11 +469,16 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     return Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(0, pF).c(pd).problem(S.Aact, P[10], y_out, S.ffw_out, nullptr, S.y1, P[1]).run(W.ws, W.ws_bytes, st);
 }
 
+// ext_k / ext_v != null: the keys / values were projected outside the block (ff_kv_project_fwd, strides d->cached_k / cached_v);
+// the block then hands d K / d V to `dkv_out` (same (b, n_kv, 2, heads, dim_head) layout as the projection's output) instead of
+// computing d to_kv.weight and d visual_features itself.
 static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, const int* tt, const void* const* P, const void* dy2,
                      const void* saved, size_t saved_bytes, void* const* G, void* dy, void* dvf, void* scratch, size_t scratch_bytes,
-                     hipStream_t st) {
+                     hipStream_t st, const void* ext_k = nullptr, const void* ext_v = nullptr, void* dkv_out = nullptr) {
     FF_TRY(xa_check(d));
-    FF_CHECK(y && vf && tt && P && dy2 && saved && G && dy && scratch, FF_ERR_SHAPE, "xattn_bwd: null argument");
+    const bool hoisted = ext_k != nullptr;
+    FF_CHECK(y && tt && P && dy2 && saved && G && dy && scratch && (hoisted ? (ext_v && dkv_out) : vf != nullptr), FF_ERR_SHAPE,
+             "xattn_bwd: null argument");
     const XaDims s(*d);
     XaSaved S;
     XaScratch W;
@@ -505,17 +510,89 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     fork.side_after_main();                                                                    // dy1 ready
     FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(W.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(ws2, gws, sd));
     FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(W.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
-    char* dK = (char*)W.dKV;
+    char* dK = hoisted ? (char*)dkv_out : (char*)W.dKV;
     char* dV = dK + (size_t)s.inner * s.es;
-    FF_TRY(attention_bwd(xa_attn_desc(*d, s, false), S.Qs, S.KV, (const char*)S.KV + (size_t)s.inner * s.es, tt, S.O, W.dO, S.lse, W.dQs, dK,
-                         dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
+    const void* Kp = hoisted ? ext_k : S.KV;
+    const void* Vp = hoisted ? ext_v : (const void*)((const char*)S.KV + (size_t)s.inner * s.es);
+    FF_TRY(attention_bwd(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, S.O, W.dO, S.lse, W.dQs, dK, dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
     fork.side_after_main();                                                                    // dQs, dKV ready
     FF_TRY(Gemm(s.dt, s.inner, s.d, M).a(1, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, S.yn, G[4]).run(ws2, gws, sd));
-    FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(ws2, gws, sd));
-    if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(ws2, gws, sd));
+    if (!hoisted) {
+        FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(ws2, gws, sd));
+        if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(ws2, gws, sd));
+    }
     FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, P[4], W.dyn).run(W.ws, gws, st));
     return layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, W.dy1, G[2], G[3], W.ws, gws, st);
     // ~Fork joins the side stream into `st`
+}
+
+// =====================================================================================================
+// Key / value projection of ALL cross-attention layers at once (gated_cross_attention.py:84-86 runs `to_kv` on the same
+// visual features in every layer, with different weights): grouped launches of up to kGemmMaxZ same-shape problems fill the
+// chip where the per-layer 2048 x 1024 x 1024 products do not, and d(visual features) is summed once instead of by 36 autograd adds.
+// =====================================================================================================
+static int kvp_check(const ff_kvproj_desc* d) {
+    FF_CHECK(d, FF_ERR_SHAPE, "kv_project: null descriptor");
+    FF_CHECK(d->dtype == FF_DTYPE_F32 || d->dtype == FF_DTYPE_BF16, FF_ERR_UNSUPPORTED, "kv_project: dtype %d", d->dtype);
+    FF_CHECK(d->n_layers > 0 && d->rows > 0 && d->dim_visual > 0 && d->kv_dim > 0 && (long long)d->rows * d->dim_visual < (1LL << 31), FF_ERR_SHAPE,
+             "kv_project: bad dimensions");
+    return FF_OK;
+}
+static size_t kvp_gemm_ws(const ff_kvproj_desc* d) {
+    const int z = kGemmMaxZ;
+    return align_up(std::max({gemm_workspace_bytes(d->dtype, d->rows, d->kv_dim, d->dim_visual, z, 0),
+                              gemm_workspace_bytes(d->dtype, d->kv_dim, d->dim_visual, d->rows, z, 0),
+                              gemm_workspace_bytes(d->dtype, d->rows, d->dim_visual, d->kv_dim, z, 0)}));
+}
+static size_t kvp_ws_bytes(const ff_kvproj_desc* d, bool with_dvf) {
+    const size_t es = d->dtype == FF_DTYPE_BF16 ? 2 : 4;
+    size_t w = kvp_gemm_ws(d);
+    if (with_dvf)
+        w += align_up((size_t)d->n_layers * d->rows * d->dim_visual * es) +
+             align_up(rows_reduce_workspace(d->n_layers, d->rows * d->dim_visual, d->n_layers, d->n_layers));
+    return w;
+}
+static int kv_project_fwd(const ff_kvproj_desc* d, const void* vf, const void* const* w_kv, void* const* kv_out, void* ws, size_t ws_bytes,
+                          hipStream_t st) {
+    FF_TRY(kvp_check(d));
+    FF_CHECK(vf && w_kv && kv_out && ws && ws_bytes >= kvp_gemm_ws(d), FF_ERR_WORKSPACE, "kv_project_fwd: null argument or workspace too small");
+    const RowMap pV = plain_rows(d->dim_visual), pKV = plain_rows(d->kv_dim);
+    for (int l0 = 0; l0 < d->n_layers; l0 += kGemmMaxZ) {
+        Gemm g(d->dtype, d->rows, d->kv_dim, d->dim_visual);
+        g.a(0, pV).b(0, pV).c(pKV);
+        for (int l = l0; l < std::min(d->n_layers, l0 + kGemmMaxZ); l++) g.problem(vf, w_kv[l], kv_out[l]);
+        FF_TRY(g.run(ws, ws_bytes, st));
+    }
+    return FF_OK;
+}
+static int kv_project_bwd(const ff_kvproj_desc* d, const void* vf, const void* const* w_kv, const void* const* dkv, void* const* dw_kv,
+                          void* dvf, void* ws, size_t ws_bytes, hipStream_t st) {
+    FF_TRY(kvp_check(d));
+    FF_CHECK(vf && w_kv && dkv && dw_kv && ws && ws_bytes >= kvp_ws_bytes(d, dvf != nullptr), FF_ERR_WORKSPACE,
+             "kv_project_bwd: null argument or workspace too small");
+    const size_t es = d->dtype == FF_DTYPE_BF16 ? 2 : 4, gws = kvp_gemm_ws(d);
+    const RowMap pV = plain_rows(d->dim_visual), pKV = plain_rows(d->kv_dim);
+    char* terms = (char*)ws + gws;                                             // [n_layers][rows][dim_visual]: one product per layer
+    const size_t term_bytes = (size_t)d->rows * d->dim_visual * es;
+    for (int l0 = 0; l0 < d->n_layers; l0 += kGemmMaxZ) {
+        const int l1 = std::min(d->n_layers, l0 + kGemmMaxZ);
+        Gemm gw(d->dtype, d->kv_dim, d->dim_visual, d->rows);                  // d W_l = d KV_l^T . vf
+        gw.a(1, pKV).b(1, pV).c(pV);
+        for (int l = l0; l < l1; l++) gw.problem(dkv[l], vf, dw_kv[l]);
+        FF_TRY(gw.run(ws, gws, st));
+        if (dvf) {
+            Gemm gx(d->dtype, d->rows, d->dim_visual, d->kv_dim);              // d vf contribution of layer l = d KV_l . W_l
+            gx.a(0, pKV).b(1, pV).c(pV);
+            for (int l = l0; l < l1; l++) gx.problem(dkv[l], w_kv[l], terms + (size_t)l * term_bytes);
+            FF_TRY(gx.run(ws, gws, st));
+        }
+    }
+    if (dvf) {   // sum the n_layers products in fp32
+        const int cols = d->rows * d->dim_visual;
+        FF_TRY(rows_reduce(d->dtype, d->n_layers, cols, plain_rows(cols), d->n_layers, d->n_layers, terms, dvf,
+                           terms + align_up((size_t)d->n_layers * term_bytes), rows_reduce_workspace(d->n_layers, cols, d->n_layers, d->n_layers), st));
+    }
+    return FF_OK;
 }
 
 }  // namespace ff
@@ -572,4 +649,25 @@ extern "C" int ff_xattn_block_bwd(const ff_xattn_desc* d, const void* y, const v
                                   void* dy, void* dvisual_features, void* scratch, size_t scratch_bytes, ff_stream_t stream) {
     return ff::xattn_bwd(d, y, visual_features, text_time, params, dy_out, saved, saved_bytes, grads, dy, dvisual_features, scratch,
                          scratch_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ff_xattn_block_bwd_kv(const ff_xattn_desc* d, const void* y, const void* k, const void* v, const int* text_time,
+                                     const void* const* params, const void* dy_out, const void* saved, size_t saved_bytes,
+                                     void* const* grads, void* dy, void* dkv, void* scratch, size_t scratch_bytes, ff_stream_t stream) {
+    using namespace ff;
+    FF_CHECK(k && v && dkv, FF_ERR_SHAPE, "ff_xattn_block_bwd_kv: null K / V / dKV");
+    return xattn_bwd(d, y, nullptr, text_time, params, dy_out, saved, saved_bytes, grads, dy, nullptr, scratch, scratch_bytes,
+                     (hipStream_t)stream, k, v, dkv);
+}
+extern "C" size_t ff_kv_project_workspace_bytes(const ff_kvproj_desc* d, int with_dvf) {
+    if (ff::kvp_check(d) != FF_OK) return 0;
+    return ff::kvp_ws_bytes(d, with_dvf != 0);
+}
+extern "C" int ff_kv_project_fwd(const ff_kvproj_desc* d, const void* visual_features, const void* const* w_kv, void* const* kv_out,
+                                 void* workspace, size_t workspace_bytes, ff_stream_t stream) {
+    return ff::kv_project_fwd(d, visual_features, w_kv, kv_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int ff_kv_project_bwd(const ff_kvproj_desc* d, const void* visual_features, const void* const* w_kv, const void* const* dkv,
+                                 void* const* dw_kv, void* dvisual_features, void* workspace, size_t workspace_bytes, ff_stream_t stream) {
+    return ff::kv_project_bwd(d, visual_features, w_kv, dkv, dw_kv, dvisual_features, workspace, workspace_bytes, (hipStream_t)stream);
 }

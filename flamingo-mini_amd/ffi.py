@@ -78,6 +78,10 @@ class AdamWDesc(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("step_dev", C.c_void_p)]
 
 
+class KvProjDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dtype", "n_layers", "rows", "dim_visual", "kv_dim")]
+
+
 class XattnDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("batch", C.c_int), ("n_tokens", C.c_int), ("dim", C.c_int), ("dim_visual", C.c_int),
                 ("n_media", C.c_int), ("n_visual", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int), ("ff_mult", C.c_int),
@@ -120,6 +124,10 @@ _SIGNATURES = {
     "ff_shifted_ce_fwd": (_I, [_I, _I, _I, _I, _P, _P, C.c_longlong, _P, _P, _P]),
     "ff_shifted_ce_bwd": (_I, [_I, _I, _I, _I, _P, _P, C.c_longlong, _P, _P, _P, _P]),
     "ff_adamw_step": (_I, [C.POINTER(AdamWDesc), _P, _P, _P, _P, _P, _P]),
+    "ff_xattn_block_bwd_kv": (_I, [C.POINTER(XattnDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
+    "ff_kv_project_workspace_bytes": (_SZ, [C.POINTER(KvProjDesc), _I]),
+    "ff_kv_project_fwd": (_I, [C.POINTER(KvProjDesc), _P, _P, _P, _P, _SZ, _P]),
+    "ff_kv_project_bwd": (_I, [C.POINTER(KvProjDesc), _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ff_xattn_block_bwd": (_I, [C.POINTER(XattnDesc), _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

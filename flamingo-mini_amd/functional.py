@@ -173,6 +173,103 @@ class _XattnBlockFn(torch.autograd.Function):
         return (dy, dvf, None, None, None, *grads)
 
 
+# ---- keys / values of ALL layers projected up front (ff_kv_project_*), blocks consume them and hand d K / d V back ----
+class _KvProjectFn(torch.autograd.Function):
+    """(vf (b, N, q, dv), W_0 .. W_{n-1} (kv_dim, dv)) -> KV_0 .. KV_{n-1} (b, N*q, kv_dim), K = [..., :kv_dim/2], V = the rest."""
+
+    @staticmethod
+    def forward(ctx, vf, *weights):
+        lib = ffi.lib()
+        vf = vf.contiguous()
+        weights = tuple(w.contiguous() for w in weights)
+        b, N, q, dv = vf.shape
+        kv_dim = weights[0].shape[0]
+        desc = ffi.KvProjDesc(ffi.dtype_code(vf.dtype), len(weights), b * N * q, dv, kv_dim)
+        kvs = tuple(torch.empty((b, N * q, kv_dim), dtype=vf.dtype, device=vf.device) for _ in weights)
+        ws = _empty_bytes(lib.ff_kv_project_workspace_bytes(desc, 0), vf.device)
+        ffi.check(lib.ff_kv_project_fwd(desc, vf.data_ptr(), ffi.ptr_array(weights), ffi.ptr_array(kvs), ws.data_ptr(), ws.numel(),
+                                        ffi.stream_handle(vf.device)), "ff_kv_project_fwd")
+        ctx.desc = desc
+        ctx.save_for_backward(vf, *weights)
+        ctx.set_materialize_grads(False)
+        return kvs
+
+    @staticmethod
+    def backward(ctx, *dkvs):
+        lib = ffi.lib()
+        vf, *weights = ctx.saved_tensors
+        desc = ctx.desc
+        b, N, q, _ = vf.shape
+        dkvs = [torch.zeros((b, N * q, desc.kv_dim), dtype=vf.dtype, device=vf.device) if g is None else g.contiguous() for g in dkvs]
+        flat, grads = _flat_grads(weights)
+        dvf = torch.empty_like(vf) if ctx.needs_input_grad[0] else None
+        ws = _empty_bytes(lib.ff_kv_project_workspace_bytes(desc, 1 if dvf is not None else 0), vf.device)
+        ffi.check(lib.ff_kv_project_bwd(desc, vf.data_ptr(), ffi.ptr_array(weights), ffi.ptr_array(dkvs), ffi.ptr_array(grads), ffi.ptr(dvf),
+                                        ws.data_ptr(), ws.numel(), ffi.stream_handle(vf.device)), "ff_kv_project_bwd")
+        for cb in _grad_ready_callbacks:
+            cb(flat)
+        return (dvf, *grads)
+
+
+def kv_project(visual_features: torch.Tensor, to_kv_weights: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, ...]:
+    """`to_kv` of every cross-attention layer applied to the same visual features (gated_cross_attention.py:84-86) in grouped
+    launches; returns one (b, N*q, 2*inner) tensor per layer for xattn_block(..., hoisted_kv=...)."""
+    ffi.require_cuda(visual_features, *to_kv_weights)
+    _same_dtype(visual_features, to_kv_weights, "kv_project")
+    return _KvProjectFn.apply(visual_features, *to_kv_weights)
+
+
+_KV_PARAM = 5        # position of attn.to_kv.weight in a block's parameter list
+
+
+class _XattnBlockKvFn(torch.autograd.Function):
+    """Block forward / backward with externally projected K / V: consumes `kv` (b, n_kv, 2*inner), returns d kv."""
+
+    @staticmethod
+    def _desc(y, kv, n_visual, dim_visual, cfg, tt):
+        inner = cfg[0] * cfg[1]
+        desc = _xattn_desc(y, kv.shape[1] // n_visual, n_visual, dim_visual, cfg, tt)
+        desc.cached_k = desc.cached_v = ffi.Strides(kv.shape[1] * 2 * inner, 2 * inner, cfg[1])   # (batch, row, head) strides
+        return desc, inner
+
+    @staticmethod
+    def forward(ctx, y, kv, tt, cfg, n_visual, *params):
+        lib = ffi.lib()
+        y, kv = y.contiguous(), kv.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        desc, inner = _XattnBlockKvFn._desc(y, kv, n_visual, params[_KV_PARAM].shape[1], cfg, tt)
+        dev = y.device
+        saved = _empty_bytes(lib.ff_xattn_saved_bytes(desc), dev)
+        scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
+        out = torch.empty_like(y)
+        ffi.check(lib.ff_xattn_block_fwd(desc, y.data_ptr(), None, tt.data_ptr(), ffi.ptr_array(params), kv.data_ptr(),
+                                         kv.data_ptr() + inner * kv.element_size(), out.data_ptr(), saved.data_ptr(), saved.numel(),
+                                         scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_fwd(hoisted kv)")
+        ctx.cfg, ctx.n_visual = cfg, n_visual
+        ctx.save_for_backward(y, kv, tt, saved, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = ffi.lib()
+        y, kv, tt, saved, *params = ctx.saved_tensors
+        desc, inner = _XattnBlockKvFn._desc(y, kv, ctx.n_visual, params[_KV_PARAM].shape[1], ctx.cfg, tt)
+        dev = y.device
+        dout = dout.contiguous()
+        own = [p for i, p in enumerate(params) if i != _KV_PARAM]            # d to_kv.weight comes from _KvProjectFn
+        flat, own_grads = _flat_grads(own)
+        grads = own_grads[:_KV_PARAM] + [None] + own_grads[_KV_PARAM:]
+        dy, dkv = torch.empty_like(y), torch.empty_like(kv)
+        scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
+        ffi.check(lib.ff_xattn_block_bwd_kv(desc, y.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * kv.element_size(), tt.data_ptr(),
+                                            ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(), ffi.ptr_array(grads),
+                                            dy.data_ptr(), dkv.data_ptr(), scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)),
+                  "ff_xattn_block_bwd_kv")
+        for cb in _grad_ready_callbacks:
+            cb(flat)
+        return (dy, dkv, None, None, None, *grads)
+
+
 def _kv_views(saved: torch.Tensor, y: torch.Tensor, n_kv: int, heads: int, dim_head: int):
     """K / V as (b, h, n_kv, dim_head) views of the library's (b, n_kv, 2, h, dim_head) buffer (no copy)."""
     b = y.shape[0]
@@ -182,12 +279,21 @@ def _kv_views(saved: torch.Tensor, y: torch.Tensor, n_kv: int, heads: int, dim_h
 
 
 def xattn_block(y: torch.Tensor, visual_features: Optional[torch.Tensor], tt: torch.Tensor, params: Sequence[torch.Tensor], cfg,
-                n_visual: int, previous_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, output_kv: bool = False):
+                n_visual: int, previous_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, output_kv: bool = False,
+                hoisted_kv: Optional[torch.Tensor] = None):
     """GatedCrossAttentionBlock forward.  cfg = (heads, dim_head, ff_mult, act); tt = text_time int32 (b, L_total).
-    Returns (y_out, (k, v) or None)."""
+    hoisted_kv: this layer's output of kv_project (then visual_features is not read).  Returns (y_out, (k, v) or None)."""
     ffi.require_cuda(y, tt, *params)
     _same_dtype(y, params, "GatedCrossAttentionBlock")
     heads, dim_head = cfg[0], cfg[1]
+    if previous_kv is None and hoisted_kv is not None:
+        ffi.require_cuda(hoisted_kv)
+        out = _XattnBlockKvFn.apply(y, hoisted_kv, tt, tuple(cfg), n_visual, *params)
+        kv = None
+        if output_kv:
+            split = hoisted_kv.detach().view(hoisted_kv.shape[0], hoisted_kv.shape[1], 2, heads, dim_head)
+            kv = (split[:, :, 0].permute(0, 2, 1, 3), split[:, :, 1].permute(0, 2, 1, 3))
+        return out, kv
     if previous_kv is None:
         ffi.require_cuda(visual_features)
         if visual_features.dtype != y.dtype:

@@ -54,18 +54,20 @@ class GatedCrossAttentionBlock(nn.Module):
 
     def forward(self, y: torch.Tensor, visual_features: Optional[torch.Tensor], media_locations: torch.Tensor,
                 previous_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, output_kv: bool = False,
-                text_time: Optional[torch.Tensor] = None):
+                text_time: Optional[torch.Tensor] = None, hoisted_kv: Optional[torch.Tensor] = None):
         """y (b, L, dim); visual_features (b, N, n_visual, dim_visual); media_locations (b, L_total) 0/1.
-        `text_time` (int32 cumsum of media_locations) may be passed to share it between layers."""
-        if previous_kv is None:
+        `text_time` (int32 cumsum of media_locations) may be passed to share it between layers; `hoisted_kv` is this layer's
+        slice of functional.kv_project (keys / values of all layers projected up front)."""
+        if previous_kv is None and hoisted_kv is None:
             assert visual_features is not None and visual_features.ndim == 4
         if text_time is None:
             text_time = F.text_time(media_locations)
         if previous_kv is None:
             assert text_time.shape == y.shape[:2]
         shape_before = y.shape
+        extra = {} if hoisted_kv is None else {"hoisted_kv": hoisted_kv}
         out, kv = F.xattn_block(y, visual_features, text_time, self.fused_params(), self.cfg, self.n_visual,
-                                previous_kv=previous_kv, output_kv=bool(output_kv))
+                                previous_kv=previous_kv, output_kv=bool(output_kv), **extra)
         assert out.shape == shape_before
         return out, kv
 
@@ -86,14 +88,16 @@ class ModifiedLMBlock(nn.Module):
         self.media_locations = None
         self.xattn_layer_past = None
         self.text_time = None
+        self.hoisted_kv = None
         self.kv_output = None
 
     def condition(self, visual_features: torch.Tensor, media_locations: torch.Tensor, xattn_layer_past=None,
-                  text_time: Optional[torch.Tensor] = None) -> None:
+                  text_time: Optional[torch.Tensor] = None, hoisted_kv: Optional[torch.Tensor] = None) -> None:
         self.visual_features = visual_features
         self.media_locations = media_locations
         self.xattn_layer_past = xattn_layer_past
         self.text_time = text_time
+        self.hoisted_kv = hoisted_kv
 
     def _use_cache_flag(self, args, kwargs) -> bool:
         if "use_cache" in kwargs:
@@ -115,6 +119,7 @@ class ModifiedLMBlock(nn.Module):
             previous_kv=self.xattn_layer_past,
             output_kv=use_cache,
             text_time=self.text_time,
+            hoisted_kv=self.hoisted_kv,
         )
         self.kv_output = kv
         return self.lm_block(hidden_states, *args, **kwargs)

@@ -226,6 +226,33 @@ int ff_xattn_block_bwd(const ff_xattn_desc* d, const void* y, const void* visual
 
 
 /* ------------------------------------------------------------------------------------------------------
+ * Key / value projection hoisted out of the cross-attention layers.  gated_cross_attention.py:84-86 applies every layer's
+ * `to_kv` to the SAME visual features; projecting for all layers in grouped launches (and summing d visual_features once)
+ * replaces n_layers small GEMMs per direction.  w_kv[l] (kv_dim, dim_visual) = layer l's to_kv.weight; kv_out[l] / dkv[l]
+ * (rows, kv_dim) with rows = batch * n_media * n_visual, K = columns [0, kv_dim/2), V = the rest - the layout
+ * ff_xattn_block_fwd expects for cached_k / cached_v with strides {n_kv * kv_dim, kv_dim, dim_head}.
+ * Training step:  ff_kv_project_fwd -> per layer ff_xattn_block_fwd(cached_k = kv_out[l], cached_v = kv_out[l] + kv_dim/2)
+ *                 ... per layer ff_xattn_block_bwd_kv(... dkv[l]) -> ff_kv_project_bwd (d to_kv.weight of every layer, d visual_features).
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct ff_kvproj_desc {
+    int dtype;
+    int n_layers;
+    int rows;         /* batch * n_media * n_visual */
+    int dim_visual;
+    int kv_dim;       /* 2 * heads * dim_head */
+} ff_kvproj_desc;
+size_t ff_kv_project_workspace_bytes(const ff_kvproj_desc* d, int with_dvisual_features);
+int ff_kv_project_fwd(const ff_kvproj_desc* d, const void* visual_features, const void* const* w_kv, void* const* kv_out,
+                      void* workspace, size_t workspace_bytes, ff_stream_t stream);
+int ff_kv_project_bwd(const ff_kvproj_desc* d, const void* visual_features, const void* const* w_kv, const void* const* dkv,
+                      void* const* dw_kv, void* dvisual_features, void* workspace, size_t workspace_bytes, ff_stream_t stream);
+/* Backward of a block whose K / V came from ff_kv_project_fwd (d->cached_k / cached_v = their strides): writes d K / d V into
+ * `dkv` (same layout as kv_out[l]); grads[5] (to_kv.weight) is not written. */
+int ff_xattn_block_bwd_kv(const ff_xattn_desc* d, const void* y, const void* k, const void* v, const int* text_time,
+                          const void* const* params, const void* dy_out, const void* saved, size_t saved_bytes, void* const* grads,
+                          void* dy, void* dkv, void* scratch, size_t scratch_bytes, ff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW over the trainable parameters (the reference trains with `--optim adamw_torch`,
  * training/train.sh:10-13; parameters_trainable() modeling_flamingo.py:132-138).  All tensors of one call share `dtype`
  * (params, grads and both moment buffers); math is fp32.  step is the 1-based step count AFTER incrementing

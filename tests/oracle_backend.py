@@ -65,11 +65,73 @@ class _Xa(torch.autograd.Function):
         return (torch.from_numpy(dy).to(ydt), torch.from_numpy(dvf).to(ydt), None, None, None) + _emit_flat(g, XA_KEYS, like)
 
 
+class _KvProj(torch.autograd.Function):
+    """What ff_kv_project_fwd / _bwd compute, with the product's gradient plumbing: all d to_kv.weight in ONE flat buffer that is
+    announced to the grad-ready callbacks (the data-parallel reducer's bucket)."""
+
+    @staticmethod
+    def forward(ctx, vf, *weights):
+        rows = vf.reshape(vf.shape[0], vf.shape[1] * vf.shape[2], vf.shape[3])
+        ctx.save_for_backward(vf, *weights)
+        ctx.set_materialize_grads(False)
+        return tuple(rows @ w.t() for w in weights)
+
+    @staticmethod
+    def backward(ctx, *dkvs):
+        from flamingo_mini_amd import functional as F
+        vf, *weights = ctx.saved_tensors
+        rows = vf.reshape(-1, vf.shape[3])
+        flat, views = F._flat_grads(weights)
+        dvf = torch.zeros_like(rows)
+        for view, w, g in zip(views, weights, dkvs):
+            g2 = torch.zeros(rows.shape[0], w.shape[0], dtype=vf.dtype) if g is None else g.reshape(-1, w.shape[0])
+            view.copy_(g2.t() @ rows)
+            dvf += g2 @ w
+        for cb in F._grad_ready_callbacks:
+            cb(flat)
+        return (dvf.reshape(vf.shape), *views)
+
+
+class _XaHoisted(torch.autograd.Function):
+    """_Xa with projected K / V as the "visual features" and an identity to_kv (params[5]); `real_w` only keeps the real weight
+    in the graph with a None gradient, like the product's _XattnBlockKvFn."""
+
+    @staticmethod
+    def forward(ctx, y, kv4, tt, cfg, n_visual, real_w, *params):
+        heads, dim_head, ffm, act = cfg
+        p = dict(zip(XA_KEYS, map(_np, params)))
+        ml = np.diff(tt.numpy().astype(np.int64), axis=1, prepend=0)
+        out, kv, cache = O.gated_xattn_block_fwd(_np(y), _np(kv4), ml, p, heads=heads, dim_head=dim_head, act=act, n_visual=n_visual)
+        ctx.stuff = (cache, p, cfg, y.dtype, [torch.empty_like(t) for i, t in enumerate(params) if i != 5])
+        return torch.from_numpy(out).to(y.dtype), torch.from_numpy(kv[0]).to(y.dtype), torch.from_numpy(kv[1]).to(y.dtype)
+
+    @staticmethod
+    def backward(ctx, dout, _dk, _dv):
+        cache, p, cfg, ydt, like = ctx.stuff
+        dy, dkv4, g = O.gated_xattn_block_bwd(_np(dout), cache, p, heads=cfg[0], dim_head=cfg[1], act=cfg[3])
+        keys = [k for i, k in enumerate(XA_KEYS) if i != 5]
+        own = list(_emit_flat(g, keys, like))
+        grads = own[:5] + [None] + own[5:]
+        return (torch.from_numpy(dy).to(ydt), torch.from_numpy(dkv4).to(ydt), None, None, None, None, *grads)
+
+
 class OracleBackend:
     def resampler(self, x_f, params, cfg):
         return _Rs.apply(x_f, tuple(cfg), *params)
 
-    def xattn_block(self, y, vf, tt, params, cfg, n_visual, previous_kv, output_kv):
+    def kv_project(self, vf, weights):
+        return _KvProj.apply(vf, *weights)
+
+    def xattn_block(self, y, vf, tt, params, cfg, n_visual, previous_kv, output_kv, hoisted_kv=None):
+        if previous_kv is None and hoisted_kv is not None:
+            # the oracle projects K / V itself: feed it the projected tensor with an identity to_kv, so its
+            # d(visual features) is exactly d(K, V) and its to_kv gradient is discarded (it comes from kv_project)
+            b, n_kv, kv_dim = hoisted_kv.shape
+            params = list(params)
+            real_w = params[5]
+            params[5] = torch.eye(kv_dim, dtype=real_w.dtype)
+            out, k, v = _XaHoisted.apply(y, hoisted_kv.reshape(b, n_kv // n_visual, n_visual, kv_dim), tt, tuple(cfg), n_visual, real_w, *params)
+            return out, ((k.detach(), v.detach()) if output_kv else None)
         if previous_kv is None:
             out, k, v = _Xa.apply(y, vf, tt, tuple(cfg), n_visual, *params)
             return out, ((k.detach(), v.detach()) if output_kv else None)
@@ -91,10 +153,11 @@ def install():
     if _saved:
         return
     backend = OracleBackend()
-    _saved.update(resampler=F.resampler, xattn_block=F.xattn_block, text_time=F.text_time)
+    _saved.update(resampler=F.resampler, xattn_block=F.xattn_block, text_time=F.text_time, kv_project=F.kv_project)
+    F.kv_project = lambda vf, weights: backend.kv_project(vf, weights)
     F.resampler = lambda x_f, params, cfg: backend.resampler(x_f, params, cfg)
-    F.xattn_block = lambda y, vf, tt, params, cfg, n_visual, previous_kv=None, output_kv=False: \
-        backend.xattn_block(y, vf, tt, params, cfg, n_visual, previous_kv, output_kv)
+    F.xattn_block = lambda y, vf, tt, params, cfg, n_visual, previous_kv=None, output_kv=False, hoisted_kv=None: \
+        backend.xattn_block(y, vf, tt, params, cfg, n_visual, previous_kv, output_kv, hoisted_kv)
     F.text_time = lambda ml: ml.to(torch.int64).cumsum(-1).to(torch.int32)
 
 

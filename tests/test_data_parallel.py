@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build_tiny():
+def _build_tiny(hoist_kv=False):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -28,6 +28,7 @@ def _build_tiny():
     from test_model_plumbing import build
     oracle_backend.install()                            # CPU ranks: fused entry points patched to the oracle (tests only)
     model, z = build(torch.float64, "cpu")
+    model.flamingo.hoist_kv = hoist_kv
     return model.train(), z
 
 
@@ -38,12 +39,12 @@ def _loss(model, z, rows):
     return model(input_ids=ids, attention_mask=torch.ones_like(ids), media_locations=ml, pixel_values=px, labels=ids).loss
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, hoist_kv):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from flamingo_mini_amd.data_parallel import GradientAllReducer
-    model, z = _build_tiny()
+    model, z = _build_tiny(hoist_kv)
     reducer = GradientAllReducer(model)
     buckets = []
     orig = reducer._on_bucket
@@ -60,16 +61,18 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("hoist_kv", [False, True], ids=["per-layer-kv", "hoisted-kv"])
+def test_two_rank_gloo_matches_single_process(tmp_path, hoist_kv):
     port = _free_port()
-    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, port, str(tmp_path), hoist_kv), nprocs=2, join=True, start_method="spawn")
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     # reference: one process, mean of the two per-sequence losses == DDP-averaged gradients
-    model, z = _build_tiny()
+    model, z = _build_tiny(hoist_kv)
     model.zero_grad(set_to_none=True)
     ((_loss(model, z, [0]) + _loss(model, z, [1])) / 2).backward()
     n_hooks = len(model.flamingo.get_modified_layers())
-    assert int(r0["nbuckets"]) == n_hooks + 2      # one flat bucket per xattn block + the resampler + the token embedding (loose hook)
+    # one flat bucket per xattn block + the resampler + the token embedding (loose hook) (+ all to_kv weights when hoisted)
+    assert int(r0["nbuckets"]) == n_hooks + 2 + int(hoist_kv)
     for k, p in model.named_parameters():
         if not p.requires_grad:
             continue

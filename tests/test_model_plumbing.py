@@ -65,11 +65,13 @@ def run_checks(model, z, device, dtype, tol_out, tol_grad):
     assert rel(o2.logits, z["step2_logits"]) < tol_out
 
 
-def test_full_model_plumbing_cpu_with_oracle_checker():
+@pytest.mark.parametrize("hoist_kv", [False, True], ids=["per-layer-kv", "hoisted-kv"])
+def test_full_model_plumbing_cpu_with_oracle_checker(hoist_kv):
     import oracle_backend
     oracle_backend.install()
     try:
         model, z = build(torch.float64, "cpu")
+        model.flamingo.hoist_kv = hoist_kv        # K / V of all layers projected up front: same logits, loss and gradients
         run_checks(model, z, "cpu", torch.float64, 1e-9, 1e-8)
     finally:
         oracle_backend.uninstall()
@@ -83,8 +85,10 @@ def test_cpu_tensors_raise_in_the_product_path():
 
 
 @pytest.mark.gpu
-def test_full_model_fp32_on_hip_matches_reference():
+@pytest.mark.parametrize("hoist_kv", [False, True], ids=["per-layer-kv", "hoisted-kv"])
+def test_full_model_fp32_on_hip_matches_reference(hoist_kv):
     model, z = build(torch.float32, "cuda")
+    model.flamingo.hoist_kv = hoist_kv
     run_checks(model, z, "cuda", torch.float32, 1e-4, 5e-4)
 
 

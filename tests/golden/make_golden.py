@@ -221,3 +221,109 @@ def full_model_case():
 
 if __name__ == "__main__" and os.environ.get("FLAMINGO_GOLDEN_FULL", "1") == "1":
     full_model_case()
+
+
+# ---------------------------------------------------------------------------------------------------
+# tiny FULL model, GPT-2-backed, config-A-like geometry (BASELINE configs[0]: gpt2 + ViT-B/32: 50 CLIP tokens per image,
+# xattn_every=1, 1 image, seq_len 32, batch 2).  transformers >= 5 calls GPT-2 blocks positionally, which the reference's
+# ModifiedLMBlock.forward(hidden_states, use_cache=False, **kwargs) (gated_cross_attention.py:231-252) cannot take, so ONLY that
+# method is replaced by an argument-tolerant one that runs the reference's own xattn_block + lm_block in the same order.
+# Also: 6-D (video) and 4-D pixel inputs and the visual_features= hand-off (modeling_flamingo.py:153-167, 189, 212-215).
+# ---------------------------------------------------------------------------------------------------
+TINY_GPT2 = dict(
+    lm_kw=dict(n_embd=64, n_layer=3, n_head=2, vocab_size=96, n_positions=64, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0),
+    clip_kw=dict(hidden_size=48, num_hidden_layers=2, num_attention_heads=2, intermediate_size=96, patch_size=16, image_size=112),
+    flamingo_kw=dict(lm="gpt2-tiny", clip_model_type="openai/clip-vit-tiny", dim=64, dim_visual=48, xattn_every=1,
+                     xattn_dim_head=32, xattn_heads=2, xattn_ff_mult=2, xattn_act="gelu", resampler_depth=2,
+                     resampler_dim_head=32, resampler_heads=2, resampler_num_latents=8, resampler_num_time_embeds=4,
+                     resampler_ff_mult=2, resampler_act="sqrelu"),
+)
+
+
+def full_model_case_gpt2():
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel, GPT2Config, GPT2LMHeadModel
+    CLIPVisionModel.from_pretrained = classmethod(lambda cls, name, **kw: CLIPVisionModel(CLIPVisionConfig(**TINY_GPT2["clip_kw"])))
+    GPT2LMHeadModel.from_pretrained = classmethod(lambda cls, name, **kw: GPT2LMHeadModel(GPT2Config(**TINY_GPT2["lm_kw"])))
+    shim = sys.modules["einops_exts"]
+    for name in list(sys.modules):
+        if name.startswith("flamingo_mini"):
+            del sys.modules[name]
+    sys.modules["einops_exts"] = shim
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import flamingo_mini as ref
+    from flamingo_mini import gated_cross_attention as gca
+
+    def tolerant_forward(self, hidden_states, *args, use_cache=False, **kwargs):
+        hidden_states, kv = self.xattn_block(y=hidden_states, visual_features=self.visual_features, media_locations=self.media_locations,
+                                             previous_kv=self.xattn_layer_past, output_kv=use_cache)
+        self.kv_output = kv
+        return self.lm_block(hidden_states, *args, use_cache=use_cache, **kwargs)
+
+    gca.ModifiedLMBlock.forward = tolerant_forward
+    torch.manual_seed(11)
+    cfg = ref.FlamingoConfig(**TINY_GPT2["flamingo_kw"])
+    model = ref.FlamingoModel(cfg)
+    assert type(model.flamingo).__name__ == "FlamingoGPT2"
+    with torch.no_grad():      # every value float32-representable, so the state_dict can be stored in float32 without loss
+        for i, hook in enumerate(model.flamingo.get_modified_layers()):
+            hook.xattn_block.alpha_attn.fill_(0.5 - 0.25 * i)
+            hook.xattn_block.alpha_ffw.fill_(-0.375 + 0.25 * i)
+    model = model.float().double()
+    model.train()
+    b, L, N = 2, 32, 1
+    px = t64(det((b, N, 3, 112, 112), "gpt2-px"))
+    ids = torch.from_numpy((np.abs(det((b, L), "gpt2-ids")) * 96).astype(np.int64) % 96)
+    ml = torch.zeros(b, L, dtype=torch.long); ml[0, 0] = 1; ml[1, [3, 17]] = 1     # row 1: leading t=0 tokens + a 2nd tag with 1 image (uniform rows)
+    am = torch.ones(b, L, dtype=torch.long)
+    out = model(input_ids=ids, attention_mask=am, media_locations=ml, pixel_values=px, labels=ids)
+    out.loss.backward()
+    sd = {k: v.detach().numpy().astype(np.float32) for k, v in model.state_dict().items()}
+    for k, v in model.state_dict().items():
+        assert np.array_equal(sd[k].astype(np.float64), v.detach().numpy()), k
+    grads = {k: p.grad.numpy() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    model.eval()
+    with torch.no_grad():
+        o1 = model(input_ids=ids[:, :-1], attention_mask=am[:, :-1], media_locations=ml[:, :-1], pixel_values=px, use_cache=True)
+        o2 = model(input_ids=ids[:, -1:], attention_mask=am, media_locations=ml, past_key_values=o1.past_key_values, use_cache=True)
+        full = model(input_ids=ids, attention_mask=am, media_locations=ml, pixel_values=px)
+        assert torch.allclose(o2.logits[:, -1], full.logits[:, -1], atol=1e-8)
+        # visual_features= instead of pixel_values (modeling_flamingo.py:189,212-215): same logits
+        vf = model.flamingo.encode_resample_visuals(px)
+        via_vf = model(input_ids=ids, attention_mask=am, media_locations=ml, visual_features=vf)
+        assert torch.allclose(via_vf.logits, full.logits, atol=1e-10)
+        # 6-D video pixels (b N T c h w), T = 2 frames flattened into the resampler's key axis (:153-167)
+        px6 = t64(det((b, 1, 2, 3, 112, 112), "gpt2-px6"))
+        vid = model(input_ids=ids, attention_mask=am, media_locations=ml, pixel_values=px6)
+        # 4-D pixels (N c h w) = ONE sequence with N = 2 images (:153-156).  forward() itself asserts pixel_values.size(0) == batch
+        # (:244), so the 4-D form is only reachable through encode_resample_visuals; its output then feeds visual_features=.
+        px4 = t64(det((2, 3, 112, 112), "gpt2-px4"))
+        ml4 = torch.zeros(1, L, dtype=torch.long); ml4[0, [1, 9]] = 1
+        vf4 = model.flamingo.encode_resample_visuals(px4)
+        assert tuple(vf4.shape) == (1, 2, 8, 48)
+        four = model(input_ids=ids[:1], attention_mask=am[:1], media_locations=ml4, visual_features=vf4)
+    save = {"sd." + k: v for k, v in sd.items()}
+    save.update({"g." + k: v for k, v in grads.items()})
+    save.update(ids=ids.numpy(), ml=ml.numpy(), ml4=ml4.numpy(), logits=out.logits.detach().numpy(), loss=np.array(out.loss.item()),
+                eval_logits=full.logits.numpy(), step2_logits=o2.logits.numpy(), vf=vf.numpy(), video_logits=vid.logits.numpy(),
+                vf4=vf4.numpy(), four_d_logits=four.logits.numpy())
+    np.savez_compressed(os.path.join(HERE, "full_gpt2_tiny.npz"), **save)
+    n_rs = sum(p.numel() for p in model.flamingo.resampler.parameters())
+    print("full_gpt2_tiny: logits", tuple(out.logits.shape), "loss", out.loss.item(), "trainable grads", len(grads),
+          "resampler params", n_rs, "transformers", transformers.__version__)
+
+
+def param_count_pins():
+    """The two known-answer parameter counts of the reference (examples/model_stats.ipynb:1605), re-derived from the reference classes."""
+    mods = load_reference()
+    rs = mods["perceiver_resampler"].PerceiverResampler(dim=1024, depth=6)
+    xa = mods["gated_cross_attention"].GatedCrossAttentionBlock(dim=1280, dim_visual=1024)
+    n_rs, n_xa = sum(p.numel() for p in rs.parameters()), sum(p.numel() for p in xa.parameters())
+    assert (n_rs, n_xa) == (63023104, 15471618), (n_rs, n_xa)
+    print("param counts: resampler(dim 1024, depth 6) =", n_rs, " xattn block(1280, 1024) =", n_xa)
+
+
+if __name__ == "__main__" and os.environ.get("FLAMINGO_GOLDEN_FULL", "1") == "1":
+    full_model_case_gpt2()
+    param_count_pins()

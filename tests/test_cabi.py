@@ -85,3 +85,15 @@ def test_gemm_plan_for_the_benchmark_shapes():
     assert plan(4096, 4096, 4096) == (128, 128, 1)
     bm, bn, sk = plan(512, 1024, 10272, 1, 1)                # resampler dWk/dWv: 32 tiles, K = 10272
     assert (bm, bn) == (128, 128) and sk >= 4
+
+
+def test_reference_parameter_counts():
+    """The reference's own known-answer pins (examples/model_stats.ipynb:1605): a depth-6 resampler at dim_visual 1024 has
+    63 023 104 parameters, one gated cross-attention block at (dim 1280, dim_visual 1024) 15 471 618 - re-derived from the reference
+    classes by tests/golden/make_golden.py:param_count_pins."""
+    from flamingo_mini_amd import GatedCrossAttentionBlock, PerceiverResampler
+    rs = PerceiverResampler(dim=1024, depth=6)
+    xa = GatedCrossAttentionBlock(dim=1280, dim_visual=1024)
+    assert sum(p.numel() for p in rs.parameters()) == 63023104
+    assert sum(p.numel() for p in xa.parameters()) == 15471618
+    assert len(rs.fused_params()) == len(list(rs.parameters())) and len(xa.fused_params()) == len(list(xa.parameters()))

@@ -73,6 +73,32 @@ def test_config_D_video_resampler(dtype):
         m(dev(det((1, 5, 10, dim), "D-x5"), dtype))
 
 
+def test_config_B_full_batch_block_bf16_vs_oracle():
+    """BASELINE configs[1] at its FULL per-GPU batch (32 x 32 tokens, gpt2-large block, 1 image), benchmark dtype, straight
+    against the float64 oracle on the same bf16-rounded inputs (not only against the library's own fp32 path)."""
+    ml = np.zeros((32, 32), np.int64); ml[:, 0] = 1
+    _check_block(torch.bfloat16, 1280, 1024, 32, 32, 1, ml, tag="Bfull")
+
+
+def test_config_A_geometry_block_and_resampler():
+    """BASELINE configs[0] geometry (gpt2 124M + CLIP ViT-B/32): dim 768, dim_visual 768, 50 CLIP tokens, L = 32, batch 2, fp32."""
+    ml = np.zeros((2, 32), np.int64); ml[:, 0] = 1
+    _check_block(torch.float32, 768, 768, 2, 32, 1, ml, tag="A")
+    p = resampler_params(768, 6, 8, 64, 64, 4, 4, tag="A")
+    m = build_resampler(p, 768, 6, 8, 64, 64, 4, 4, "gelu", torch.float32)
+    xd = dev(det((2, 1, 50, 768), "A-x"), torch.float32).requires_grad_(True)
+    dyd = dev(det((2, 64, 768), "A-dy"), torch.float32)
+    y = m(xd)
+    y.backward(dyd)
+    p64 = {k: as64(v) for k, v in m.state_dict().items()}
+    yr, cache = O.resampler_fwd(as64(xd), p64)
+    dxr, gr = O.resampler_bwd(as64(dyd), cache, p64)
+    t = TOL[torch.float32]
+    assert rel(y, yr) < t["out"] and rel(xd.grad, dxr) < t["grad"]
+    for k in ("time_pos_emb", "latents", "layers.0.0.to_q.weight", "layers.5.1.1.weight"):
+        assert rel(dict(m.named_parameters())[k].grad, gr[k]) < t["grad"], k
+
+
 def test_config_B_full_size_properties():
     """flamingo-mini sizes, batch 32: resampler (32, 1, 257, 1024) depth 6 and one gpt2-large block (32, 32, 1280)."""
     dim, dv, b, L = 1280, 1024, 32, 32

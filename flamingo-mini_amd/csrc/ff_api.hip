@@ -27,63 +27,6 @@ int check_launch(const char* what) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// Fork / join onto a library-owned side stream.  The weight-gradient GEMMs (and gate-gradient reductions) of a
-// backward pass are not on its critical path and no single GEMM of these sizes fills 256 CUs, so they run
-// concurrently with the data-gradient chain when FF_OVERLAP=1.  Measured on MI355X at config B: no gain (57.1 vs 56.8 ms
-// per step) - the GEMMs are bound by chip-wide operand-tile traffic, so concurrent kernels only slow each other down -
-// hence OFF by default (everything on the caller's stream).  Ordering is by events only.  The side stream joins the caller's stream before the entry point returns.
-// ---------------------------------------------------------------------------------------------------------
-namespace {
-struct SideState {
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[64];
-    int next = 0;
-    bool ready = false;
-};
-SideState g_side[16];
-bool overlap_enabled() {
-    static const int v = [] { const char* e = getenv("FF_OVERLAP"); return e ? atoi(e) : 0; }();
-    return v != 0;
-}
-}  // namespace
-
-class Fork {
-  public:
-    explicit Fork(hipStream_t main) : main_(main), side_(main), st_(nullptr) {
-        if (!overlap_enabled()) return;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
-        SideState& s = g_side[dev];
-        if (!s.ready) {
-            if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return;
-            for (auto& e : s.ev)
-                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
-            s.ready = true;
-        }
-        st_ = &s;
-        side_ = s.stream;
-        side_after_main();
-    }
-    ~Fork() { join(); }
-    hipStream_t side() const { return side_; }
-    bool active() const { return st_ != nullptr; }
-    void side_after_main() { link(main_, side_); }    // side stream waits for everything enqueued on main so far
-    void join() {                                     // main waits for everything enqueued on the side stream so far
-        link(side_, main_);
-    }
-
-  private:
-    void link(hipStream_t from, hipStream_t to) {
-        if (!st_) return;
-        hipEvent_t e = st_->ev[st_->next++ & 63];
-        hipEventRecord(e, from);
-        hipStreamWaitEvent(to, e, 0);
-    }
-    hipStream_t main_, side_;
-    SideState* st_;
-};
-
 static LnArgs ln_args(int dtype, int rows, int cols, RowMap x, RowMap y, RowMap dx) {
     LnArgs a;
     a.dtype = dtype; a.rows = rows; a.cols = cols;
@@ -144,8 +87,15 @@ static size_t rs_saved_layout(const RsDims& s, void* base, size_t cap, RsSaved& 
     return align_up(a.used);
 }
 
+// Backward keeps what the weight-gradient GEMMs need (d x at each layer's output, d x_mid, d H, d Qs, d K, d V) for EVERY layer:
+// the weight gradients are not on the critical path, so they run after the data-gradient chain as grouped launches over up to
+// kGemmMaxZ layers (same shapes, different operands) - one chip-filling launch instead of four that each fill a third of it.
+struct RsLayerStash {
+    void *dx_out, *dx_mid, *dH, *dQs, *dK, *dV;
+};
 struct RsScratch {
-    void *dx, *dx_b, *dH, *dxn, *dO, *dQs, *dK, *dV, *dkv, *dln, *dxf, *ws, *ws2, *dx_mid;
+    void *dx0, *dxn, *dO, *dkv, *dln, *dxf, *ws;
+    RsLayerStash L[kMaxDepth];
     size_t ws_bytes;
 };
 static size_t rs_ws_bytes(const RsDims& s) {
@@ -153,7 +103,9 @@ static size_t rs_ws_bytes(const RsDims& s) {
     size_t w = 0;
     auto g = [&](int M, int N, int K, int nz) { w = std::max(w, gemm_workspace_bytes(s.dt, M, N, K, nz, 0)); };
     g(Mq, s.inner, s.D, 1); g(Mkv, s.inner, s.D, 2); g(Mq, s.D, s.inner, 1); g(Mq, s.ffi, s.D, 1); g(Mq, s.D, s.ffi, 1);   // fwd
-    g(s.D, s.ffi, Mq, 1); g(s.ffi, s.D, Mq, 1); g(s.D, s.inner, Mq, 1); g(s.inner, s.D, Mq, 1); g(s.inner, s.D, Mkv, 2);  // wgrad
+    for (int nz = 1; nz <= kGemmMaxZ; nz++) {                                                                               // grouped wgrad
+        g(s.D, s.ffi, Mq, nz); g(s.ffi, s.D, Mq, nz); g(s.D, s.inner, Mq, nz); g(s.inner, s.D, Mq, nz); g(s.inner, s.D, Mkv, nz);
+    }
     g(Mkv, s.D, s.inner, 1);
     w = std::max(w, layernorm_bwd_workspace(s.Bn * s.F, s.D));
     w = std::max(w, layernorm_bwd_workspace(Mq, s.D));
@@ -166,21 +118,22 @@ static size_t rs_scratch_layout(const RsDims& s, void* base, size_t cap, bool bw
     const size_t rows_q = (size_t)s.Bn * s.q, rows_kv = (size_t)s.Bn * s.R;
     o.ws_bytes = rs_ws_bytes(s);
     o.ws = a.take(o.ws_bytes);
-    o.ws2 = nullptr; o.dx_mid = nullptr;
     if (bwd) {
-        o.ws2 = a.take(o.ws_bytes);                 // workspace of the side stream
-        o.dx_mid = a.take(rows_q * s.D * s.es);     // d x_mid is read by side-stream GEMMs while d x_in is produced
-        o.dx = a.take(rows_q * s.D * s.es);
-        o.dx_b = a.take(rows_q * s.D * s.es);
-        o.dH = a.take(rows_q * s.ffi * s.es);
+        o.dx0 = a.take(rows_q * s.D * s.es);        // d (latents broadcast over the batch)
         o.dxn = a.take(rows_q * s.D * s.es);
         o.dO = a.take(rows_q * s.inner * s.es);
-        o.dQs = a.take(rows_q * s.inner * s.es);
-        o.dK = a.take(rows_kv * s.inner * s.es);
-        o.dV = a.take(rows_kv * s.inner * s.es);
         o.dkv = a.take(rows_kv * s.D * s.es);
         o.dln = a.take(rows_q * s.D * s.es);
         o.dxf = a.take((size_t)s.Bn * s.F * s.D * s.es);
+        for (int l = 0; l < s.depth; l++) {
+            RsLayerStash& L = o.L[l];
+            L.dx_out = a.take(rows_q * s.D * s.es);
+            L.dx_mid = a.take(rows_q * s.D * s.es);
+            L.dH = a.take(rows_q * s.ffi * s.es);
+            L.dQs = a.take(rows_q * s.inner * s.es);
+            L.dK = a.take(rows_kv * s.inner * s.es);
+            L.dV = a.take(rows_kv * s.inner * s.es);
+        }
     }
     return align_up(a.used);
 }
@@ -278,63 +231,79 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
     float* attn_ws = (float*)((char*)W.ws + W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4));
     const size_t gws = W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4);
 
-    // Weight gradients go to the side stream (`sd`, workspace ws2); the data-gradient chain stays on `st`.  d x ping-pongs
-    // between two buffers (dx_in -> dx_mid -> dx_out) so nothing the side stream still reads is overwritten; the side
-    // stream is joined at the end of every layer.
-    Fork fork(st);
-    hipStream_t sd = fork.side();
-    void* ws2 = fork.active() ? W.ws2 : W.ws;
-    void* dx_in = W.dx;
-    void* dx_out = W.dx_b;
-
-    // final norm (:187)
-    FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), dout, S.x_last, nullptr, P[2], S.mean_o, S.rstd_o, dx_in, nullptr, G[2], G[3],
-                         W.ws, gws, st));
+    // ---- data-gradient chain (critical path); weight-gradient operands are left in W.L[l] ----
+    // final norm (:187): d x at the output of the last layer
+    FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), dout, S.x_last, nullptr, P[2], S.mean_o, S.rstd_o, W.L[s.depth - 1].dx_out, nullptr,
+                         G[2], G[3], W.ws, gws, st));
     for (int l = s.depth - 1; l >= 0; l--) {
         const void* const* p = P + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
         void* const* g = G + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
         const RsLayerSaved& L = S.L[l];
+        const RsLayerStash& T = W.L[l];
         const void* x_in = l == 0 ? latents : L.x_in;
         const RowMap x_map = l == 0 ? lat_bcast : pD;
-        const char* kv_lat_base = (const char*)L.kv_in + (size_t)s.F * s.D * s.es;
         char* dkv_lat_base = (char*)W.dkv + (size_t)s.F * s.D * s.es;
-
-        fork.side_after_main();                                                                // dx_in ready
+        void* dx_below = l == 0 ? W.dx0 : W.L[l - 1].dx_out;                                   // d x at this layer's input
         // ---- FeedForward backward (x_next = x_mid + W3 act(W1 LN(x_mid))) ----
-        FF_TRY(Gemm(s.dt, s.D, s.ffi, Mq).a(1, pD).b(1, pF).c(pF).problem(dx_in, L.Aact, g[11]).run(ws2, gws, sd));
-        FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(1, pF).c(pF).act_bwd(s.act).problem(dx_in, p[11], W.dH, nullptr, L.Hpre).run(W.ws, gws, st));
-        fork.side_after_main();                                                                // dH ready
-        FF_TRY(Gemm(s.dt, s.ffi, s.D, Mq).a(1, pF).b(1, pD).c(pD).problem(W.dH, L.xn_f, g[10]).run(ws2, gws, sd));
-        FF_TRY(Gemm(s.dt, Mq, s.D, s.ffi).a(0, pF).b(1, pD).c(pD).problem(W.dH, p[10], W.dxn).run(W.ws, gws, st));
-        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), W.dxn, L.x_mid, nullptr, p[8], L.mean_f, L.rstd_f, W.dx_mid, dx_in, g[8], g[9],
-                             W.ws, gws, st));                                                  // W.dx_mid = d x_mid
+        FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(1, pF).c(pF).act_bwd(s.act).problem(T.dx_out, p[11], T.dH, nullptr, L.Hpre).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, Mq, s.D, s.ffi).a(0, pF).b(1, pD).c(pD).problem(T.dH, p[10], W.dxn).run(W.ws, gws, st));
+        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), W.dxn, L.x_mid, nullptr, p[8], L.mean_f, L.rstd_f, T.dx_mid, T.dx_out, g[8], g[9],
+                             W.ws, gws, st));                                                  // T.dx_mid = d x_mid
         // ---- attention backward (x_mid = x_in + Wo O) ----
-        fork.side_after_main();                                                                // dx_mid ready
-        FF_TRY(Gemm(s.dt, s.D, s.inner, Mq).a(1, pD).b(1, pI).c(pI).problem(W.dx_mid, L.O, g[7]).run(ws2, gws, sd));
-        FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, pD).b(1, pI).c(pI).problem(W.dx_mid, p[7], W.dO).run(W.ws, gws, st));
-        FF_TRY(attention_bwd(rs_attn_desc(s), L.Qs, L.K, L.V, nullptr, L.O, W.dO, L.lse, W.dQs, W.dK, W.dV, attn_ws,
+        FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, pD).b(1, pI).c(pI).problem(T.dx_mid, p[7], W.dO).run(W.ws, gws, st));
+        FF_TRY(attention_bwd(rs_attn_desc(s), L.Qs, L.K, L.V, nullptr, L.O, W.dO, L.lse, T.dQs, T.dK, T.dV, attn_ws,
                              (size_t)s.Bn * s.H * s.q * 4, st));
-        fork.side_after_main();                                                                // dQs, dK, dV ready
-        // d to_q, d to_k, d to_v
-        FF_TRY(Gemm(s.dt, s.inner, s.D, Mq).a(1, pI).b(1, kv_lat).c(pD).scale(s.scale).problem(W.dQs, kv_lat_base, g[4]).run(ws2, gws, sd));
-        FF_TRY(Gemm(s.dt, s.inner, s.D, Mkv).a(1, pI).b(1, pD).c(pD).problem(W.dK, L.kv_in, g[5]).problem(W.dV, L.kv_in, g[6]).run(ws2, gws, sd));
         // d kv_in = dK Wk + dV Wv
-        FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(W.dK, p[5], W.dkv).run(W.ws, gws, st));
-        FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(W.dV, p[6], W.dkv, nullptr, nullptr, W.dkv).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(T.dK, p[5], W.dkv).run(W.ws, gws, st));
+        FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(T.dV, p[6], W.dkv, nullptr, nullptr, W.dkv).run(W.ws, gws, st));
         // d LN(latents) = scale * dQs Wq + d kv_in[latent rows]
         FF_TRY(Gemm(s.dt, Mq, s.D, s.inner).a(0, pI).b(1, pD).c(pD).res_map(kv_lat).scale(s.scale)
-                   .problem(W.dQs, p[4], W.dln, nullptr, nullptr, dkv_lat_base).run(W.ws, gws, st));
-        // norm_latents backward, accumulated onto the residual path: dx_out = d x_in
-        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, x_map, pD, pD), W.dln, x_in, nullptr, p[2], L.mean_l, L.rstd_l, dx_out, W.dx_mid, g[2], g[3],
+                   .problem(T.dQs, p[4], W.dln, nullptr, nullptr, dkv_lat_base).run(W.ws, gws, st));
+        // norm_latents backward, accumulated onto the residual path: d x_in
+        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, x_map, pD, pD), W.dln, x_in, nullptr, p[2], L.mean_l, L.rstd_l, dx_below, T.dx_mid, g[2], g[3],
                              W.ws, gws, st));
         {   // norm_media backward: d x_f accumulates over the layers (needed for d time_pos_emb even with CLIP frozen)
             LnArgs a = ln_args(s.dt, Mf, s.D, pD, kv_media, pD);
             a.add_rows_per_seg = s.F; a.add_div = s.v;
             FF_TRY(layernorm_bwd(a, W.dkv, x_f, tpe, p[0], S.mean_m, S.rstd_m, dxf, l == s.depth - 1 ? nullptr : dxf, g[0], g[1], W.ws, gws, st));
         }
-        fork.join();                                // this layer's weight gradients are done before its buffers are reused
-        std::swap(dx_in, dx_out);
     }
+    // ---- weight gradients, grouped over up to kGemmMaxZ layers per launch ----
+    for (int l0 = 0; l0 < s.depth; l0 += kGemmMaxZ) {
+        const int l1 = std::min(s.depth, l0 + kGemmMaxZ);
+        Gemm g3(s.dt, s.D, s.ffi, Mq), g1(s.dt, s.ffi, s.D, Mq), go(s.dt, s.D, s.inner, Mq), gq(s.dt, s.inner, s.D, Mq);
+        g3.a(1, pD).b(1, pF).c(pF);                       // d W3 = d x_out^T . act(H)
+        g1.a(1, pF).b(1, pD).c(pD);                       // d W1 = d H^T . LN(x_mid)
+        go.a(1, pD).b(1, pI).c(pI);                       // d Wo = d x_mid^T . O
+        gq.a(1, pI).b(1, kv_lat).c(pD).scale(s.scale);    // d Wq = scale * d Qs^T . LN(latents)   (the latent rows of kv_in)
+        for (int l = l0; l < l1; l++) {
+            void* const* g = G + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
+            const RsLayerSaved& L = S.L[l];
+            const RsLayerStash& T = W.L[l];
+            g3.problem(T.dx_out, L.Aact, g[11]);
+            g1.problem(T.dH, L.xn_f, g[10]);
+            go.problem(T.dx_mid, L.O, g[7]);
+            gq.problem(T.dQs, (const char*)L.kv_in + (size_t)s.F * s.D * s.es, g[4]);
+        }
+        FF_TRY(g3.run(W.ws, gws, st));
+        FF_TRY(g1.run(W.ws, gws, st));
+        FF_TRY(go.run(W.ws, gws, st));
+        FF_TRY(gq.run(W.ws, gws, st));
+    }
+    {   // d Wk, d Wv = d K^T / d V^T . kv_in: two problems per layer
+        Gemm gkv(s.dt, s.inner, s.D, Mkv);
+        gkv.a(1, pI).b(1, pD).c(pD);
+        for (int l = 0; l < s.depth; l++) {
+            void* const* g = G + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
+            gkv.problem(W.L[l].dK, S.L[l].kv_in, g[5]);
+            gkv.problem(W.L[l].dV, S.L[l].kv_in, g[6]);
+            if (gkv.P.nz == kGemmMaxZ || l == s.depth - 1) {
+                FF_TRY(gkv.run(W.ws, gws, st));
+                gkv.P.nz = 0;
+            }
+        }
+    }
+    void* dx_in = W.dx0;
     // d latents = sum over the batch of d x_0 (:179);  d time_pos_emb[t] = sum_{b, n} d x_f[b, t, n] (:166)
     FF_TRY(rows_reduce(s.dt, Mq, s.D, pD, s.q, 1, dx_in, G[0], W.ws, gws, st));
     if (s.nte > s.T) {
@@ -351,7 +320,9 @@ struct XaDims {
     int dt, b, L, d, dv, Nm, nv, Nk, H, dh, inner, ffi, act;
     size_t es;
     float scale;
+    bool ext_kv;     // keys / values come from outside the block (cached decode, ff_kv_project_fwd): no K/V region in `saved`
     explicit XaDims(const ff_xattn_desc& x) {
+        ext_kv = x.cached_k.sr != 0;
         dt = x.dtype; b = x.batch; L = x.n_tokens; d = x.dim; dv = x.dim_visual; Nm = x.n_media; nv = x.n_visual; Nk = Nm * nv;
         H = x.heads; dh = x.dim_head; inner = H * dh; ffi = x.ff_mult * d; act = x.act; es = dtype_size(dt);
         scale = 1.0f / sqrtf((float)dh);
@@ -365,7 +336,7 @@ struct XaSaved {
 static size_t xa_saved_layout(const XaDims& s, void* base, size_t cap, XaSaved& o) {
     Arena a(base, cap);
     const size_t M = (size_t)s.b * s.L;
-    o.KV = a.take((size_t)s.b * s.Nk * 2 * s.inner * s.es);   // first: its offset is part of the ABI (ff_xattn_kv_offset)
+    o.KV = s.ext_kv ? nullptr : a.take((size_t)s.b * s.Nk * 2 * s.inner * s.es);   // first: its offset is part of the ABI (ff_xattn_kv_offset)
     o.kv_offset = 0;
     o.mean_a = a.take<float>(M * 4);
     o.rstd_a = a.take<float>(M * 4);
@@ -384,9 +355,22 @@ static size_t xa_saved_layout(const XaDims& s, void* base, size_t cap, XaSaved& 
     return align_up(a.used);
 }
 struct XaScratch {
-    void *dy1, *dH, *dxn, *dO, *dQs, *dKV, *dyn, *ws, *ws2;
+    void *dy1, *dH, *dxn, *dO, *dQs, *dKV, *dyn, *ws;
     size_t ws_bytes;
 };
+// What the four weight-gradient GEMMs of a block read besides `saved` and d y_out: kept in a caller-owned `stash` when they are
+// deferred (ff_xattn_block_bwd_kv_data -> ff_xattn_wgrad_grouped), in `scratch` otherwise.
+struct XaStash {
+    void *dy1, *dH, *dQs;
+};
+static size_t xa_stash_layout(const XaDims& s, void* base, size_t cap, XaStash& o) {
+    Arena a(base, cap);
+    const size_t M = (size_t)s.b * s.L;
+    o.dy1 = a.take(M * s.d * s.es);
+    o.dH = a.take(M * s.ffi * s.es);
+    o.dQs = a.take(M * s.inner * s.es);
+    return align_up(a.used);
+}
 static size_t xa_ws_bytes(const XaDims& s) {
     const int M = s.b * s.L, Mk = s.b * s.Nk;
     size_t w = 0;
@@ -402,15 +386,13 @@ static size_t xa_scratch_layout(const XaDims& s, void* base, size_t cap, bool bw
     const size_t M = (size_t)s.b * s.L;
     o.ws_bytes = xa_ws_bytes(s);
     o.ws = a.take(o.ws_bytes);
-    o.ws2 = nullptr;
     if (bwd) {
-        o.ws2 = a.take(o.ws_bytes);                 // workspace of the side stream
         o.dy1 = a.take(M * s.d * s.es);
         o.dH = a.take(M * s.ffi * s.es);
         o.dxn = a.take(M * s.d * s.es);
         o.dO = a.take(M * s.inner * s.es);
         o.dQs = a.take(M * s.inner * s.es);
-        o.dKV = a.take((size_t)s.b * s.Nk * 2 * s.inner * s.es);
+        o.dKV = s.ext_kv ? nullptr : a.take((size_t)s.b * s.Nk * 2 * s.inner * s.es);
         o.dyn = a.take(M * s.d * s.es);
     }
     return align_up(a.used);
@@ -443,6 +425,7 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     const bool cached = ck != nullptr;
     FF_CHECK(y && tt && P && y_out && saved && scratch && (cached ? cv != nullptr : vf != nullptr), FF_ERR_SHAPE, "xattn_fwd: null argument");
     const XaDims s(*d);
+    FF_CHECK(s.ext_kv == cached, FF_ERR_SHAPE, "xattn_fwd: external K / V need their strides in the descriptor (cached_k / cached_v) and vice versa");
     XaSaved S;
     XaScratch W;
     FF_CHECK(xa_saved_layout(s, saved, saved_bytes, S) <= saved_bytes, FF_ERR_WORKSPACE, "xattn_fwd: saved buffer too small");
@@ -472,58 +455,101 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
 // ext_k / ext_v != null: the keys / values were projected outside the block (ff_kv_project_fwd, strides d->cached_k / cached_v);
 // the block then hands d K / d V to `dkv_out` (same (b, n_kv, 2, heads, dim_head) layout as the projection's output) instead of
 // computing d to_kv.weight and d visual_features itself.
+// stash != null: the four weight-gradient GEMMs (d ffw.3, d ffw.1, d to_out, d to_q) are NOT run; their operands d y1, d H, d Qs are
+// left in `stash` for xattn_wgrad_grouped.  The LayerNorm / gate gradients (G[0..3], G[7], G[8]) are always produced here.
 static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, const int* tt, const void* const* P, const void* dy2,
                      const void* saved, size_t saved_bytes, void* const* G, void* dy, void* dvf, void* scratch, size_t scratch_bytes,
-                     hipStream_t st, const void* ext_k = nullptr, const void* ext_v = nullptr, void* dkv_out = nullptr) {
+                     hipStream_t st, const void* ext_k = nullptr, const void* ext_v = nullptr, void* dkv_out = nullptr,
+                     void* stash = nullptr, size_t stash_bytes = 0) {
     FF_TRY(xa_check(d));
     const bool hoisted = ext_k != nullptr;
     FF_CHECK(y && tt && P && dy2 && saved && G && dy && scratch && (hoisted ? (ext_v && dkv_out) : vf != nullptr), FF_ERR_SHAPE,
              "xattn_bwd: null argument");
     const XaDims s(*d);
+    FF_CHECK(s.ext_kv == hoisted, FF_ERR_SHAPE, "xattn_bwd: external K / V need their strides in the descriptor (cached_k / cached_v) and vice versa");
     XaSaved S;
     XaScratch W;
     FF_CHECK(xa_saved_layout(s, (void*)saved, saved_bytes, S) <= saved_bytes, FF_ERR_WORKSPACE, "xattn_bwd: saved buffer too small");
     FF_CHECK(xa_scratch_layout(s, scratch, scratch_bytes, true, W) <= scratch_bytes, FF_ERR_WORKSPACE, "xattn_bwd: scratch too small");
+    XaStash T{W.dy1, W.dH, W.dQs};
+    const bool defer = stash != nullptr;
+    if (defer) FF_CHECK(xa_stash_layout(s, stash, stash_bytes, T) <= stash_bytes, FF_ERR_WORKSPACE, "xattn_bwd: stash too small");
     const int M = s.b * s.L, Mk = s.b * s.Nk;
     const RowMap pd = plain_rows(s.d), pI = plain_rows(s.inner), pF = plain_rows(s.ffi), pV = plain_rows(s.dv), pKV = plain_rows(2 * s.inner);
     const size_t attn_ws_bytes = align_up((size_t)s.b * s.H * s.L * 4);
     const size_t gws = W.ws_bytes - attn_ws_bytes;
     float* attn_ws = (float*)((char*)W.ws + gws);
 
-    // Weight gradients / gate gradients go to the side stream (`sd`, workspace ws2); the data-gradient chain stays on `st`.
-    Fork fork(st);
-    hipStream_t sd = fork.side();
-    void* ws2 = fork.active() ? W.ws2 : W.ws;
     // ---- y2 = y1 + tanh(alpha_ffw) * ffw(y1) ----
-    FF_TRY(Gemm(s.dt, s.d, s.ffi, M).a(1, pd).b(1, pF).c(pF).problem(dy2, S.Aact, G[10], nullptr, nullptr, nullptr, P[1]).run(ws2, gws, sd));
-    FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(1, pF).c(pF).act_bwd(s.act).problem(dy2, P[10], W.dH, nullptr, S.Hpre, nullptr, P[1]).run(W.ws, gws, st));
-    fork.side_after_main();                                                                    // dH ready
-    FF_TRY(Gemm(s.dt, s.ffi, s.d, M).a(1, pF).b(1, pd).c(pd).problem(W.dH, S.xn_f, G[9]).run(ws2, gws, sd));
-    FF_TRY(Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(1, pd).c(pd).problem(W.dH, P[9], W.dxn).run(W.ws, gws, st));
+    if (!defer) FF_TRY(Gemm(s.dt, s.d, s.ffi, M).a(1, pd).b(1, pF).c(pF).problem(dy2, S.Aact, G[10], nullptr, nullptr, nullptr, P[1]).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(1, pF).c(pF).act_bwd(s.act).problem(dy2, P[10], T.dH, nullptr, S.Hpre, nullptr, P[1]).run(W.ws, gws, st));
+    if (!defer) FF_TRY(Gemm(s.dt, s.ffi, s.d, M).a(1, pF).b(1, pd).c(pd).problem(T.dH, S.xn_f, G[9]).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(1, pd).c(pd).problem(T.dH, P[9], W.dxn).run(W.ws, gws, st));
     {   // LN(y1) backward -> dy1, with both gate gradients folded in: d alpha_ffw = sum(dy2 . ffw_out), d alpha_attn = sum(dy1 . attn_out)
         LnDots dots;
         dots.a = S.ffw_out; dots.alpha_a = P[1]; dots.out_a = G[1];
         dots.b = S.attn_out; dots.alpha_b = P[0]; dots.out_b = G[0];
-        FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, W.dy1, dy2, G[7], G[8], W.ws, gws, st, &dots));
+        FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, T.dy1, dy2, G[7], G[8], W.ws, gws, st, &dots));
     }
     // ---- y1 = y + tanh(alpha_attn) * to_out(attention) ----
-    fork.side_after_main();                                                                    // dy1 ready
-    FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(W.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(ws2, gws, sd));
-    FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(W.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
+    if (!defer) FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(T.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(T.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
     char* dK = hoisted ? (char*)dkv_out : (char*)W.dKV;
     char* dV = dK + (size_t)s.inner * s.es;
     const void* Kp = hoisted ? ext_k : S.KV;
     const void* Vp = hoisted ? ext_v : (const void*)((const char*)S.KV + (size_t)s.inner * s.es);
-    FF_TRY(attention_bwd(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, S.O, W.dO, S.lse, W.dQs, dK, dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
-    fork.side_after_main();                                                                    // dQs, dKV ready
-    FF_TRY(Gemm(s.dt, s.inner, s.d, M).a(1, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, S.yn, G[4]).run(ws2, gws, sd));
+    FF_TRY(attention_bwd(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, S.O, W.dO, S.lse, T.dQs, dK, dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
+    if (!defer) FF_TRY(Gemm(s.dt, s.inner, s.d, M).a(1, pI).b(1, pd).c(pd).scale(s.scale).problem(T.dQs, S.yn, G[4]).run(W.ws, gws, st));
     if (!hoisted) {
-        FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(ws2, gws, sd));
-        if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(ws2, gws, sd));
+        FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(W.ws, gws, st));
+        if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(W.ws, gws, st));
     }
-    FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(W.dQs, P[4], W.dyn).run(W.ws, gws, st));
-    return layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, W.dy1, G[2], G[3], W.ws, gws, st);
-    // ~Fork joins the side stream into `st`
+    FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(T.dQs, P[4], W.dyn).run(W.ws, gws, st));
+    return layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, T.dy1, G[2], G[3], W.ws, gws, st);
+}
+
+// Weight gradients of n <= kGemmMaxZ same-shaped blocks whose data-gradient pass ran with a stash: four grouped launches
+// (d ffw.3.weight, d ffw.1.weight, d attn.to_out.weight, d attn.to_q.weight), each covering all n blocks.
+static size_t xa_wgrad_ws_bytes(const XaDims& s) {
+    const int M = s.b * s.L;
+    size_t w = 0;
+    for (int nz = 1; nz <= kGemmMaxZ; nz++)
+        w = std::max({w, gemm_workspace_bytes(s.dt, s.d, s.ffi, M, nz, 0), gemm_workspace_bytes(s.dt, s.ffi, s.d, M, nz, 0),
+                      gemm_workspace_bytes(s.dt, s.d, s.inner, M, nz, 0), gemm_workspace_bytes(s.dt, s.inner, s.d, M, nz, 0)});
+    return align_up(w);
+}
+static int xattn_wgrad_grouped(const ff_xattn_desc* d, int n, const void* const* dy2, const void* const* saved, size_t saved_bytes,
+                               const void* const* stash, size_t stash_bytes, const void* const* params, void* const* grads, void* ws,
+                               size_t ws_bytes, hipStream_t st) {
+    FF_TRY(xa_check(d));
+    FF_CHECK(n >= 1 && n <= kGemmMaxZ && dy2 && saved && stash && params && grads, FF_ERR_SHAPE, "xattn_wgrad_grouped: 1..%d blocks per call", kGemmMaxZ);
+    const XaDims s(*d);
+    FF_CHECK(ws_bytes >= xa_wgrad_ws_bytes(s) && (ws || !xa_wgrad_ws_bytes(s)), FF_ERR_WORKSPACE, "xattn_wgrad_grouped: workspace too small");
+    const int M = s.b * s.L;
+    const RowMap pd = plain_rows(s.d), pI = plain_rows(s.inner), pF = plain_rows(s.ffi);
+    Gemm g3(s.dt, s.d, s.ffi, M), g1(s.dt, s.ffi, s.d, M), go(s.dt, s.d, s.inner, M), gq(s.dt, s.inner, s.d, M);
+    g3.a(1, pd).b(1, pF).c(pF);                     // d ffw.3 = tanh(alpha_ffw) * d y2^T . act(H)
+    g1.a(1, pF).b(1, pd).c(pd);                     // d ffw.1 = d H^T . LN(y1)
+    go.a(1, pd).b(1, pI).c(pI);                     // d to_out = tanh(alpha_attn) * d y1^T . O
+    gq.a(1, pI).b(1, pd).c(pd).scale(s.scale);      // d to_q = scale * d Qs^T . LN(y)
+    for (int i = 0; i < n; i++) {
+        XaSaved S;
+        XaStash T;
+        FF_CHECK(dy2[i] && saved[i] && stash[i], FF_ERR_SHAPE, "xattn_wgrad_grouped: null buffer of block %d", i);
+        FF_CHECK(xa_saved_layout(s, (void*)saved[i], saved_bytes, S) <= saved_bytes, FF_ERR_WORKSPACE, "xattn_wgrad_grouped: saved buffer too small");
+        FF_CHECK(xa_stash_layout(s, (void*)stash[i], stash_bytes, T) <= stash_bytes, FF_ERR_WORKSPACE, "xattn_wgrad_grouped: stash too small");
+        const void* const* P = params + (size_t)i * FF_XATTN_PARAMS;
+        void* const* G = grads + (size_t)i * FF_XATTN_PARAMS;
+        FF_CHECK(G[10] && G[9] && G[6] && G[4] && P[0] && P[1], FF_ERR_SHAPE, "xattn_wgrad_grouped: null parameter / gradient of block %d", i);
+        g3.problem(dy2[i], S.Aact, G[10], nullptr, nullptr, nullptr, P[1]);
+        g1.problem(T.dH, S.xn_f, G[9]);
+        go.problem(T.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]);
+        gq.problem(T.dQs, S.yn, G[4]);
+    }
+    FF_TRY(g3.run(ws, ws_bytes, st));
+    FF_TRY(g1.run(ws, ws_bytes, st));
+    FF_TRY(go.run(ws, ws_bytes, st));
+    return gq.run(ws, ws_bytes, st);
 }
 
 // =====================================================================================================
@@ -600,7 +626,7 @@ static int kv_project_bwd(const ff_kvproj_desc* d, const void* vf, const void* c
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
-extern "C" int ff_version(void) { return 1; }
+extern "C" int ff_version(void) { return 2; }
 extern "C" const char* ff_arch(void) { return "gfx950"; }
 extern "C" const char* ff_last_error(void) { return ff::g_err; }
 
@@ -658,6 +684,30 @@ extern "C" int ff_xattn_block_bwd_kv(const ff_xattn_desc* d, const void* y, cons
     FF_CHECK(k && v && dkv, FF_ERR_SHAPE, "ff_xattn_block_bwd_kv: null K / V / dKV");
     return xattn_bwd(d, y, nullptr, text_time, params, dy_out, saved, saved_bytes, grads, dy, nullptr, scratch, scratch_bytes,
                      (hipStream_t)stream, k, v, dkv);
+}
+extern "C" size_t ff_xattn_wgrad_stash_bytes(const ff_xattn_desc* d) {
+    if (ff::xa_check(d) != FF_OK) return 0;
+    ff::XaStash T;
+    return ff::xa_stash_layout(ff::XaDims(*d), nullptr, 0, T);
+}
+extern "C" size_t ff_xattn_wgrad_workspace_bytes(const ff_xattn_desc* d) {
+    if (ff::xa_check(d) != FF_OK) return 0;
+    return ff::xa_wgrad_ws_bytes(ff::XaDims(*d));
+}
+extern "C" int ff_xattn_block_bwd_kv_data(const ff_xattn_desc* d, const void* y, const void* k, const void* v, const int* text_time,
+                                          const void* const* params, const void* dy_out, const void* saved, size_t saved_bytes,
+                                          void* const* grads, void* dy, void* dkv, void* stash, size_t stash_bytes, void* scratch,
+                                          size_t scratch_bytes, ff_stream_t stream) {
+    using namespace ff;
+    FF_CHECK(k && v && dkv && stash, FF_ERR_SHAPE, "ff_xattn_block_bwd_kv_data: null K / V / dKV / stash");
+    return xattn_bwd(d, y, nullptr, text_time, params, dy_out, saved, saved_bytes, grads, dy, nullptr, scratch, scratch_bytes,
+                     (hipStream_t)stream, k, v, dkv, stash, stash_bytes);
+}
+extern "C" int ff_xattn_wgrad_grouped(const ff_xattn_desc* d, int n_blocks, const void* const* dy_out, const void* const* saved,
+                                      size_t saved_bytes, const void* const* stash, size_t stash_bytes, const void* const* params,
+                                      void* const* grads, void* workspace, size_t workspace_bytes, ff_stream_t stream) {
+    return ff::xattn_wgrad_grouped(d, n_blocks, dy_out, saved, saved_bytes, stash, stash_bytes, params, grads, workspace, workspace_bytes,
+                                   (hipStream_t)stream);
 }
 extern "C" size_t ff_kv_project_workspace_bytes(const ff_kvproj_desc* d, int with_dvf) {
     if (ff::kvp_check(d) != FF_OK) return 0;

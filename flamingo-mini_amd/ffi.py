@@ -13,7 +13,7 @@ import torch
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FF_OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -21,6 +21,7 @@ ACT_NONE, ACT_GELU, ACT_SQRELU, ACT_RELU = -1, 0, 1, 2
 ACTS = {"gelu": ACT_GELU, "sqrelu": ACT_SQRELU, "relu": ACT_RELU}
 ATTN_DENSE, ATTN_MEDIA = 0, 1
 RESAMPLER_GLOBAL_PARAMS, RESAMPLER_LAYER_PARAMS, XATTN_PARAMS = 4, 12, 11
+WGRAD_GROUP_MAX = 4
 
 
 class FusionLibraryError(RuntimeError):
@@ -128,6 +129,10 @@ _SIGNATURES = {
     "ff_kv_project_workspace_bytes": (_SZ, [C.POINTER(KvProjDesc), _I]),
     "ff_kv_project_fwd": (_I, [C.POINTER(KvProjDesc), _P, _P, _P, _P, _SZ, _P]),
     "ff_kv_project_bwd": (_I, [C.POINTER(KvProjDesc), _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ff_xattn_wgrad_stash_bytes": (_SZ, [C.POINTER(XattnDesc)]),
+    "ff_xattn_wgrad_workspace_bytes": (_SZ, [C.POINTER(XattnDesc)]),
+    "ff_xattn_block_bwd_kv_data": (_I, [C.POINTER(XattnDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
+    "ff_xattn_wgrad_grouped": (_I, [C.POINTER(XattnDesc), _I, _P, _P, _SZ, _P, _SZ, _P, _P, _P, _SZ, _P]),
     "ff_xattn_block_bwd": (_I, [C.POINTER(XattnDesc), _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

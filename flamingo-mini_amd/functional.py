@@ -25,6 +25,59 @@ def remove_grad_ready_callback(fn) -> None:
         _grad_ready_callbacks.remove(fn)
 
 
+class _WgradQueue:
+    """Deferred, grouped weight gradients of the cross-attention blocks (ff_xattn_block_bwd_kv_data / ff_xattn_wgrad_grouped).
+
+    A block's backward enqueues only its data-gradient chain and parks the operands of its four weight-gradient GEMMs in a `stash`;
+    whenever WGRAD_GROUP_MAX same-shaped blocks are waiting (and once more at the end of the backward pass, through the autograd
+    engine's queue_callback) their weight gradients are computed by grouped launches that fill the chip.  The gradient tensors were
+    already handed to autograd (views of the block's flat buffer): they are FILLED by the flush, which is enqueued on the same stream
+    before backward() returns, so everything that consumes .grad afterwards is ordered behind it.  Blocks whose parameters already
+    hold a .grad (gradient accumulation: autograd would ADD the returned tensor right away) do not defer.
+    FF_DEFER_WGRAD=0 disables the deferral."""
+
+    def __init__(self):
+        import os
+        self.enabled = os.environ.get("FF_DEFER_WGRAD", "1") == "1"
+        self.pending: list = []
+        self._callback_armed = False
+
+    def push(self, entry) -> None:
+        self.pending.append(entry)
+        if not self._callback_armed:
+            self._callback_armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+        same = [e for e in self.pending if e["key"] == entry["key"]]
+        if len(same) >= ffi.WGRAD_GROUP_MAX:
+            self._run(same)
+
+    def flush(self) -> None:
+        self._callback_armed = False
+        while self.pending:
+            key = self.pending[0]["key"]
+            self._run([e for e in self.pending if e["key"] == key][: ffi.WGRAD_GROUP_MAX])
+
+    def _run(self, group) -> None:
+        lib = ffi.lib()
+        ids = {id(e) for e in group}
+        self.pending = [e for e in self.pending if id(e) not in ids]
+        e0 = group[0]
+        desc, dev = e0["desc"], e0["device"]
+        ws = _empty_bytes(lib.ff_xattn_wgrad_workspace_bytes(desc), dev)
+        params = [p for e in group for p in e["params"]]
+        grads = [g for e in group for g in e["grads"]]
+        ffi.check(lib.ff_xattn_wgrad_grouped(desc, len(group), ffi.ptr_array([e["dout"] for e in group]), ffi.ptr_array([e["saved"] for e in group]),
+                                             e0["saved"].numel(), ffi.ptr_array([e["stash"] for e in group]), e0["stash"].numel(),
+                                             ffi.ptr_array(params), ffi.ptr_array(grads), ws.data_ptr(), ws.numel(), ffi.stream_handle(dev)),
+                  "ff_xattn_wgrad_grouped")
+        for e in group:
+            for cb in _grad_ready_callbacks:
+                cb(e["flat"])
+
+
+_wgrad_queue = _WgradQueue()
+
+
 def _flat_grads(params: Sequence[torch.Tensor]):
     """One contiguous buffer holding every parameter gradient of a fused module (each slice 16-byte aligned).  Autograd
     adopts the slices as `param.grad` without copying, so the buffer doubles as a ready-made all-reduce bucket."""
@@ -261,6 +314,16 @@ class _XattnBlockKvFn(torch.autograd.Function):
         grads = own_grads[:_KV_PARAM] + [None] + own_grads[_KV_PARAM:]
         dy, dkv = torch.empty_like(y), torch.empty_like(kv)
         scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
+        if _wgrad_queue.enabled and all(p.grad is None for p in own):
+            # data gradients now; d ffw.3 / d ffw.1 / d to_out / d to_q later, grouped with the neighbouring layers' (see _WgradQueue)
+            stash = _empty_bytes(lib.ff_xattn_wgrad_stash_bytes(desc), dev)
+            ffi.check(lib.ff_xattn_block_bwd_kv_data(desc, y.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * kv.element_size(), tt.data_ptr(),
+                                                     ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(), ffi.ptr_array(grads),
+                                                     dy.data_ptr(), dkv.data_ptr(), stash.data_ptr(), stash.numel(), scratch.data_ptr(),
+                                                     scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_bwd_kv_data")
+            key = (dev, y.dtype, tuple(y.shape), kv.shape[1], ctx.n_visual, tuple(ctx.cfg), params[_KV_PARAM].shape[1])
+            _wgrad_queue.push(dict(key=key, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, grads=grads, flat=flat))
+            return (dy, dkv, None, None, None, *grads)
         ffi.check(lib.ff_xattn_block_bwd_kv(desc, y.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * kv.element_size(), tt.data_ptr(),
                                             ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(), ffi.ptr_array(grads),
                                             dy.data_ptr(), dkv.data_ptr(), scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)),

@@ -204,6 +204,8 @@ int ff_resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void* co
  * Cached decode (previous_kv): pass cached_k/cached_v (+ strides) and visual_features = NULL; n_media is then
  * n_kv / n_visual and text_time rows are read at tt_offset (the last n_tokens entries, :102-104).
  * Uncached: K/V are produced in `saved` at ff_xattn_kv_offset() as (batch, n_media*n_visual, 2, heads, dim_head).
+ * Non-zero cached_k / cached_v strides in the descriptor <=> K / V come from outside (cached decode or ff_kv_project_fwd); `saved`
+ * then holds no K/V region (size queries and calls must use the same descriptor).
  * ------------------------------------------------------------------------------------------------------ */
 #define FF_XATTN_PARAMS 11
 typedef struct ff_xattn_desc {
@@ -251,6 +253,25 @@ int ff_kv_project_bwd(const ff_kvproj_desc* d, const void* visual_features, cons
 int ff_xattn_block_bwd_kv(const ff_xattn_desc* d, const void* y, const void* k, const void* v, const int* text_time,
                           const void* const* params, const void* dy_out, const void* saved, size_t saved_bytes, void* const* grads,
                           void* dy, void* dkv, void* scratch, size_t scratch_bytes, ff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Deferred, grouped weight gradients.  The four weight-gradient GEMMs of a block (d ffw.3.weight, d ffw.1.weight,
+ * d attn.to_out.weight, d attn.to_q.weight = 1/3 of its FLOPs) are not on the critical path of backward and a single one
+ * fills a third of the chip.  ff_xattn_block_bwd_kv_data is ff_xattn_block_bwd_kv without them: it leaves their operands
+ * (d y1, d H, d Qs) in the caller-owned `stash`; ff_xattn_wgrad_grouped then computes them for up to FF_WGRAD_GROUP_MAX
+ * same-shaped blocks per call in four grouped launches.  grads[5] (to_kv) is never written; the LayerNorm / gate gradients
+ * (grads[0..3], [7], [8]) are written by the data pass.  `params` / `grads` of the grouped call: n_blocks * FF_XATTN_PARAMS
+ * pointers, block after block; dy_out / saved / stash: one pointer per block (the buffers of that block's data pass).
+ * ------------------------------------------------------------------------------------------------------ */
+#define FF_WGRAD_GROUP_MAX 4
+size_t ff_xattn_wgrad_stash_bytes(const ff_xattn_desc* d);
+size_t ff_xattn_wgrad_workspace_bytes(const ff_xattn_desc* d);
+int ff_xattn_block_bwd_kv_data(const ff_xattn_desc* d, const void* y, const void* k, const void* v, const int* text_time,
+                               const void* const* params, const void* dy_out, const void* saved, size_t saved_bytes, void* const* grads,
+                               void* dy, void* dkv, void* stash, size_t stash_bytes, void* scratch, size_t scratch_bytes, ff_stream_t stream);
+int ff_xattn_wgrad_grouped(const ff_xattn_desc* d, int n_blocks, const void* const* dy_out, const void* const* saved, size_t saved_bytes,
+                           const void* const* stash, size_t stash_bytes, const void* const* params, void* const* grads, void* workspace,
+                           size_t workspace_bytes, ff_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW over the trainable parameters (the reference trains with `--optim adamw_torch`,

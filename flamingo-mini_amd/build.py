@@ -17,7 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion.so")
 SOURCES = ["ff_api.hip", "ff_gemm.hip", "ff_rowwise.hip", "ff_attention.hip", "ff_optim.hip", "ff_loss.hip", "ff_elementwise.hip"]
-HEADERS = ["ff_common.h", "ff_internal.h", os.path.join("..", "..", "include", "flamingo_fusion.h")]
+HEADERS = ["ff_common.h", "ff_internal.h", "ff_gemm_tiles.h", "ff_attention_core.h", os.path.join("..", "..", "include", "flamingo_fusion.h")]
 ARCH = "gfx950"
 # kernarg preload: leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+); kernels fall back to loads on old firmware
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + os.environ.get("FF_EXTRA_FLAGS", "").split()

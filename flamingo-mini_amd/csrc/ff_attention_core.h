@@ -1,0 +1,172 @@
+// Device-side building blocks of the attention kernels (ff_attention.hip) and of the fused projection + attention kernels
+// (ff_xattn_fused.hip): own-row fragments, LDS tile staging, the two transposed MFMA products, per-row key ranges.
+#pragma once
+#include "ff_common.h"
+
+namespace ff {
+
+constexpr int kTile = 64;  // rows per workgroup / per LDS tile
+constexpr float kNegBig = -1.0e30f, kPosBig = 1.0e30f;
+
+template <typename T> struct AttnCfg;
+template <> struct AttnCfg<bf16> { static constexpr int pad = 8; };   // LDS row padding (elements)
+template <> struct AttnCfg<float> { static constexpr int pad = 4; };
+
+// ---- fragments of the 16 own rows of a wave (B-operand style: lane (c, g) holds row c) -------------
+template <typename T, int DH> struct OwnFrag;
+template <int DH> struct OwnFrag<bf16, DH> {
+    bf16x8 f[DH / 32];
+    FF_DEV void load(const bf16* row, int g) {  // row == nullptr -> zeros
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ks++) {
+            if (row) f[ks] = *(const bf16x8*)(row + ks * 32 + g * 8);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[ks][e] = (bf16)0.f;
+        }
+    }
+    FF_DEV float dot(const OwnFrag& o) const {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ks++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += (float)f[ks][e] * (float)o.f[ks][e];
+        return s;
+    }
+};
+template <int DH> struct OwnFrag<float, DH> {
+    f32x4 f[DH / 16];
+    FF_DEV void load(const float* row, int g) {
+#pragma unroll
+        for (int s = 0; s < DH / 16; s++) f[s] = row ? *(const f32x4*)(row + s * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    FF_DEV float dot(const OwnFrag& o) const {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < DH / 16; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) s += f[i][e] * o.f[i][e];
+        return s;
+    }
+};
+
+// ---- global -> LDS staging of a [64][DH] tile (zero filled past n_valid rows) ----------------------
+template <typename T, int DH>
+FF_DEV void stage_tile(T* lds, const T* base, long long row_stride, int row0, int n_rows) {
+    constexpr int LD = DH + AttnCfg<T>::pad;
+    constexpr int VN = Vec<T>::N, CH = DH / VN;
+    for (int idx = threadIdx.x; idx < kTile * CH; idx += 256) {
+        const int r = idx / CH, ch = idx - r * CH;
+        uint4 v = {0, 0, 0, 0};
+        if (row0 + r < n_rows) v = *(const uint4*)(base + (long long)(row0 + r) * row_stride + ch * VN);
+        *(uint4*)(lds + r * LD + ch * VN) = v;
+    }
+}
+
+// ---- Z[sub][r] (other row sub*16 + g*4 + r, own row c) += X_tile . own^T ---------------------------
+template <int DH> FF_DEV void mma_k(f32x4 (&z)[4], const bf16* tile, const OwnFrag<bf16, DH>& own) {
+    constexpr int LD = DH + AttnCfg<bf16>::pad;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ks++) {
+            const bf16x8 a = *(const bf16x8*)(tile + (sub * 16 + c) * LD + ks * 32 + g * 8);
+            z[sub] = mfma_bf16(a, own.f[ks], z[sub]);
+        }
+}
+template <int DH> FF_DEV void mma_k(f32x4 (&z)[4], const float* tile, const OwnFrag<float, DH>& own) {
+    constexpr int LD = DH + AttnCfg<float>::pad;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+        for (int s = 0; s < DH / 16; s++) {
+            const f32x4 a = *(const f32x4*)(tile + (sub * 16 + c) * LD + s * 16 + g * 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) z[sub] = mfma_f32(a[j], own.f[s][j], z[sub]);
+        }
+}
+
+// ---- Acc^T[dt][r] (d = dt*16 + g*4 + r, own row c) += Y_tile^T . Z' --------------------------------
+template <int DH> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const bf16* tile, const f32x4 (&z)[4]) {
+    constexpr int LD = DH + AttnCfg<bf16>::pad;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {  // k-step of 32 other rows = sub-tiles 2s, 2s+1
+        bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            b[e] = (bf16)z[2 * s][e];
+            b[4 + e] = (bf16)z[2 * s + 1][e];
+        }
+        const bf16* p = tile + ((2 * s) * 16 + g * 4 + (c >> 2)) * LD + (c & 3) * 4;
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; dt++) {
+            const bf16x8 a = cat4(lds_read_tr16(p + dt * 16), lds_read_tr16(p + 16 * LD + dt * 16));
+            acc[dt] = mfma_bf16(a, b, acc[dt]);
+        }
+    }
+}
+template <int DH> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const float* tile, const f32x4 (&z)[4]) {
+    constexpr int LD = DH + AttnCfg<float>::pad;
+    const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float* row = tile + (sub * 16 + g * 4 + r) * LD + c;
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; dt++) acc[dt] = mfma_f32(row[dt * 16], z[sub][r], acc[dt]);
+        }
+}
+
+// ---- which keys a query row may see ------------------------------------------------------------------
+struct RowRange {
+    int lo, hi;   // attended keys [lo, hi)
+    int softmax;  // 1: ordinary softmax row (gradient flows to the scores); 0: zero row or uniform row
+    int uniform;  // 1: fully masked row -> scores are all equal (gated_cross_attention.py:112-115)
+};
+FF_DEV RowRange row_range(const ff_attn_desc& d, const int* tt, int b, int q) {
+    RowRange r;
+    if (q >= d.n_q) { r.lo = r.hi = 0; r.softmax = 0; r.uniform = 0; return r; }
+    if (d.mode == FF_ATTN_DENSE) { r.lo = 0; r.hi = d.n_kv; r.softmax = 1; r.uniform = 0; return r; }
+    const int t = tt[(long long)b * d.tt_stride + d.tt_offset + q];
+    const int n_media = d.n_kv / d.n_visual;
+    if (t <= 0) { r.lo = r.hi = 0; r.softmax = 0; r.uniform = 0; }                              // :119-121 zeroed row
+    else if (t <= n_media) { r.lo = (t - 1) * d.n_visual; r.hi = t * d.n_visual; r.softmax = 1; r.uniform = 0; }  // :111
+    else { r.lo = 0; r.hi = d.n_kv; r.softmax = 0; r.uniform = 1; }                            // all masked -> uniform
+    return r;
+}
+
+template <typename T, int DH> FF_DEV void store_acc_row(T* row, const f32x4 (&acc)[DH / 16], float scale, int g) {
+    typedef __attribute__((ext_vector_type(4))) T vec4;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; dt++) {
+        vec4 v;
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = from_f32<T>(acc[dt][r] * scale);
+        *(vec4*)(row + dt * 16 + g * 4) = v;
+    }
+}
+
+FF_DEV float group_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16, 64)), fmaxf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
+FF_DEV float group_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+
+// block-wide [min lo, max hi) over the 64 own rows, to skip key tiles nobody attends to
+FF_DEV void block_range(int lo, int hi, int* sh, int& blo, int& bhi) {
+    if (hi <= lo) { lo = 0x7fffffff; hi = 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w] = lo; sh[4 + w] = hi; }
+    __syncthreads();
+    blo = min(min(sh[0], sh[1]), min(sh[2], sh[3]));
+    bhi = max(max(sh[4], sh[5]), max(sh[6], sh[7]));
+}
+
+
+}  // namespace ff

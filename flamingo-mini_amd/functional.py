@@ -34,12 +34,16 @@ class _WgradQueue:
     already handed to autograd (views of the block's flat buffer): they are FILLED by the flush, which is enqueued on the same stream
     before backward() returns, so everything that consumes .grad afterwards is ordered behind it.  Blocks whose parameters already
     hold a .grad (gradient accumulation: autograd would ADD the returned tensor right away) do not defer.
+    The queue keeps raw addresses, never the gradient tensors themselves: AccumulateGrad adopts an incoming gradient without a copy
+    only while nobody else references it (otherwise it clones - at that moment, i.e. before the flush has filled it).  The final
+    callback verifies that adoption really happened for every deferred gradient and repairs the ones autograd copied after all.
     FF_DEFER_WGRAD=0 disables the deferral."""
 
     def __init__(self):
         import os
         self.enabled = os.environ.get("FF_DEFER_WGRAD", "1") == "1"
         self.pending: list = []
+        self.done: list = []
         self._callback_armed = False
 
     def push(self, entry) -> None:
@@ -56,6 +60,14 @@ class _WgradQueue:
         while self.pending:
             key = self.pending[0]["key"]
             self._run([e for e in self.pending if e["key"] == key][: ffi.WGRAD_GROUP_MAX])
+        done, self.done = self.done, []
+        for e in done:      # every AccumulateGrad of this backward pass has run by now
+            for p, (off, n) in zip(e["wparams"], e["wslices"]):
+                filled = e["flat"][off:off + n].view(p.shape)
+                if p.grad is None:
+                    continue                                 # retain_graph / autograd.grad without accumulation: nothing to repair
+                if p.grad.data_ptr() != filled.data_ptr():   # autograd cloned the (then unfilled) tensor instead of adopting it
+                    p.grad.copy_(filled)
 
     def _run(self, group) -> None:
         lib = ffi.lib()
@@ -65,27 +77,37 @@ class _WgradQueue:
         desc, dev = e0["desc"], e0["device"]
         ws = _empty_bytes(lib.ff_xattn_wgrad_workspace_bytes(desc), dev)
         params = [p for e in group for p in e["params"]]
-        grads = [g for e in group for g in e["grads"]]
+        n = ffi.XATTN_PARAMS
+        grad_ptrs = (ffi.C.c_void_p * (n * len(group)))()
+        for i, e in enumerate(group):
+            for j in range(n):
+                grad_ptrs[i * n + j] = e["grad_ptrs"][j]
         ffi.check(lib.ff_xattn_wgrad_grouped(desc, len(group), ffi.ptr_array([e["dout"] for e in group]), ffi.ptr_array([e["saved"] for e in group]),
                                              e0["saved"].numel(), ffi.ptr_array([e["stash"] for e in group]), e0["stash"].numel(),
-                                             ffi.ptr_array(params), ffi.ptr_array(grads), ws.data_ptr(), ws.numel(), ffi.stream_handle(dev)),
+                                             ffi.ptr_array(params), grad_ptrs, ws.data_ptr(), ws.numel(), ffi.stream_handle(dev)),
                   "ff_xattn_wgrad_grouped")
         for e in group:
             for cb in _grad_ready_callbacks:
                 cb(e["flat"])
+        self.done.extend(group)
 
 
 _wgrad_queue = _WgradQueue()
 
 
-def _flat_grads(params: Sequence[torch.Tensor]):
-    """One contiguous buffer holding every parameter gradient of a fused module (each slice 16-byte aligned).  Autograd
-    adopts the slices as `param.grad` without copying, so the buffer doubles as a ready-made all-reduce bucket."""
+def _flat_offsets(params: Sequence[torch.Tensor]):
     align = 16 // params[0].element_size()
     offs, total = [], 0
     for p in params:
         offs.append(total)
         total += (p.numel() + align - 1) // align * align
+    return offs, total
+
+
+def _flat_grads(params: Sequence[torch.Tensor]):
+    """One contiguous buffer holding every parameter gradient of a fused module (each slice 16-byte aligned).  Autograd
+    adopts the slices as `param.grad` without copying, so the buffer doubles as a ready-made all-reduce bucket."""
+    offs, total = _flat_offsets(params)
     flat = torch.empty(total, dtype=params[0].dtype, device=params[0].device)   # alignment pads are never read
     return flat, [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
 
@@ -322,7 +344,13 @@ class _XattnBlockKvFn(torch.autograd.Function):
                                                      dy.data_ptr(), dkv.data_ptr(), stash.data_ptr(), stash.numel(), scratch.data_ptr(),
                                                      scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_bwd_kv_data")
             key = (dev, y.dtype, tuple(y.shape), kv.shape[1], ctx.n_visual, tuple(ctx.cfg), params[_KV_PARAM].shape[1])
-            _wgrad_queue.push(dict(key=key, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, grads=grads, flat=flat))
+            offs, _ = _flat_offsets(own)
+            deferred = (4, 6, 9, 10)                       # attn.to_q, attn.to_out, ffw.1, ffw.3 in the block's parameter order
+            own_index = {i: (i if i < _KV_PARAM else i - 1) for i in deferred}
+            _wgrad_queue.push(dict(key=key, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, flat=flat,
+                                   grad_ptrs=[None if g is None else g.data_ptr() for g in grads],
+                                   wparams=[params[i] for i in deferred],
+                                   wslices=[(offs[own_index[i]], params[i].numel()) for i in deferred]))
             return (dy, dkv, None, None, None, *grads)
         ffi.check(lib.ff_xattn_block_bwd_kv(desc, y.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * kv.element_size(), tt.data_ptr(),
                                             ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(), ffi.ptr_array(grads),

@@ -99,6 +99,16 @@ def gemm_profile_summary(lib, ffi, max_records):
     groups, shapes, attn = {}, {}, {}
     for i in range(n):
         r = recs[i]
+        if r.tile in (-4, -5):   # fused LayerNorm + projection + attention of a cross-attention block (forward / backward): every operand once
+            es = 2 if r.dtype == ffi.DTYPE_BF16 else 4
+            heads, dh = r.a_layout, r.split_k
+            batch, inner = r.nz // heads, heads * dh
+            rows_d, rows_i, kv_i, w_b = batch * r.M * r.K * es, batch * r.M * inner * es, batch * r.N * inner * es, inner * r.K * es
+            nbytes = {-4: 2 * rows_d + w_b + 2 * kv_i + 2 * rows_i,            # y, yn | Wq | K, V | Qs, O
+                      -5: rows_d + w_b + 3 * rows_i + 4 * kv_i}[r.tile]        # dy1 | Wo | Qs, O, dQ | K, V, dK, dV
+            a = attn.setdefault({-4: "xattn_fused_fwd", -5: "xattn_fused_bwd"}[r.tile], dict(ms=0.0, bytes=0.0, launches=0))
+            a["ms"] += r.ms; a["bytes"] += nbytes; a["launches"] += 1
+            continue
         if r.tile < 0:      # attention core: algorithmic HBM bytes = each of Q, K, V, O (and their gradients) touched once
             es = 2 if r.dtype == ffi.DTYPE_BF16 else 4
             q_b, kv_b = r.nz * r.M * r.K * es, r.nz * r.N * r.K * es

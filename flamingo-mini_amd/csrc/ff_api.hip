@@ -419,6 +419,22 @@ static ff_attn_desc xa_attn_desc(const ff_xattn_desc& x, const XaDims& s, bool c
     return a;
 }
 
+// FF_XATTN_FUSED=0 falls back to the separate LayerNorm / projection GEMM / attention launches (debugging, A/B timing)
+static bool xa_fused_enabled() {
+    static const int v = [] { const char* e = getenv("FF_XATTN_FUSED"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+static XaFusedArgs xa_fused_args(const ff_xattn_desc& x, const XaDims& s, bool ext_kv) {
+    XaFusedArgs a = {};
+    a.batch = s.b; a.heads = s.H; a.n_q = s.L; a.n_kv = s.Nk; a.n_visual = s.nv; a.tt_stride = x.tt_stride; a.tt_offset = x.tt_offset;
+    a.dim = s.d; a.inner = s.inner; a.scale = s.scale; a.eps = 1e-5f;
+    const ff_strides sk = {(long long)s.Nk * 2 * s.inner, 2LL * s.inner, s.dh};
+    a.k = ext_kv ? x.cached_k : sk;
+    a.v = ext_kv ? x.cached_v : sk;
+    a.dk = sk; a.dv = sk;
+    return a;
+}
+
 static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, const int* tt, const void* const* P, const void* ck,
                      const void* cv, void* y_out, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, hipStream_t st) {
     FF_TRY(xa_check(d));
@@ -432,9 +448,6 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     FF_CHECK(xa_scratch_layout(s, scratch, scratch_bytes, false, W) <= scratch_bytes, FF_ERR_WORKSPACE, "xattn_fwd: scratch too small");
     const int M = s.b * s.L, Mk = s.b * s.Nk;
     const RowMap pd = plain_rows(s.d), pI = plain_rows(s.inner), pF = plain_rows(s.ffi), pV = plain_rows(s.dv), pKV = plain_rows(2 * s.inner);
-    // y = norm(y); q = to_q(y) * scale (:74-78)
-    FF_TRY(layernorm_fwd(ln_args(s.dt, M, s.d, pd, pd, pd), y, nullptr, P[2], P[3], S.yn, S.mean_a, S.rstd_a, st));
-    FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(0, pd).c(pI).scale(s.scale).problem(S.yn, P[4], S.Qs).run(W.ws, W.ws_bytes, st));
     const void *Kp, *Vp;
     if (!cached) {  // k, v = to_kv(flatten(visual_features)).chunk(2) (:84-86): K = columns [0, inner), V = [inner, 2 inner)
         FF_TRY(Gemm(s.dt, Mk, 2 * s.inner, s.dv).a(0, pV).b(0, pV).c(pKV).problem(vf, P[5], S.KV).run(W.ws, W.ws_bytes, st));
@@ -443,7 +456,15 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     } else {
         Kp = ck; Vp = cv;
     }
-    FF_TRY(attention_fwd(xa_attn_desc(*d, s, cached), S.Qs, Kp, Vp, tt, S.O, S.lse, st));           // :95-123
+    if (xa_fused_enabled() && xa_fused_supported(s.dt, s.dh, s.d, s.inner)) {
+        // y = norm(y); q = to_q(y) * scale; masked softmax(q k^T) v (:74-78, :95-123) in ONE launch per block
+        FF_TRY(xa_qattn_fwd(xa_fused_args(*d, s, cached), s.dt, s.dh, y, P[2], P[3], P[4], Kp, Vp, tt, S.yn, S.Qs, S.O, S.mean_a, S.rstd_a, S.lse, st));
+    } else {
+        // y = norm(y); q = to_q(y) * scale (:74-78)
+        FF_TRY(layernorm_fwd(ln_args(s.dt, M, s.d, pd, pd, pd), y, nullptr, P[2], P[3], S.yn, S.mean_a, S.rstd_a, st));
+        FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(0, pd).c(pI).scale(s.scale).problem(S.yn, P[4], S.Qs).run(W.ws, W.ws_bytes, st));
+        FF_TRY(attention_fwd(xa_attn_desc(*d, s, cached), S.Qs, Kp, Vp, tt, S.O, S.lse, st));           // :95-123
+    }
     // y = y + tanh(alpha_attn) * to_out(o) (:126, :180)
     FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(0, pI).c(pd).problem(S.O, P[6], S.y1, S.attn_out, nullptr, y, P[0]).run(W.ws, W.ws_bytes, st));
     // y = y + tanh(alpha_ffw) * ffw(y) (:182)
@@ -493,12 +514,20 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     }
     // ---- y1 = y + tanh(alpha_attn) * to_out(attention) ----
     if (!defer) FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(T.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
-    FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(T.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
     char* dK = hoisted ? (char*)dkv_out : (char*)W.dKV;
     char* dV = dK + (size_t)s.inner * s.es;
     const void* Kp = hoisted ? ext_k : S.KV;
     const void* Vp = hoisted ? ext_v : (const void*)((const char*)S.KV + (size_t)s.inner * s.es);
-    FF_TRY(attention_bwd(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, S.O, W.dO, S.lse, T.dQs, dK, dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
+    if (xa_fused_enabled() && xa_fused_supported(s.dt, s.dh, s.d, s.inner)) {
+        // d o = tanh(alpha_attn) * d y1 . Wo and the attention backward in one launch (two when the queries of a sample span several tiles)
+        int single = 0;
+        FF_TRY(xa_dattn_bwd(xa_fused_args(*d, s, hoisted), s.dt, s.dh, T.dy1, P[6], P[0], S.Qs, Kp, Vp, tt, S.O, S.lse, W.dO, T.dQs, dK, dV, attn_ws,
+                            &single, st));
+        if (!single) FF_TRY(attention_bwd_dkv(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, W.dO, S.lse, attn_ws, dK, dV, st));
+    } else {
+        FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(T.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
+        FF_TRY(attention_bwd(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, S.O, W.dO, S.lse, T.dQs, dK, dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
+    }
     if (!defer) FF_TRY(Gemm(s.dt, s.inner, s.d, M).a(1, pI).b(1, pd).c(pd).scale(s.scale).problem(T.dQs, S.yn, G[4]).run(W.ws, gws, st));
     if (!hoisted) {
         FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(W.ws, gws, st));

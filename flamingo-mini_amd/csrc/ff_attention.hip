@@ -46,46 +46,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const ff_attn_desc d_in, 
 
     const T* Kb = K + b * d.k.sb + h * d.k.sh;
     const T* Vb = V + b * d.v.sb + h * d.v.sh;
-    for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
-        __syncthreads();
-        stage_tile<T, DH>(sK, Kb, d.k.sr, k0, d.n_kv);
-        stage_tile<T, DH>(sV, Vb, d.v.sr, k0, d.n_kv);
-        __syncthreads();
-        f32x4 z[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) z[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mma_k<DH>(z, sK, fq);
-        float tmax = kNegBig;
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = k0 + s * 16 + g * 4 + r;
-                const bool ok = key >= rr.lo && key < rr.hi;
-                const float v = rr.uniform ? 0.f : z[s][r];
-                z[s][r] = ok ? v : kNegBig;
-                tmax = fmaxf(tmax, z[s][r]);
-            }
-        tmax = group_max(tmax);
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = __expf(m - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float p = z[s][r] > 0.5f * kNegBig ? __expf(z[s][r] - m_new) : 0.f;
-                z[s][r] = p;
-                psum += p;
-            }
-        lsum = lsum * alpha + psum;
-        m = m_new;
-#pragma unroll
-        for (int dt = 0; dt < DH / 16; dt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[dt][r] *= alpha;
-        mma_t<DH>(acc, sV, z);
-    }
+    attn_fwd_loop<T, DH>(d, fq, rr, blo, bhi, Kb, Vb, sK, sV, acc, m, lsum);
     lsum = group_sum(lsum);
     if (q < d.n_q) {
         const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
@@ -131,27 +92,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const ff_attn_desc d_i
     for (int dt = 0; dt < DH / 16; dt++) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* Kb = K + b * d.k.sb + h * d.k.sh;
     const T* Vb = V + b * d.v.sb + h * d.v.sh;
-    for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
-        __syncthreads();
-        stage_tile<T, DH>(sK, Kb, d.k.sr, k0, d.n_kv);
-        stage_tile<T, DH>(sV, Vb, d.v.sr, k0, d.n_kv);
-        __syncthreads();
-        f32x4 z[4], dp[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        mma_k<DH>(z, sK, fq);     // S^T
-        mma_k<DH>(dp, sV, fdo);   // dP^T = V dO^T
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = k0 + s * 16 + g * 4 + r;
-                const bool ok = key >= rr.lo && key < rr.hi;
-                const float p = ok ? __expf(z[s][r] - L) : 0.f;
-                z[s][r] = p * (dp[s][r] - Dq);  // dS^T
-            }
-        mma_t<DH>(acc, sK, z);    // dQ^T += K^T dS^T
-    }
+    attn_dq_loop<T, DH>(d, fq, fdo, rr, L, Dq, blo, bhi, Kb, Vb, sK, sV, acc);
     if (qok) store_acc_row<T, DH>(dQ + b * d.dq.sb + (long long)q * d.dq.sr + h * d.dq.sh, acc, 1.f, g);
 }
 
@@ -200,25 +141,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const ff_attn_desc d_
             s_D[threadIdx.x] = q < d.n_q ? Dsum[sidx] : 0.f;
         }
         __syncthreads();
-        f32x4 z[4], dp[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        mma_k<DH>(z, sQ, fk);     // S[q][key]
-        mma_k<DH>(dp, sDO, fv);   // dP[q][key]
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int qi = s * 16 + g * 4 + r;
-                const bool ok = key >= s_lo[qi] && key < s_hi[qi];
-                const int flag = s_flag[qi];
-                const float sc = (flag & 2) ? 0.f : z[s][r];
-                const float p = ok ? __expf(sc - s_lse[qi]) : 0.f;
-                z[s][r] = p;                                                   // P
-                dp[s][r] = (flag & 1) ? p * (dp[s][r] - s_D[qi]) : 0.f;        // dS
-            }
-        mma_t<DH>(acc_v, sDO, z);   // dV^T += dO^T P
-        mma_t<DH>(acc_k, sQ, dp);   // dK^T += Q^T dS
+        attn_dkv_step<T, DH>(key, fk, fv, sQ, sDO, s_lo, s_hi, s_flag, s_lse, s_D, acc_k, acc_v);
     }
     if (kok) {
         store_acc_row<T, DH>(dK + b * d.dk.sb + (long long)key * d.dk.sr + h * d.dk.sh, acc_k, 1.f, g);
@@ -271,6 +194,17 @@ int attention_fwd(const ff_attn_desc& d, const void* Q, const void* K, const voi
 }
 
 size_t attention_bwd_workspace(const ff_attn_desc& d) { return (size_t)d.batch * d.heads * d.n_q * sizeof(float); }
+
+int attention_bwd_dkv(const ff_attn_desc& d, const void* Q, const void* K, const void* V, const int* tt, const void* dO, const float* lse,
+                      const float* Dsum, void* dK, void* dV, hipStream_t st) {
+    FF_TRY(check_desc(d, true));
+    FF_CHECK(Q && K && V && dO && lse && Dsum && dK && dV && (d.mode == FF_ATTN_DENSE || tt), FF_ERR_SHAPE, "attention_bwd_dkv: null argument");
+    const dim3 gk(cdiv(d.n_kv, kTile), d.heads, d.batch);
+    const int pid = profile_begin(d.dtype, -3, 0, 0, d.n_q, d.n_kv, d.dim_head, d.batch * d.heads, d.mode, st);
+    FF_ATTN_DISPATCH(d, attn_bwd_dkv_kernel<T, DH><<<gk, dim3(256), 0, st>>>(d, (const T*)Q, (const T*)K, (const T*)V, tt, (const T*)dO, lse, Dsum, (T*)dK, (T*)dV));
+    profile_end(pid, st);
+    return check_launch("attn_bwd_dkv");
+}
 
 int attention_bwd(const ff_attn_desc& d, const void* Q, const void* K, const void* V, const int* tt, const void* O, const void* dO,
                   const float* lse, void* dQ, void* dK, void* dV, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -169,4 +169,111 @@ FF_DEV void block_range(int lo, int hi, int* sh, int& blo, int& bhi) {
 }
 
 
+// =====================================================================================================
+// Loop bodies shared by the stand-alone attention kernels and the fused projection + attention kernels.
+// All of them use the workgroup's 4 waves: wave w owns "own" rows w*16 .. w*16+15 of a 64-row tile.
+// =====================================================================================================
+// forward: online softmax over the key tiles [blo, bhi) for the wave's 16 own queries (fragment fq, per-lane key range rr)
+template <typename T, int DH>
+FF_DEV void attn_fwd_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const RowRange& rr, int blo, int bhi, const T* Kb, const T* Vb,
+                          T* sK, T* sV, f32x4 (&acc)[DH / 16], float& m, float& lsum) {
+    const int g = (threadIdx.x & 63) >> 4;
+    for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
+        __syncthreads();
+        stage_tile<T, DH>(sK, Kb, d.k.sr, k0, d.n_kv);
+        stage_tile<T, DH>(sV, Vb, d.v.sr, k0, d.n_kv);
+        __syncthreads();
+        f32x4 z[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) z[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma_k<DH>(z, sK, fq);
+        float tmax = kNegBig;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = k0 + s * 16 + g * 4 + r;
+                const bool ok = key >= rr.lo && key < rr.hi;
+                const float v = rr.uniform ? 0.f : z[s][r];
+                z[s][r] = ok ? v : kNegBig;
+                tmax = fmaxf(tmax, z[s][r]);
+            }
+        tmax = group_max(tmax);
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = __expf(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float p = z[s][r] > 0.5f * kNegBig ? __expf(z[s][r] - m_new) : 0.f;
+                z[s][r] = p;
+                psum += p;
+            }
+        lsum = lsum * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; dt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[dt][r] *= alpha;
+        mma_t<DH>(acc, sV, z);
+    }
+}
+
+// backward, own rows = queries: dQ^T += K^T dS^T over the key tiles [blo, bhi); L = saved log-sum-exp, Dq = sum_d dO * O of the own row
+template <typename T, int DH>
+FF_DEV void attn_dq_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const OwnFrag<T, DH>& fdo, const RowRange& rr, float L, float Dq,
+                         int blo, int bhi, const T* Kb, const T* Vb, T* sK, T* sV, f32x4 (&acc)[DH / 16]) {
+    const int g = (threadIdx.x & 63) >> 4;
+    for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
+        __syncthreads();
+        stage_tile<T, DH>(sK, Kb, d.k.sr, k0, d.n_kv);
+        stage_tile<T, DH>(sV, Vb, d.v.sr, k0, d.n_kv);
+        __syncthreads();
+        f32x4 z[4], dp[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_k<DH>(z, sK, fq);     // S^T
+        mma_k<DH>(dp, sV, fdo);   // dP^T = V dO^T
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = k0 + s * 16 + g * 4 + r;
+                const bool ok = key >= rr.lo && key < rr.hi;
+                const float p = ok ? __expf(z[s][r] - L) : 0.f;
+                z[s][r] = p * (dp[s][r] - Dq);  // dS^T
+            }
+        mma_t<DH>(acc, sK, z);    // dQ^T += K^T dS^T
+    }
+}
+
+// backward, own rows = keys: one 64-query tile already staged in LDS (sQ, sDO) with its per-query key ranges / flags / statistics
+// (s_lo, s_hi, s_flag = softmax | uniform << 1, s_lse, s_D); accumulates dV^T += dO^T P and dK^T += Q^T dS for the wave's 16 own keys.
+template <typename T, int DH>
+FF_DEV void attn_dkv_step(int key, const OwnFrag<T, DH>& fk, const OwnFrag<T, DH>& fv, const T* sQ, const T* sDO, const int* s_lo,
+                          const int* s_hi, const int* s_flag, const float* s_lse, const float* s_D, f32x4 (&acc_k)[DH / 16],
+                          f32x4 (&acc_v)[DH / 16]) {
+    const int g = (threadIdx.x & 63) >> 4;
+    f32x4 z[4], dp[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    mma_k<DH>(z, sQ, fk);     // S[q][key]
+    mma_k<DH>(dp, sDO, fv);   // dP[q][key]
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int qi = s * 16 + g * 4 + r;
+            const bool ok = key >= s_lo[qi] && key < s_hi[qi];
+            const int flag = s_flag[qi];
+            const float sc = (flag & 2) ? 0.f : z[s][r];
+            const float p = ok ? __expf(sc - s_lse[qi]) : 0.f;
+            z[s][r] = p;                                                   // P
+            dp[s][r] = (flag & 1) ? p * (dp[s][r] - s_D[qi]) : 0.f;        // dS
+        }
+    mma_t<DH>(acc_v, sDO, z);   // dV^T += dO^T P
+    mma_t<DH>(acc_k, sQ, dp);   // dK^T += Q^T dS
+}
+
 }  // namespace ff

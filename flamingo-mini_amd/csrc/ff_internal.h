@@ -63,7 +63,8 @@ struct Gemm {
 };
 
 // launch timing hooks (ff_gemm_profile_*): tile < 0 marks the attention kernels (-1 fwd, -2 dQ, -3 dK/dV; M = n_q, N = n_kv,
-// K = dim_head, nz = batch * heads, split_k = mode)
+// K = dim_head, nz = batch * heads, split_k = mode) and the fused projection + attention kernels of the cross-attention block
+// (-4 forward, -5 backward; M = n_q, N = n_kv, K = model dim, nz = batch * heads, a_layout = heads, split_k = dim_head)
 int profile_begin(int dtype, int tile, int a_layout, int b_layout, int M, int N, int K, int nz, int split_k, hipStream_t st);
 void profile_end(int i, hipStream_t st);
 
@@ -103,6 +104,28 @@ int attention_fwd(const ff_attn_desc& d, const void* Q, const void* K, const voi
 int attention_bwd(const ff_attn_desc& d, const void* Q, const void* K, const void* V, const int* tt, const void* O,
                   const void* dO, const float* lse, void* dQ, void* dK, void* dV, void* ws, size_t ws_bytes,
                   hipStream_t st);
+
+// d K / d V only (own rows = keys), for callers that already hold d O and Dsum[b][h][q] = sum_d dO * O
+int attention_bwd_dkv(const ff_attn_desc& d, const void* Q, const void* K, const void* V, const int* tt, const void* dO, const float* lse,
+                      const float* Dsum, void* dK, void* dV, hipStream_t st);
+
+// ---- fused projection + attention kernels of the gated cross-attention block (ff_xattn_fused.hip) ----
+// Q / O / dQ / dO live as [batch * n_q][inner] rows (head h = columns h * dim_head ..); K / V / dK / dV through strides.
+struct XaFusedArgs {
+    int batch, heads, n_q, n_kv, n_visual, tt_stride, tt_offset;
+    int dim, inner;          // model width (the projection's contraction length), heads * dim_head
+    float scale, eps;
+    int reserved;
+    ff_strides k, v, dk, dv;
+};
+bool xa_fused_supported(int dtype, int dim_head, int dim, int inner);
+// LayerNorm(y) -> q = to_q * scale -> masked attention; writes Qs, O, lse, the LayerNorm statistics and (optionally) the normalised rows yn
+int xa_qattn_fwd(const XaFusedArgs& a, int dtype, int dim_head, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K,
+                 const void* V, const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st);
+// d O = tanh(*gate) * d y1 . Wo -> d Q (and d K / d V when *single_tile comes back 1; otherwise d O and Dsum are left for attention_bwd_dkv)
+int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1, const void* Wo, const void* gate, const void* Qs, const void* K,
+                 const void* V, const int* tt, const void* O, const float* lse, void* dO, void* dQ, void* dK, void* dV, float* Dsum,
+                 int* single_tile, hipStream_t st);
 
 // ---- bump allocator over a caller-provided buffer ----------------------------------------------
 struct Arena {

@@ -1,0 +1,469 @@
+// Fused cross-attention kernels of the gated xattn block (gated_cross_attention.py:74-126 and its autograd):
+//
+//   xa_qattn_fwd_kernel   one workgroup per (query tile, head, sample):
+//                         LayerNorm(y) -> q = to_q(.) * scale (head slice of the weight) -> masked softmax(q K^T) V -> O
+//                         i.e. what used to be a LayerNorm launch, a split-K GEMM (+ its reduce launch) and an attention launch.
+//                         LayerNorm is the GEMM's prologue: raw y tiles travel global -> LDS by DMA and are normalised in the
+//                         A fragments (statistics of the tile's rows are computed once by the workgroup itself).
+//   xa_dattn_bwd_kernel   the mirror image: d O = tanh(alpha) * d y1 . Wo (head slice) -> attention backward (d Q; and d K, d V too
+//                         when a sample's queries fit one tile, which is the training shape: 32 tokens) - instead of a GEMM
+//                         (+ split-K reduce) and two attention launches.
+//
+// bf16: operand tiles through the LDS-DMA ring of the GEMM family (ff_gemm_tiles.h), v_mfma_f32_16x16x32_bf16; each wave owns 16
+// rows of the tile for the projection AND the attention, so Q / d O reach the attention MFMAs through a 9 KiB LDS tile.
+// fp32 (verification precision): the projection reads its operands straight from global memory (v_mfma_f32_16x16x4_f32).
+#include "ff_common.h"
+#include "ff_internal.h"
+#include "ff_gemm_tiles.h"
+#include "ff_attention_core.h"
+
+namespace ff {
+
+namespace {
+
+template <typename T> struct IsBf16 { static constexpr bool value = false; };
+template <> struct IsBf16<bf16> { static constexpr bool value = true; };
+
+// bytes of the region that first holds the projection's operand ring and then the attention tiles
+template <typename T, int DH, int BM, int NS, int ATT_ROWS> constexpr size_t region0_bytes() {
+    constexpr size_t ring = IsBf16<T>::value ? (size_t)NS * (BM + DH) * kBK * sizeof(bf16) : 0;
+    constexpr size_t att = (size_t)ATT_ROWS * (DH + AttnCfg<T>::pad) * sizeof(T);
+    return ((ring > att ? ring : att) + 255) / 256 * 256;
+}
+
+FF_DEV ff_attn_desc attn_view(const XaFusedArgs& a, int dim_head) {
+    ff_attn_desc d = {};
+    d.batch = a.batch; d.heads = a.heads; d.dim_head = dim_head; d.n_q = a.n_q; d.n_kv = a.n_kv;
+    d.mode = FF_ATTN_MEDIA; d.n_visual = a.n_visual; d.tt_stride = a.tt_stride; d.tt_offset = a.tt_offset;
+    d.k = a.k; d.v = a.v; d.dk = a.dk; d.dv = a.dv;
+    return d;
+}
+
+// D[n][m] += B_tile[n][k] * A_tile[m][k] over k = [0, dim) for the wave's 16 rows m of the A tile and all DH columns n, operands
+// through the LDS-DMA ring.  `transform(fa, kk)` is applied to every A fragment (8 consecutive k starting at kk) - the LayerNorm
+// prologue of the forward kernel.  BL: layout of the B operand (0: stored [DH][dim], 1: stored [dim][ldb], columns n_base..).
+template <int DH, int BM, int NS, int BL, typename F>
+FF_DEV void project_bf16(bf16* ring, const bf16* Ab, long long lda, int row0, int row_lim, const bf16* Bb, long long ldb, int n_base, int n_lim,
+                         int dim, int w, int l, f32x4 (&acc)[DH / 16], F transform) {
+    constexpr int A_ELEMS = BM * kBK, B_ELEMS = DH * kBK, STAGE = A_ELEMS + B_ELEMS, NT = DH / 16;
+    constexpr int PER_TILE = BM / 32 + DH / 32;
+    static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
+    static_assert(NS >= 2 && NS <= 4, "ring depth");
+    const RowMap a_map{lda, 0, 0}, b_map{ldb, 0, 0};
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7fffffff, 0x00020000);
+    const int nk = (dim + kBK - 1) / kBK;
+    auto issue = [&](int tile) {
+        bf16* st = ring + (tile % NS) * STAGE;
+        const int k0 = tile * kBK;
+        dma_tile<BM, 0>(ra, st, a_map, row0, row_lim, k0, dim, w, l);
+        dma_tile<DH, BL>(rb, st + A_ELEMS, b_map, n_base, n_lim, k0, dim, w, l);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; s++)
+        if (s < nk) issue(s);
+    const bool active = w * 16 < BM;        // wave-uniform: a 32-row tile keeps two waves as DMA helpers only
+    for (int kt = 0; kt < nk; kt++) {
+        const int younger = min(nk - 1 - kt, NS - 2);
+        if (NS >= 4 && younger == 2) wait_vmcnt<2 * PER_TILE>();
+        else if (NS >= 3 && younger >= 1) wait_vmcnt<PER_TILE>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();       // tile kt is in LDS for everyone; stage (kt - 1) % NS is free
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        if (active) {
+            const bf16* sA = ring + (kt % NS) * STAGE;
+            const bf16* sB = sA + A_ELEMS;
+#pragma unroll
+            for (int ks = 0; ks < kBK / 32; ks++) {
+                bf16x8 fa = frag_read2<BM, 0>(sA, w * 16, ks);
+                transform(fa, kt * kBK + ks * 32 + ((l >> 4) << 3));
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[j] = mfma_bf16(frag_read2<DH, BL>(sB, j * 16, ks), fa, acc[j]);   // D[n][m]
+            }
+        }
+    }
+}
+
+// acc[j][r] = value (row m = w*16 + c, column j*16 + g*4 + r) -> tile[m][...] (LD = DH + pad)
+template <typename T, int DH> FF_DEV void park_rows(T* tile, const f32x4 (&acc)[DH / 16], float scale, int w, int c, int g) {
+    typedef __attribute__((ext_vector_type(4))) T vec4;
+    constexpr int LD = DH + AttnCfg<T>::pad;
+#pragma unroll
+    for (int j = 0; j < DH / 16; j++) {
+        vec4 v;
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = from_f32<T>(acc[j][r] * scale);
+        *(vec4*)(tile + (w * 16 + c) * LD + j * 16 + g * 4) = v;
+    }
+}
+
+// rows [0, n_rows) of an LDS tile -> global rows (16-byte row-contiguous pieces)
+template <typename T, int DH> FF_DEV void tile_to_global(const T* tile, T* dst, long long row_stride, int n_rows) {
+    constexpr int LD = DH + AttnCfg<T>::pad, VN = Vec<T>::N, CH = DH / VN;
+    for (int idx = threadIdx.x; idx < n_rows * CH; idx += 256) {
+        const int r = idx / CH, ch = idx - r * CH;
+        *(uint4*)(dst + (long long)r * row_stride + ch * VN) = *(const uint4*)(tile + r * LD + ch * VN);
+    }
+}
+
+}  // namespace
+
+// =====================================================================================================
+// forward: LayerNorm -> Q projection (one head) -> masked attention
+// =====================================================================================================
+template <typename T, int DH, int BM, int NS>
+__global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_in, const T* __restrict__ y, const T* __restrict__ gamma,
+                                                           const T* __restrict__ beta, const T* __restrict__ Wq, const T* __restrict__ K,
+                                                           const T* __restrict__ V, const int* __restrict__ tt, T* __restrict__ yn,
+                                                           T* __restrict__ Qs, T* __restrict__ O, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const XaFusedArgs a = fetch_args(a_in);
+    constexpr int LD = DH + AttnCfg<T>::pad, NT = DH / 16, VN = Vec<T>::N;
+    constexpr size_t R0 = region0_bytes<T, DH, BM, NS, BM + 2 * kTile>();
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int row0 = qt * BM;
+    const int n_rows = min(BM, a.n_q - row0);
+    const int dimp = (a.dim + kBK - 1) / kBK * kBK;
+    T* s_g = (T*)(smem + R0);
+    T* s_b = s_g + dimp;
+    float* s_mean = (float*)(s_b + dimp);
+    float* s_rstd = s_mean + BM;
+    int* sh = (int*)(s_rstd + BM);
+
+    // ---- LayerNorm statistics of the tile's rows (two passes, fp32, like torch), gamma / beta into LDS ----
+    for (int i = t; i < dimp; i += 256) {
+        s_g[i] = i < a.dim ? gamma[i] : from_f32<T>(0.f);
+        s_b[i] = i < a.dim ? beta[i] : from_f32<T>(0.f);
+    }
+    {
+        constexpr int TPR = 256 / BM;     // threads per row (adjacent lanes of one wave)
+        const int r = t / TPR, sub = t % TPR;
+        const bool rok = r < n_rows;
+        const long long grow = (long long)b * a.n_q + row0 + (rok ? r : 0);
+        const T* yr = y + grow * a.dim;
+        const int nchunk = a.dim / VN;
+        float s = 0.f;
+        if (rok)
+            for (int ch = sub; ch < nchunk; ch += TPR) {
+                float v[VN];
+                Vec<T>::load(yr + ch * VN, v);
+#pragma unroll
+                for (int e = 0; e < VN; e++) s += v[e];
+            }
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mu = s / (float)a.dim;
+        float q = 0.f;
+        if (rok)
+            for (int ch = sub; ch < nchunk; ch += TPR) {
+                float v[VN];
+                Vec<T>::load(yr + ch * VN, v);
+#pragma unroll
+                for (int e = 0; e < VN; e++) q += (v[e] - mu) * (v[e] - mu);
+            }
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = rsqrtf(q / (float)a.dim + a.eps);
+        if (sub == 0) {
+            s_mean[r] = rok ? mu : 0.f;
+            s_rstd[r] = rok ? rs : 0.f;
+            if (rok && h == 0) { mean[grow] = mu; rstd[grow] = rs; }
+        }
+        if (rok && h == 0 && yn) {        // the normalised rows themselves are an operand of d to_q.weight: written once per row tile
+            T* ynr = yn + grow * a.dim;
+            for (int ch = sub; ch < nchunk; ch += TPR) {
+                float v[VN], gv[VN], bv[VN];
+                Vec<T>::load(yr + ch * VN, v);
+                Vec<T>::load(gamma + ch * VN, gv);
+                Vec<T>::load(beta + ch * VN, bv);
+#pragma unroll
+                for (int e = 0; e < VN; e++) v[e] = (v[e] - mu) * rs * gv[e] + bv[e];
+                Vec<T>::store(ynr + ch * VN, v);
+            }
+        }
+    }
+    __syncthreads();      // statistics + gamma / beta visible; no plain load is outstanding when the DMA pipeline starts
+
+    // ---- q[m][n] = sum_k LN(y)[m][k] Wq[h*DH + n][k] ----
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m_own = w * 16 + c;                      // the lane's own row of the tile
+    const bool own_ok = m_own < n_rows;                // (false for the helper waves of a 32-row tile)
+    const float mu = m_own < BM ? s_mean[m_own] : 0.f, rs = m_own < BM ? s_rstd[m_own] : 0.f;
+    if constexpr (IsBf16<T>::value) {
+        auto ln = [&](bf16x8& fa, int kk) {
+            float gv[8], bv[8];
+            Vec<bf16>::load(s_g + kk, gv);
+            Vec<bf16>::load(s_b + kk, bv);
+#pragma unroll
+            for (int e = 0; e < 8; e++) fa[e] = (bf16)(((float)fa[e] - mu) * rs * gv[e] + bv[e]);
+        };
+        project_bf16<DH, BM, NS, 0>((bf16*)smem, y + (long long)b * a.n_q * a.dim, a.dim, row0, a.n_q, Wq + (long long)h * DH * a.dim, a.dim, 0,
+                                    DH, a.dim, w, l, acc, ln);
+    } else {
+        if (w * 16 < BM) {
+            const float* yr = y + ((long long)b * a.n_q + row0 + (own_ok ? m_own : 0)) * a.dim;
+            for (int k = 0; k < a.dim; k += 4) {
+                const int kk = k + g;
+                const bool kok = kk < a.dim;
+                const float av = own_ok && kok ? (yr[kk] - mu) * rs * s_g[kk] + s_b[kk] : 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const float bv = kok ? Wq[((long long)h * DH + j * 16 + c) * a.dim + kk] : 0.f;
+                    acc[j] = mfma_f32(bv, av, acc[j]);       // D[n][m]
+                }
+            }
+        }
+    }
+    __syncthreads();      // the operand ring is dead: its memory becomes the Q / K / V tiles of the attention
+    T* sQ = (T*)smem;
+    T* sK = sQ + BM * LD;
+    T* sV = sK + kTile * LD;
+    if (w * 16 < BM) park_rows<T, DH>(sQ, acc, a.scale, w, c, g);
+    __syncthreads();
+    tile_to_global<T, DH>(sQ, Qs + ((long long)b * a.n_q + row0) * a.inner + h * DH, a.inner, n_rows);   // saved for backward
+
+    // ---- O = softmax_masked(q K^T) V for the wave's 16 own queries ----
+    const ff_attn_desc d = attn_view(a, DH);
+    const int q = row0 + m_own;
+    RowRange rr = row_range(d, tt, b, q);
+    if (!own_ok) { rr.lo = rr.hi = 0; rr.softmax = 0; rr.uniform = 0; }
+    int blo, bhi;
+    block_range(rr.lo, rr.hi, sh, blo, bhi);
+    OwnFrag<T, DH> fq;
+    fq.load(own_ok ? sQ + m_own * LD : nullptr, g);
+    f32x4 o[NT];
+#pragma unroll
+    for (int dt = 0; dt < NT; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = kNegBig, lsum = 0.f;
+    attn_fwd_loop<T, DH>(d, fq, rr, blo, bhi, K + b * a.k.sb + h * a.k.sh, V + b * a.v.sb + h * a.v.sh, sK, sV, o, m, lsum);
+    lsum = group_sum(lsum);
+    if (own_ok) {
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        store_acc_row<T, DH>(O + ((long long)b * a.n_q + q) * a.inner + h * DH, o, inv, g);
+        if (g == 0) lse[((long long)b * a.heads + h) * a.n_q + q] = lsum > 0.f ? m + __logf(lsum) : kPosBig;
+    }
+}
+
+// =====================================================================================================
+// backward: d O projection (one head) -> attention backward
+// =====================================================================================================
+template <typename T, int DH, int BM, int NS, bool SINGLE>
+__global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_in, const T* __restrict__ dy1, const T* __restrict__ Wo,
+                                                           const T* __restrict__ gate, const T* __restrict__ Qs, const T* __restrict__ K,
+                                                           const T* __restrict__ V, const int* __restrict__ tt, const T* __restrict__ O,
+                                                           const float* __restrict__ lse, T* __restrict__ dO_out, T* __restrict__ dQ,
+                                                           T* __restrict__ dK, T* __restrict__ dV, float* __restrict__ Dsum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const XaFusedArgs a = fetch_args(a_in);
+    constexpr int LD = DH + AttnCfg<T>::pad, NT = DH / 16;
+    constexpr size_t R0 = region0_bytes<T, DH, BM, NS, 4 * kTile>();
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int row0 = qt * BM;
+    const int n_rows = min(BM, a.n_q - row0);
+    int* s_lo = (int*)(smem + R0);
+    int* s_hi = s_lo + kTile;
+    int* s_flag = s_hi + kTile;
+    float* s_lse = (float*)(s_flag + kTile);
+    float* s_D = s_lse + kTile;
+    int* sh = (int*)(s_D + kTile);
+
+    // ---- dO[m][n] = tanh(alpha) * sum_k dy1[m][k] Wo[k][h*DH + n] ----
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m_own = w * 16 + c;
+    const bool own_ok = m_own < n_rows;
+    if constexpr (IsBf16<T>::value) {
+        auto none = [](bf16x8&, int) {};
+        project_bf16<DH, BM, NS, 1>((bf16*)smem, dy1 + (long long)b * a.n_q * a.dim, a.dim, row0, a.n_q, Wo, a.inner, h * DH, (h + 1) * DH,
+                                    a.dim, w, l, acc, none);
+    } else {
+        if (w * 16 < BM) {
+            const float* dr = dy1 + ((long long)b * a.n_q + row0 + (own_ok ? m_own : 0)) * a.dim;
+            for (int k = 0; k < a.dim; k += 4) {
+                const int kk = k + g;
+                const bool kok = kk < a.dim;
+                const float av = own_ok && kok ? dr[kk] : 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const float bv = kok ? Wo[(long long)kk * a.inner + h * DH + j * 16 + c] : 0.f;
+                    acc[j] = mfma_f32(bv, av, acc[j]);
+                }
+            }
+        }
+    }
+    __syncthreads();      // operand ring dead -> dO / Q / K / V tiles
+    T* sDO = (T*)smem;
+    T* sQ = sDO + kTile * LD;
+    T* sK = sQ + kTile * LD;
+    T* sV = sK + kTile * LD;
+    const float gt = tanhf(to_f32(gate[0]));
+    if (w * 16 < BM) park_rows<T, DH>(sDO, acc, gt, w, c, g);
+    else {                // rows BM .. 63 of the 64-row dO tile do not exist: zero them (they are "other" rows of the dK / dV products)
+        typedef __attribute__((ext_vector_type(4))) T vec4;
+        vec4 z;
+#pragma unroll
+        for (int r = 0; r < 4; r++) z[r] = from_f32<T>(0.f);
+#pragma unroll
+        for (int j = 0; j < NT; j++) *(vec4*)(sDO + (w * 16 + c) * LD + j * 16 + g * 4) = z;
+    }
+    const T* Qb = Qs + (long long)b * a.n_q * a.inner + h * DH;
+    stage_tile<T, DH>(sQ, Qb, a.inner, row0, SINGLE ? a.n_q : min(a.n_q, row0 + BM));   // rows past the tile / the sample are zeros
+    __syncthreads();
+    if (!SINGLE && dO_out) tile_to_global<T, DH>(sDO, dO_out + ((long long)b * a.n_q + row0) * a.inner + h * DH, a.inner, n_rows);
+
+    // ---- own rows = queries: D = sum_d dO * O, dQ ----
+    const ff_attn_desc d = attn_view(a, DH);
+    const int q = row0 + m_own;
+    OwnFrag<T, DH> fq, fdo, fo;
+    fq.load(own_ok ? sQ + m_own * LD : nullptr, g);
+    fdo.load(own_ok ? sDO + m_own * LD : nullptr, g);
+    fo.load(own_ok ? O + ((long long)b * a.n_q + q) * a.inner + h * DH : nullptr, g);
+    const float Dq = group_sum(fdo.dot(fo));
+    const long long sidx = ((long long)b * a.heads + h) * a.n_q + q;
+    const float L = own_ok ? lse[sidx] : kPosBig;
+    if (own_ok && g == 0 && Dsum) Dsum[sidx] = Dq;
+    const RowRange rr_full = row_range(d, tt, b, q);
+    RowRange rr = rr_full;
+    if (!own_ok || !rr.softmax) rr.lo = rr.hi = 0;      // zero / uniform rows: no gradient reaches the scores
+    if (SINGLE && t < kTile) { s_lo[t] = 0; s_hi[t] = 0; s_flag[t] = 0; s_lse[t] = kPosBig; s_D[t] = 0.f; }
+    int blo, bhi;
+    block_range(rr.lo, rr.hi, sh, blo, bhi);            // (contains a __syncthreads: the defaults above are in place)
+    if (SINGLE && own_ok && g == 0) {
+        s_lo[m_own] = rr_full.lo; s_hi[m_own] = rr_full.hi; s_flag[m_own] = rr_full.softmax | (rr_full.uniform << 1);
+        s_lse[m_own] = L; s_D[m_own] = Dq;
+    }
+    f32x4 dq[NT];
+#pragma unroll
+    for (int dt = 0; dt < NT; dt++) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* Kb = K + b * a.k.sb + h * a.k.sh;
+    const T* Vb = V + b * a.v.sb + h * a.v.sh;
+    attn_dq_loop<T, DH>(d, fq, fdo, rr, L, Dq, blo, bhi, Kb, Vb, sK, sV, dq);
+    if (own_ok) store_acc_row<T, DH>(dQ + ((long long)b * a.n_q + q) * a.inner + h * DH, dq, 1.f, g);
+
+    // ---- own rows = keys (the sample's queries are all in this tile): dK, dV ----
+    if constexpr (SINGLE) {
+        __syncthreads();
+        for (int k0 = 0; k0 < a.n_kv; k0 += kTile) {
+            const int key = k0 + m_own;
+            const bool kok = key < a.n_kv;
+            OwnFrag<T, DH> fk, fv;
+            fk.load(kok ? Kb + (long long)key * a.k.sr : nullptr, g);
+            fv.load(kok ? Vb + (long long)key * a.v.sr : nullptr, g);
+            f32x4 acc_k[NT], acc_v[NT];
+#pragma unroll
+            for (int dt = 0; dt < NT; dt++) { acc_k[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_v[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            attn_dkv_step<T, DH>(key, fk, fv, sQ, sDO, s_lo, s_hi, s_flag, s_lse, s_D, acc_k, acc_v);
+            if (kok) {
+                store_acc_row<T, DH>(dK + b * a.dk.sb + (long long)key * a.dk.sr + h * a.dk.sh, acc_k, 1.f, g);
+                store_acc_row<T, DH>(dV + b * a.dv.sb + (long long)key * a.dv.sr + h * a.dv.sh, acc_v, 1.f, g);
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+constexpr int kFusedStages = 4;
+
+bool xa_fused_supported(int dtype, int dim_head, int dim, int inner) {
+    if (dtype == FF_DTYPE_BF16) return (dim_head == 64 || dim_head == 128) && dim % 8 == 0 && inner % 8 == 0;
+    if (dtype == FF_DTYPE_F32) return (dim_head == 16 || dim_head == 32 || dim_head == 64 || dim_head == 128) && dim % 4 == 0 && inner % 4 == 0;
+    return false;
+}
+
+template <typename T, int DH, int BM> static size_t fwd_lds(int dim) {
+    const int dimp = (dim + kBK - 1) / kBK * kBK;
+    return region0_bytes<T, DH, BM, kFusedStages, BM + 2 * kTile>() + (size_t)2 * dimp * sizeof(T) + (size_t)2 * BM * sizeof(float) + 8 * sizeof(int);
+}
+template <typename T, int DH, int BM> static size_t bwd_lds() {
+    return region0_bytes<T, DH, BM, kFusedStages, 4 * kTile>() + (size_t)5 * kTile * 4 + 8 * sizeof(int);
+}
+
+template <typename KernelT> static int allow_lds(KernelT kernel, size_t lds, const char* what) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(%s, lds=%zu): %s", what, lds, hipGetErrorString(e));
+    }
+    FF_CHECK(lds <= 160 * 1024, FF_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (dim too large for the fused kernel)", what, lds);
+    return FF_OK;
+}
+
+#define FF_XA_DISPATCH(dtype, dim_head, ...)                                                                         \
+    do {                                                                                                             \
+        if ((dtype) == FF_DTYPE_BF16) {                                                                              \
+            typedef bf16 T;                                                                                          \
+            if ((dim_head) == 64) { constexpr int DH = 64; __VA_ARGS__; }                                                   \
+            else { constexpr int DH = 128; __VA_ARGS__; }                                                                   \
+        } else {                                                                                                     \
+            typedef float T;                                                                                         \
+            if ((dim_head) == 64) { constexpr int DH = 64; __VA_ARGS__; }                                                   \
+            else if ((dim_head) == 16) { constexpr int DH = 16; __VA_ARGS__; }                                              \
+            else if ((dim_head) == 32) { constexpr int DH = 32; __VA_ARGS__; }                                              \
+            else { constexpr int DH = 128; __VA_ARGS__; }                                                                   \
+        }                                                                                                            \
+    } while (0)
+
+template <typename T, int DH, int BM>
+static int launch_fwd(const XaFusedArgs& a, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K, const void* V,
+                      const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st) {
+    const size_t lds = fwd_lds<T, DH, BM>(a.dim);
+    auto kernel = xa_qattn_fwd_kernel<T, DH, BM, kFusedStages>;
+    FF_TRY(allow_lds(kernel, lds, "xa_qattn_fwd"));
+    const dim3 grid(cdiv(a.n_q, BM), a.heads, a.batch);
+    kernel<<<grid, dim3(256), lds, st>>>(a, (const T*)y, (const T*)gamma, (const T*)beta, (const T*)Wq, (const T*)K, (const T*)V, tt, (T*)yn, (T*)Qs,
+                                         (T*)O, mean, rstd, lse);
+    return check_launch("xa_qattn_fwd");
+}
+
+int xa_qattn_fwd(const XaFusedArgs& a, int dtype, int dim_head, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K,
+                 const void* V, const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st) {
+    FF_CHECK(xa_fused_supported(dtype, dim_head, a.dim, a.inner), FF_ERR_UNSUPPORTED, "xa_qattn_fwd: unsupported dtype / head size");
+    FF_CHECK(y && gamma && beta && Wq && K && V && tt && Qs && O && mean && rstd && lse, FF_ERR_SHAPE, "xa_qattn_fwd: null argument");
+    const int pid = profile_begin(dtype, -4, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
+    int rc;
+    if (a.n_q <= 32) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_fwd<T, DH, 32>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st)));
+    else FF_XA_DISPATCH(dtype, dim_head, rc = (launch_fwd<T, DH, 64>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st)));
+    profile_end(pid, st);
+    return rc;
+}
+
+template <typename T, int DH, int BM, bool SINGLE>
+static int launch_bwd(const XaFusedArgs& a, const void* dy1, const void* Wo, const void* gate, const void* Qs, const void* K, const void* V,
+                      const int* tt, const void* O, const float* lse, void* dO, void* dQ, void* dK, void* dV, float* Dsum, hipStream_t st) {
+    const size_t lds = bwd_lds<T, DH, BM>();
+    auto kernel = xa_dattn_bwd_kernel<T, DH, BM, kFusedStages, SINGLE>;
+    FF_TRY(allow_lds(kernel, lds, "xa_dattn_bwd"));
+    const dim3 grid(cdiv(a.n_q, BM), a.heads, a.batch);
+    kernel<<<grid, dim3(256), lds, st>>>(a, (const T*)dy1, (const T*)Wo, (const T*)gate, (const T*)Qs, (const T*)K, (const T*)V, tt, (const T*)O, lse,
+                                         (T*)dO, (T*)dQ, (T*)dK, (T*)dV, Dsum);
+    return check_launch("xa_dattn_bwd");
+}
+
+// *single_tile = 1: d K / d V were produced too (every sample's queries fit one tile); 0: the caller runs the d K / d V kernel on dO / Dsum.
+int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1, const void* Wo, const void* gate, const void* Qs, const void* K,
+                 const void* V, const int* tt, const void* O, const float* lse, void* dO, void* dQ, void* dK, void* dV, float* Dsum,
+                 int* single_tile, hipStream_t st) {
+    FF_CHECK(xa_fused_supported(dtype, dim_head, a.dim, a.inner), FF_ERR_UNSUPPORTED, "xa_dattn_bwd: unsupported dtype / head size");
+    FF_CHECK(dy1 && Wo && gate && Qs && K && V && tt && O && lse && dQ && dK && dV && Dsum && single_tile, FF_ERR_SHAPE, "xa_dattn_bwd: null argument");
+    const bool single = a.n_q <= 64;
+    FF_CHECK(single || dO, FF_ERR_SHAPE, "xa_dattn_bwd: dO buffer needed when the queries span several tiles");
+    *single_tile = single ? 1 : 0;
+    const int pid = profile_begin(dtype, -5, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
+    int rc;
+    if (a.n_q <= 32) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 32, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
+    else if (single) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 64, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
+    else FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 64, false>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
+    profile_end(pid, st);
+    return rc;
+}
+
+}  // namespace ff

@@ -12,6 +12,20 @@ template <typename T> struct AttnCfg;
 template <> struct AttnCfg<bf16> { static constexpr int pad = 8; };   // LDS row padding (elements)
 template <> struct AttnCfg<float> { static constexpr int pad = 4; };
 
+// ---- LDS tile layouts ---------------------------------------------------------------------------------
+// PadLayout : [row][DH + pad], filled by stage_tile (global -> VGPR -> LDS); what the stand-alone kernels use.
+// SwzLayout : [row][64] bf16 with the 16-byte chunks of a row XOR-swizzled by row & 7 - the K-major operand tile of the GEMM
+//             family, so it can be filled by LDS-DMA (dma_tile<64, 0>: the swizzle lives on the source address) ahead of its use.
+template <typename T, int DH> struct PadLayout {
+    static constexpr int LD = DH + AttnCfg<T>::pad;
+    static constexpr int tile_elems = kTile * LD;
+    static FF_DEV int off(int row, int col) { return row * LD + col; }
+};
+struct SwzLayout {
+    static constexpr int tile_elems = kTile * 64;
+    static FF_DEV int off(int row, int col) { return row * 64 + ((((col >> 3) ^ row) & 7) << 3) + (col & 7); }
+};
+
 // ---- fragments of the 16 own rows of a wave (B-operand style: lane (c, g) holds row c) -------------
 template <typename T, int DH> struct OwnFrag;
 template <int DH> struct OwnFrag<bf16, DH> {
@@ -20,6 +34,15 @@ template <int DH> struct OwnFrag<bf16, DH> {
 #pragma unroll
         for (int ks = 0; ks < DH / 32; ks++) {
             if (row) f[ks] = *(const bf16x8*)(row + ks * 32 + g * 8);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[ks][e] = (bf16)0.f;
+        }
+    }
+    template <typename L> FF_DEV void load_tile(const bf16* tile, int row, int g, bool ok) {   // row of an LDS tile in layout L
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ks++) {
+            if (ok) f[ks] = *(const bf16x8*)(tile + L::off(row, ks * 32 + g * 8));
             else
 #pragma unroll
                 for (int e = 0; e < 8; e++) f[ks][e] = (bf16)0.f;
@@ -39,6 +62,10 @@ template <int DH> struct OwnFrag<float, DH> {
     FF_DEV void load(const float* row, int g) {
 #pragma unroll
         for (int s = 0; s < DH / 16; s++) f[s] = row ? *(const f32x4*)(row + s * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    template <typename L> FF_DEV void load_tile(const float* tile, int row, int g, bool ok) {
+#pragma unroll
+        for (int s = 0; s < DH / 16; s++) f[s] = ok ? *(const f32x4*)(tile + L::off(row, s * 16 + g * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     FF_DEV float dot(const OwnFrag& o) const {
         float s = 0.f;
@@ -64,33 +91,30 @@ FF_DEV void stage_tile(T* lds, const T* base, long long row_stride, int row0, in
 }
 
 // ---- Z[sub][r] (other row sub*16 + g*4 + r, own row c) += X_tile . own^T ---------------------------
-template <int DH> FF_DEV void mma_k(f32x4 (&z)[4], const bf16* tile, const OwnFrag<bf16, DH>& own) {
-    constexpr int LD = DH + AttnCfg<bf16>::pad;
+template <int DH, typename L = PadLayout<bf16, DH>> FF_DEV void mma_k(f32x4 (&z)[4], const bf16* tile, const OwnFrag<bf16, DH>& own) {
     const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
 #pragma unroll
     for (int sub = 0; sub < 4; sub++)
 #pragma unroll
         for (int ks = 0; ks < DH / 32; ks++) {
-            const bf16x8 a = *(const bf16x8*)(tile + (sub * 16 + c) * LD + ks * 32 + g * 8);
+            const bf16x8 a = *(const bf16x8*)(tile + L::off(sub * 16 + c, ks * 32 + g * 8));
             z[sub] = mfma_bf16(a, own.f[ks], z[sub]);
         }
 }
-template <int DH> FF_DEV void mma_k(f32x4 (&z)[4], const float* tile, const OwnFrag<float, DH>& own) {
-    constexpr int LD = DH + AttnCfg<float>::pad;
+template <int DH, typename L = PadLayout<float, DH>> FF_DEV void mma_k(f32x4 (&z)[4], const float* tile, const OwnFrag<float, DH>& own) {
     const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
 #pragma unroll
     for (int sub = 0; sub < 4; sub++)
 #pragma unroll
         for (int s = 0; s < DH / 16; s++) {
-            const f32x4 a = *(const f32x4*)(tile + (sub * 16 + c) * LD + s * 16 + g * 4);
+            const f32x4 a = *(const f32x4*)(tile + L::off(sub * 16 + c, s * 16 + g * 4));
 #pragma unroll
             for (int j = 0; j < 4; j++) z[sub] = mfma_f32(a[j], own.f[s][j], z[sub]);
         }
 }
 
 // ---- Acc^T[dt][r] (d = dt*16 + g*4 + r, own row c) += Y_tile^T . Z' --------------------------------
-template <int DH> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const bf16* tile, const f32x4 (&z)[4]) {
-    constexpr int LD = DH + AttnCfg<bf16>::pad;
+template <int DH, typename L = PadLayout<bf16, DH>> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const bf16* tile, const f32x4 (&z)[4]) {
     const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
 #pragma unroll
     for (int s = 0; s < 2; s++) {  // k-step of 32 other rows = sub-tiles 2s, 2s+1
@@ -100,24 +124,22 @@ template <int DH> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const bf16* tile, con
             b[e] = (bf16)z[2 * s][e];
             b[4 + e] = (bf16)z[2 * s + 1][e];
         }
-        const bf16* p = tile + ((2 * s) * 16 + g * 4 + (c >> 2)) * LD + (c & 3) * 4;
+        const int row = (2 * s) * 16 + g * 4 + (c >> 2), col = (c & 3) * 4;
 #pragma unroll
         for (int dt = 0; dt < DH / 16; dt++) {
-            const bf16x8 a = cat4(lds_read_tr16(p + dt * 16), lds_read_tr16(p + 16 * LD + dt * 16));
+            const bf16x8 a = cat4(lds_read_tr16(tile + L::off(row, col + dt * 16)), lds_read_tr16(tile + L::off(row + 16, col + dt * 16)));
             acc[dt] = mfma_bf16(a, b, acc[dt]);
         }
     }
 }
-template <int DH> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const float* tile, const f32x4 (&z)[4]) {
-    constexpr int LD = DH + AttnCfg<float>::pad;
+template <int DH, typename L = PadLayout<float, DH>> FF_DEV void mma_t(f32x4 (&acc)[DH / 16], const float* tile, const f32x4 (&z)[4]) {
     const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
 #pragma unroll
     for (int sub = 0; sub < 4; sub++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const float* row = tile + (sub * 16 + g * 4 + r) * LD + c;
 #pragma unroll
-            for (int dt = 0; dt < DH / 16; dt++) acc[dt] = mfma_f32(row[dt * 16], z[sub][r], acc[dt]);
+            for (int dt = 0; dt < DH / 16; dt++) acc[dt] = mfma_f32(tile[L::off(sub * 16 + g * 4 + r, dt * 16 + c)], z[sub][r], acc[dt]);
         }
 }
 
@@ -174,19 +196,31 @@ FF_DEV void block_range(int lo, int hi, int* sh, int& blo, int& bhi) {
 // All of them use the workgroup's 4 waves: wave w owns "own" rows w*16 .. w*16+15 of a 64-row tile.
 // =====================================================================================================
 // forward: online softmax over the key tiles [blo, bhi) for the wave's 16 own queries (fragment fq, per-lane key range rr)
-template <typename T, int DH>
+// Staging policy of the K / V tiles: St::L = LDS layout, St::stage2(...) = bring rows row0.. of two matrices into two tiles (complete,
+// but not yet barrier-published, on return).  `staged_k0`: key tile the caller has already staged (and published) itself, or -1.
+template <typename T, int DH> struct SyncStage {
+    typedef PadLayout<T, DH> L;
+    static FF_DEV void stage2(T* s0, const T* b0, long long sr0, T* s1, const T* b1, long long sr1, int row0, int n_rows) {
+        stage_tile<T, DH>(s0, b0, sr0, row0, n_rows);
+        stage_tile<T, DH>(s1, b1, sr1, row0, n_rows);
+    }
+};
+
+template <typename T, int DH, typename St = SyncStage<T, DH>>
 FF_DEV void attn_fwd_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const RowRange& rr, int blo, int bhi, const T* Kb, const T* Vb,
-                          T* sK, T* sV, f32x4 (&acc)[DH / 16], float& m, float& lsum) {
+                          T* sK, T* sV, f32x4 (&acc)[DH / 16], float& m, float& lsum, int staged_k0 = -1) {
+    typedef typename St::L L;
     const int g = (threadIdx.x & 63) >> 4;
     for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
-        __syncthreads();
-        stage_tile<T, DH>(sK, Kb, d.k.sr, k0, d.n_kv);
-        stage_tile<T, DH>(sV, Vb, d.v.sr, k0, d.n_kv);
-        __syncthreads();
+        if (k0 != staged_k0) {
+            __syncthreads();
+            St::stage2(sK, Kb, d.k.sr, sV, Vb, d.v.sr, k0, d.n_kv);
+            __syncthreads();
+        }
         f32x4 z[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) z[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mma_k<DH>(z, sK, fq);
+        mma_k<DH, L>(z, sK, fq);
         float tmax = kNegBig;
 #pragma unroll
         for (int s = 0; s < 4; s++)
@@ -216,25 +250,27 @@ FF_DEV void attn_fwd_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const
         for (int dt = 0; dt < DH / 16; dt++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[dt][r] *= alpha;
-        mma_t<DH>(acc, sV, z);
+        mma_t<DH, L>(acc, sV, z);
     }
 }
 
 // backward, own rows = queries: dQ^T += K^T dS^T over the key tiles [blo, bhi); L = saved log-sum-exp, Dq = sum_d dO * O of the own row
-template <typename T, int DH>
+template <typename T, int DH, typename St = SyncStage<T, DH>>
 FF_DEV void attn_dq_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const OwnFrag<T, DH>& fdo, const RowRange& rr, float L, float Dq,
-                         int blo, int bhi, const T* Kb, const T* Vb, T* sK, T* sV, f32x4 (&acc)[DH / 16]) {
+                         int blo, int bhi, const T* Kb, const T* Vb, T* sK, T* sV, f32x4 (&acc)[DH / 16], int staged_k0 = -1) {
+    typedef typename St::L LY;
     const int g = (threadIdx.x & 63) >> 4;
     for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
-        __syncthreads();
-        stage_tile<T, DH>(sK, Kb, d.k.sr, k0, d.n_kv);
-        stage_tile<T, DH>(sV, Vb, d.v.sr, k0, d.n_kv);
-        __syncthreads();
+        if (k0 != staged_k0) {
+            __syncthreads();
+            St::stage2(sK, Kb, d.k.sr, sV, Vb, d.v.sr, k0, d.n_kv);
+            __syncthreads();
+        }
         f32x4 z[4], dp[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        mma_k<DH>(z, sK, fq);     // S^T
-        mma_k<DH>(dp, sV, fdo);   // dP^T = V dO^T
+        mma_k<DH, LY>(z, sK, fq);     // S^T
+        mma_k<DH, LY>(dp, sV, fdo);   // dP^T = V dO^T
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -244,13 +280,13 @@ FF_DEV void attn_dq_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const 
                 const float p = ok ? __expf(z[s][r] - L) : 0.f;
                 z[s][r] = p * (dp[s][r] - Dq);  // dS^T
             }
-        mma_t<DH>(acc, sK, z);    // dQ^T += K^T dS^T
+        mma_t<DH, LY>(acc, sK, z);    // dQ^T += K^T dS^T
     }
 }
 
 // backward, own rows = keys: one 64-query tile already staged in LDS (sQ, sDO) with its per-query key ranges / flags / statistics
 // (s_lo, s_hi, s_flag = softmax | uniform << 1, s_lse, s_D); accumulates dV^T += dO^T P and dK^T += Q^T dS for the wave's 16 own keys.
-template <typename T, int DH>
+template <typename T, int DH, typename LY = PadLayout<T, DH>>
 FF_DEV void attn_dkv_step(int key, const OwnFrag<T, DH>& fk, const OwnFrag<T, DH>& fv, const T* sQ, const T* sDO, const int* s_lo,
                           const int* s_hi, const int* s_flag, const float* s_lse, const float* s_D, f32x4 (&acc_k)[DH / 16],
                           f32x4 (&acc_v)[DH / 16]) {
@@ -258,8 +294,8 @@ FF_DEV void attn_dkv_step(int key, const OwnFrag<T, DH>& fk, const OwnFrag<T, DH
     f32x4 z[4], dp[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    mma_k<DH>(z, sQ, fk);     // S[q][key]
-    mma_k<DH>(dp, sDO, fv);   // dP[q][key]
+    mma_k<DH, LY>(z, sQ, fk);     // S[q][key]
+    mma_k<DH, LY>(dp, sDO, fv);   // dP[q][key]
 #pragma unroll
     for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -272,8 +308,8 @@ FF_DEV void attn_dkv_step(int key, const OwnFrag<T, DH>& fk, const OwnFrag<T, DH
             z[s][r] = p;                                                   // P
             dp[s][r] = (flag & 1) ? p * (dp[s][r] - s_D[qi]) : 0.f;        // dS
         }
-    mma_t<DH>(acc_v, sDO, z);   // dV^T += dO^T P
-    mma_t<DH>(acc_k, sQ, dp);   // dK^T += Q^T dS
+    mma_t<DH, LY>(acc_v, sDO, z);   // dV^T += dO^T P
+    mma_t<DH, LY>(acc_k, sQ, dp);   // dK^T += Q^T dS
 }
 
 }  // namespace ff

@@ -24,12 +24,43 @@ namespace {
 template <typename T> struct IsBf16 { static constexpr bool value = false; };
 template <> struct IsBf16<bf16> { static constexpr bool value = true; };
 
-// bytes of the region that first holds the projection's operand ring and then the attention tiles
-template <typename T, int DH, int BM, int NS, int ATT_ROWS> constexpr size_t region0_bytes() {
-    constexpr size_t ring = IsBf16<T>::value ? (size_t)NS * (BM + DH) * kBK * sizeof(bf16) : 0;
-    constexpr size_t att = (size_t)ATT_ROWS * (DH + AttnCfg<T>::pad) * sizeof(T);
-    return ((ring > att ? ring : att) + 255) / 256 * 256;
+// bf16 with 64-wide heads (every published Flamingo configuration): the attention tiles are K-major swizzled [64][64] tiles filled by
+// LDS-DMA, so the first key tile (and, in backward, the Q and O tiles) are in flight while the projection runs.
+template <typename T, int DH> struct Fast { static constexpr bool value = IsBf16<T>::value && DH == 64; };
+
+struct DmaStage64 {
+    typedef SwzLayout L;
+    static FF_DEV void issue(bf16* s, const bf16* base, long long sr, int row0, int n_rows) {
+        const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+        dma_tile<64, 0>(r, s, RowMap{sr, 0, 0}, row0, n_rows, 0, kBK, w, l);
+    }
+    static FF_DEV void stage2(bf16* s0, const bf16* b0, long long sr0, bf16* s1, const bf16* b1, long long sr1, int row0, int n_rows) {
+        issue(s0, b0, sr0, row0, n_rows);
+        issue(s1, b1, sr1, row0, n_rows);
+        wait_vmcnt<0>();
+    }
+};
+template <typename T, int DH, bool FAST> struct StageOf { typedef SyncStage<T, DH> type; };
+template <> struct StageOf<bf16, 64, true> { typedef DmaStage64 type; };
+
+// ring depth: as many 64-deep k-steps in flight as ~96 KiB of LDS hold (one workgroup per CU, its DMA queue is what hides the latency)
+template <int BM, int DH> constexpr int ring_stages() {
+    constexpr int stage = (BM + DH) * kBK * 2, n = 96 * 1024 / stage;
+    return n > 8 ? 8 : (n < 2 ? 2 : n);
 }
+
+// LDS carve-up (bytes).  region A: the projection's operand ring, later the tiles parked by the workgroup itself (Q resp. dO) and,
+// on the synchronous path, the K / V (/ Q) tiles; region B (fast path only): tiles prefetched by DMA while the projection runs.
+template <typename T, int DH, int BM, int NS, int SELF_TILES, int SYNC_TILES, int PRE_TILES> struct Carve {
+    static constexpr bool FAST = Fast<T, DH>::value;
+    static constexpr size_t tile = FAST ? (size_t)SwzLayout::tile_elems * sizeof(bf16) : (size_t)PadLayout<T, DH>::tile_elems * sizeof(T);
+    static constexpr size_t ring = IsBf16<T>::value ? (size_t)NS * (BM + DH) * kBK * sizeof(bf16) : 0;
+    static constexpr size_t self = (size_t)(SELF_TILES + (FAST ? 0 : SYNC_TILES)) * tile;
+    static constexpr size_t regionA = ((ring > self ? ring : self) + 255) / 256 * 256;
+    static constexpr size_t regionB = FAST ? (size_t)PRE_TILES * tile : 0;
+    static constexpr size_t fixed = regionA + regionB;
+};
 
 FF_DEV ff_attn_desc attn_view(const XaFusedArgs& a, int dim_head) {
     ff_attn_desc d = {};
@@ -37,6 +68,15 @@ FF_DEV ff_attn_desc attn_view(const XaFusedArgs& a, int dim_head) {
     d.mode = FF_ATTN_MEDIA; d.n_visual = a.n_visual; d.tt_stride = a.tt_stride; d.tt_offset = a.tt_offset;
     d.k = a.k; d.v = a.v; d.dk = a.dk; d.dv = a.dv;
     return d;
+}
+
+// tile kt must have landed; up to `younger` (wave-uniform, <= MAXY) younger tiles of PER_TILE DMA instructions each may stay in flight
+template <int PER_TILE, int MAXY> FF_DEV void wait_tiles(int younger) {
+    if constexpr (MAXY == 0) wait_vmcnt<0>();
+    else {
+        if (younger >= MAXY) wait_vmcnt<MAXY * PER_TILE>();
+        else wait_tiles<PER_TILE, MAXY - 1>(younger);
+    }
 }
 
 // D[n][m] += B_tile[n][k] * A_tile[m][k] over k = [0, dim) for the wave's 16 rows m of the A tile and all DH columns n, operands
@@ -48,7 +88,6 @@ FF_DEV void project_bf16(bf16* ring, const bf16* Ab, long long lda, int row0, in
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = DH * kBK, STAGE = A_ELEMS + B_ELEMS, NT = DH / 16;
     constexpr int PER_TILE = BM / 32 + DH / 32;
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
-    static_assert(NS >= 2 && NS <= 4, "ring depth");
     const RowMap a_map{lda, 0, 0}, b_map{ldb, 0, 0};
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7fffffff, 0x00020000);
@@ -64,10 +103,7 @@ FF_DEV void project_bf16(bf16* ring, const bf16* Ab, long long lda, int row0, in
         if (s < nk) issue(s);
     const bool active = w * 16 < BM;        // wave-uniform: a 32-row tile keeps two waves as DMA helpers only
     for (int kt = 0; kt < nk; kt++) {
-        const int younger = min(nk - 1 - kt, NS - 2);
-        if (NS >= 4 && younger == 2) wait_vmcnt<2 * PER_TILE>();
-        else if (NS >= 3 && younger >= 1) wait_vmcnt<PER_TILE>();
-        else wait_vmcnt<0>();
+        wait_tiles<PER_TILE, NS - 2>(min(nk - 1 - kt, NS - 2));
         __builtin_amdgcn_s_barrier();       // tile kt is in LDS for everyone; stage (kt - 1) % NS is free
         if (kt + NS - 1 < nk) issue(kt + NS - 1);
         if (active) {
@@ -84,25 +120,24 @@ FF_DEV void project_bf16(bf16* ring, const bf16* Ab, long long lda, int row0, in
     }
 }
 
-// acc[j][r] = value (row m = w*16 + c, column j*16 + g*4 + r) -> tile[m][...] (LD = DH + pad)
-template <typename T, int DH> FF_DEV void park_rows(T* tile, const f32x4 (&acc)[DH / 16], float scale, int w, int c, int g) {
+// acc[j][r] = value (row m = w*16 + c, column j*16 + g*4 + r) -> LDS tile in layout L
+template <typename T, int DH, typename L> FF_DEV void park_rows(T* tile, const f32x4 (&acc)[DH / 16], float scale, int w, int c, int g) {
     typedef __attribute__((ext_vector_type(4))) T vec4;
-    constexpr int LD = DH + AttnCfg<T>::pad;
 #pragma unroll
     for (int j = 0; j < DH / 16; j++) {
         vec4 v;
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] = from_f32<T>(acc[j][r] * scale);
-        *(vec4*)(tile + (w * 16 + c) * LD + j * 16 + g * 4) = v;
+        *(vec4*)(tile + L::off(w * 16 + c, j * 16 + g * 4)) = v;
     }
 }
 
 // rows [0, n_rows) of an LDS tile -> global rows (16-byte row-contiguous pieces)
-template <typename T, int DH> FF_DEV void tile_to_global(const T* tile, T* dst, long long row_stride, int n_rows) {
-    constexpr int LD = DH + AttnCfg<T>::pad, VN = Vec<T>::N, CH = DH / VN;
+template <typename T, int DH, typename L> FF_DEV void tile_to_global(const T* tile, T* dst, long long row_stride, int n_rows) {
+    constexpr int VN = Vec<T>::N, CH = DH / VN;
     for (int idx = threadIdx.x; idx < n_rows * CH; idx += 256) {
         const int r = idx / CH, ch = idx - r * CH;
-        *(uint4*)(dst + (long long)r * row_stride + ch * VN) = *(const uint4*)(tile + r * LD + ch * VN);
+        *(uint4*)(dst + (long long)r * row_stride + ch * VN) = *(const uint4*)(tile + L::off(r, ch * VN));
     }
 }
 
@@ -111,7 +146,7 @@ template <typename T, int DH> FF_DEV void tile_to_global(const T* tile, T* dst, 
 // =====================================================================================================
 // forward: LayerNorm -> Q projection (one head) -> masked attention
 // =====================================================================================================
-template <typename T, int DH, int BM, int NS>
+template <typename T, int DH, int BM>
 __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_in, const T* __restrict__ y, const T* __restrict__ gamma,
                                                            const T* __restrict__ beta, const T* __restrict__ Wq, const T* __restrict__ K,
                                                            const T* __restrict__ V, const int* __restrict__ tt, T* __restrict__ yn,
@@ -119,54 +154,84 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
                                                            float* __restrict__ rstd, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const XaFusedArgs a = fetch_args(a_in);
-    constexpr int LD = DH + AttnCfg<T>::pad, NT = DH / 16, VN = Vec<T>::N;
-    constexpr size_t R0 = region0_bytes<T, DH, BM, NS, BM + 2 * kTile>();
+    constexpr bool FAST = Fast<T, DH>::value;
+    constexpr int NS = ring_stages<BM, DH>(), NT = DH / 16, VN = Vec<T>::N;
+    typedef typename StageOf<T, DH, FAST>::type St;
+    typedef typename St::L L;
+    typedef Carve<T, DH, BM, NS, 1, 2, 2> CV;        // parks Q; K, V tiles
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int row0 = qt * BM;
     const int n_rows = min(BM, a.n_q - row0);
     const int dimp = (a.dim + kBK - 1) / kBK * kBK;
-    T* s_g = (T*)(smem + R0);
+    T* sQ = (T*)smem;
+    T* sK = FAST ? (T*)(smem + CV::regionA) : sQ + L::tile_elems;
+    T* sV = sK + L::tile_elems;
+    T* s_g = (T*)(smem + CV::fixed);
     T* s_b = s_g + dimp;
     float* s_mean = (float*)(s_b + dimp);
     float* s_rstd = s_mean + BM;
     int* sh = (int*)(s_rstd + BM);
 
-    // ---- LayerNorm statistics of the tile's rows (two passes, fp32, like torch), gamma / beta into LDS ----
+    // ---- which keys this tile's queries see; the first key tile starts travelling to LDS right away ----
+    const ff_attn_desc d = attn_view(a, DH);
+    const int m_own = w * 16 + c;                      // the lane's own row of the tile
+    const bool own_ok = m_own < n_rows;                // (false for the helper waves of a 32-row tile)
+    const int q = row0 + m_own;
+    RowRange rr = row_range(d, tt, b, q);
+    if (!own_ok) { rr.lo = rr.hi = 0; rr.softmax = 0; rr.uniform = 0; }
+    int blo, bhi;
+    block_range(rr.lo, rr.hi, sh, blo, bhi);
+    const T* Kb = K + b * a.k.sb + h * a.k.sh;
+    const T* Vb = V + b * a.v.sb + h * a.v.sh;
+    int staged_k0 = -1;
+    if constexpr (FAST) {
+        if (blo < bhi) {
+            staged_k0 = (blo / kTile) * kTile;
+            DmaStage64::issue(sK, Kb, a.k.sr, staged_k0, a.n_kv);
+            DmaStage64::issue(sV, Vb, a.v.sr, staged_k0, a.n_kv);
+        }
+    }
+
+    // ---- LayerNorm statistics of the tile's rows: one pass over the rows, sums shifted by the row's first element ----
     for (int i = t; i < dimp; i += 256) {
         s_g[i] = i < a.dim ? gamma[i] : from_f32<T>(0.f);
         s_b[i] = i < a.dim ? beta[i] : from_f32<T>(0.f);
     }
     {
-        constexpr int TPR = 256 / BM;     // threads per row (adjacent lanes of one wave)
+        constexpr int TPR = 256 / BM, NB = 8;     // threads per row (adjacent lanes of one wave), loads in flight per thread
         const int r = t / TPR, sub = t % TPR;
         const bool rok = r < n_rows;
         const long long grow = (long long)b * a.n_q + row0 + (rok ? r : 0);
         const T* yr = y + grow * a.dim;
         const int nchunk = a.dim / VN;
-        float s = 0.f;
-        if (rok)
-            for (int ch = sub; ch < nchunk; ch += TPR) {
-                float v[VN];
-                Vec<T>::load(yr + ch * VN, v);
+        const float x0 = to_f32(yr[0]);
+        float s1 = 0.f, s2 = 0.f;
+        for (int base = sub; base < nchunk; base += TPR * NB) {
+            float v[NB][VN];
 #pragma unroll
-                for (int e = 0; e < VN; e++) s += v[e];
+            for (int u = 0; u < NB; u++) {
+                const int ch = base + u * TPR;
+                if (ch < nchunk) Vec<T>::load(yr + ch * VN, v[u]);
+                else
+#pragma unroll
+                    for (int e = 0; e < VN; e++) v[u][e] = x0;
             }
 #pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        const float mu = s / (float)a.dim;
-        float q = 0.f;
-        if (rok)
-            for (int ch = sub; ch < nchunk; ch += TPR) {
-                float v[VN];
-                Vec<T>::load(yr + ch * VN, v);
+            for (int u = 0; u < NB; u++)
 #pragma unroll
-                for (int e = 0; e < VN; e++) q += (v[e] - mu) * (v[e] - mu);
-            }
+                for (int e = 0; e < VN; e++) {
+                    const float dlt = v[u][e] - x0;
+                    s1 += dlt;
+                    s2 += dlt * dlt;
+                }
+        }
 #pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-        const float rs = rsqrtf(q / (float)a.dim + a.eps);
+        for (int o = TPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const float sh1 = s1 / (float)a.dim;
+        const float mu = x0 + sh1;
+        const float rs = rsqrtf(fmaxf(s2 / (float)a.dim - sh1 * sh1, 0.f) + a.eps);
         if (sub == 0) {
             s_mean[r] = rok ? mu : 0.f;
             s_rstd[r] = rok ? rs : 0.f;
@@ -185,14 +250,12 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
             }
         }
     }
-    __syncthreads();      // statistics + gamma / beta visible; no plain load is outstanding when the DMA pipeline starts
+    __syncthreads();      // statistics + gamma / beta visible
 
     // ---- q[m][n] = sum_k LN(y)[m][k] Wq[h*DH + n][k] ----
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int m_own = w * 16 + c;                      // the lane's own row of the tile
-    const bool own_ok = m_own < n_rows;                // (false for the helper waves of a 32-row tile)
     const float mu = m_own < BM ? s_mean[m_own] : 0.f, rs = m_own < BM ? s_rstd[m_own] : 0.f;
     if constexpr (IsBf16<T>::value) {
         auto ln = [&](bf16x8& fa, int kk) {
@@ -219,28 +282,19 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
             }
         }
     }
-    __syncthreads();      // the operand ring is dead: its memory becomes the Q / K / V tiles of the attention
-    T* sQ = (T*)smem;
-    T* sK = sQ + BM * LD;
-    T* sV = sK + kTile * LD;
-    if (w * 16 < BM) park_rows<T, DH>(sQ, acc, a.scale, w, c, g);
+    __syncthreads();      // the operand ring is dead: its memory becomes the Q tile (and, on the synchronous path, the K / V tiles)
+    if (w * 16 < BM) park_rows<T, DH, L>(sQ, acc, a.scale, w, c, g);
     __syncthreads();
-    tile_to_global<T, DH>(sQ, Qs + ((long long)b * a.n_q + row0) * a.inner + h * DH, a.inner, n_rows);   // saved for backward
+    tile_to_global<T, DH, L>(sQ, Qs + ((long long)b * a.n_q + row0) * a.inner + h * DH, a.inner, n_rows);   // saved for backward
 
     // ---- O = softmax_masked(q K^T) V for the wave's 16 own queries ----
-    const ff_attn_desc d = attn_view(a, DH);
-    const int q = row0 + m_own;
-    RowRange rr = row_range(d, tt, b, q);
-    if (!own_ok) { rr.lo = rr.hi = 0; rr.softmax = 0; rr.uniform = 0; }
-    int blo, bhi;
-    block_range(rr.lo, rr.hi, sh, blo, bhi);
     OwnFrag<T, DH> fq;
-    fq.load(own_ok ? sQ + m_own * LD : nullptr, g);
+    fq.template load_tile<L>(sQ, m_own, g, own_ok);
     f32x4 o[NT];
 #pragma unroll
     for (int dt = 0; dt < NT; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = kNegBig, lsum = 0.f;
-    attn_fwd_loop<T, DH>(d, fq, rr, blo, bhi, K + b * a.k.sb + h * a.k.sh, V + b * a.v.sb + h * a.v.sh, sK, sV, o, m, lsum);
+    attn_fwd_loop<T, DH, St>(d, fq, rr, blo, bhi, Kb, Vb, sK, sV, o, m, lsum, staged_k0);
     lsum = group_sum(lsum);
     if (own_ok) {
         const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
@@ -252,7 +306,7 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
 // =====================================================================================================
 // backward: d O projection (one head) -> attention backward
 // =====================================================================================================
-template <typename T, int DH, int BM, int NS, bool SINGLE>
+template <typename T, int DH, int BM, bool SINGLE>
 __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_in, const T* __restrict__ dy1, const T* __restrict__ Wo,
                                                            const T* __restrict__ gate, const T* __restrict__ Qs, const T* __restrict__ K,
                                                            const T* __restrict__ V, const int* __restrict__ tt, const T* __restrict__ O,
@@ -260,26 +314,60 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
                                                            T* __restrict__ dK, T* __restrict__ dV, float* __restrict__ Dsum) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const XaFusedArgs a = fetch_args(a_in);
-    constexpr int LD = DH + AttnCfg<T>::pad, NT = DH / 16;
-    constexpr size_t R0 = region0_bytes<T, DH, BM, NS, 4 * kTile>();
+    constexpr bool FAST = Fast<T, DH>::value;
+    constexpr int NS = ring_stages<BM, DH>(), NT = DH / 16;
+    typedef typename StageOf<T, DH, FAST>::type St;
+    typedef typename St::L L;
+    typedef Carve<T, DH, BM, NS, 1, 3, 4> CV;        // parks dO; Q, K, V tiles (+ O on the DMA path)
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int row0 = qt * BM;
     const int n_rows = min(BM, a.n_q - row0);
-    int* s_lo = (int*)(smem + R0);
+    T* sDO = (T*)smem;
+    T* sQ = FAST ? (T*)(smem + CV::regionA) : sDO + L::tile_elems;
+    T* sK = sQ + L::tile_elems;
+    T* sV = sK + L::tile_elems;
+    T* sO = sV + L::tile_elems;                          // DMA path only
+    int* s_lo = (int*)(smem + CV::fixed);
     int* s_hi = s_lo + kTile;
     int* s_flag = s_hi + kTile;
     float* s_lse = (float*)(s_flag + kTile);
     float* s_D = s_lse + kTile;
     int* sh = (int*)(s_D + kTile);
 
+    // ---- key ranges of the own queries; the tiles the attention will need start travelling to LDS right away ----
+    const ff_attn_desc d = attn_view(a, DH);
+    const int m_own = w * 16 + c;
+    const bool own_ok = m_own < n_rows;
+    const int q = row0 + m_own;
+    const RowRange rr_full = row_range(d, tt, b, q);
+    RowRange rr = rr_full;
+    if (!own_ok || !rr.softmax) rr.lo = rr.hi = 0;      // zero / uniform rows: no gradient reaches the scores
+    if (SINGLE && t < kTile) { s_lo[t] = 0; s_hi[t] = 0; s_flag[t] = 0; s_lse[t] = kPosBig; s_D[t] = 0.f; }
+    int blo, bhi;
+    block_range(rr.lo, rr.hi, sh, blo, bhi);
+    const T* Kb = K + b * a.k.sb + h * a.k.sh;
+    const T* Vb = V + b * a.v.sb + h * a.v.sh;
+    const T* Qb = Qs + (long long)b * a.n_q * a.inner + h * DH;
+    const int q_lim = SINGLE ? a.n_q : min(a.n_q, row0 + BM);      // rows past the tile / the sample read as zeros
+    int staged_k0 = -1;
+    if constexpr (FAST) {
+        if (blo < bhi) {
+            staged_k0 = (blo / kTile) * kTile;
+            DmaStage64::issue(sK, Kb, a.k.sr, staged_k0, a.n_kv);
+            DmaStage64::issue(sV, Vb, a.v.sr, staged_k0, a.n_kv);
+        }
+        DmaStage64::issue(sQ, Qb, a.inner, row0, q_lim);
+        DmaStage64::issue(sO, O + (long long)b * a.n_q * a.inner + h * DH, a.inner, row0, q_lim);
+    }
+    const long long sidx = ((long long)b * a.heads + h) * a.n_q + q;
+    const float Lq = own_ok ? lse[sidx] : kPosBig;
+
     // ---- dO[m][n] = tanh(alpha) * sum_k dy1[m][k] Wo[k][h*DH + n] ----
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int m_own = w * 16 + c;
-    const bool own_ok = m_own < n_rows;
     if constexpr (IsBf16<T>::value) {
         auto none = [](bf16x8&, int) {};
         project_bf16<DH, BM, NS, 1>((bf16*)smem, dy1 + (long long)b * a.n_q * a.dim, a.dim, row0, a.n_q, Wo, a.inner, h * DH, (h + 1) * DH,
@@ -299,53 +387,37 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
             }
         }
     }
-    __syncthreads();      // operand ring dead -> dO / Q / K / V tiles
-    T* sDO = (T*)smem;
-    T* sQ = sDO + kTile * LD;
-    T* sK = sQ + kTile * LD;
-    T* sV = sK + kTile * LD;
+    __syncthreads();      // operand ring dead -> dO tile (and, on the synchronous path, the Q / K / V tiles)
     const float gt = tanhf(to_f32(gate[0]));
-    if (w * 16 < BM) park_rows<T, DH>(sDO, acc, gt, w, c, g);
+    if (w * 16 < BM) park_rows<T, DH, L>(sDO, acc, gt, w, c, g);
     else {                // rows BM .. 63 of the 64-row dO tile do not exist: zero them (they are "other" rows of the dK / dV products)
         typedef __attribute__((ext_vector_type(4))) T vec4;
         vec4 z;
 #pragma unroll
         for (int r = 0; r < 4; r++) z[r] = from_f32<T>(0.f);
 #pragma unroll
-        for (int j = 0; j < NT; j++) *(vec4*)(sDO + (w * 16 + c) * LD + j * 16 + g * 4) = z;
+        for (int j = 0; j < NT; j++) *(vec4*)(sDO + L::off(w * 16 + c, j * 16 + g * 4)) = z;
     }
-    const T* Qb = Qs + (long long)b * a.n_q * a.inner + h * DH;
-    stage_tile<T, DH>(sQ, Qb, a.inner, row0, SINGLE ? a.n_q : min(a.n_q, row0 + BM));   // rows past the tile / the sample are zeros
+    if constexpr (!FAST) stage_tile<T, DH>(sQ, Qb, a.inner, row0, q_lim);
     __syncthreads();
-    if (!SINGLE && dO_out) tile_to_global<T, DH>(sDO, dO_out + ((long long)b * a.n_q + row0) * a.inner + h * DH, a.inner, n_rows);
+    if (!SINGLE && dO_out) tile_to_global<T, DH, L>(sDO, dO_out + ((long long)b * a.n_q + row0) * a.inner + h * DH, a.inner, n_rows);
 
     // ---- own rows = queries: D = sum_d dO * O, dQ ----
-    const ff_attn_desc d = attn_view(a, DH);
-    const int q = row0 + m_own;
     OwnFrag<T, DH> fq, fdo, fo;
-    fq.load(own_ok ? sQ + m_own * LD : nullptr, g);
-    fdo.load(own_ok ? sDO + m_own * LD : nullptr, g);
-    fo.load(own_ok ? O + ((long long)b * a.n_q + q) * a.inner + h * DH : nullptr, g);
+    fq.template load_tile<L>(sQ, m_own, g, own_ok);
+    fdo.template load_tile<L>(sDO, m_own, g, own_ok);
+    if constexpr (FAST) fo.template load_tile<L>(sO, m_own, g, own_ok);
+    else fo.load(own_ok ? O + ((long long)b * a.n_q + q) * a.inner + h * DH : nullptr, g);
     const float Dq = group_sum(fdo.dot(fo));
-    const long long sidx = ((long long)b * a.heads + h) * a.n_q + q;
-    const float L = own_ok ? lse[sidx] : kPosBig;
     if (own_ok && g == 0 && Dsum) Dsum[sidx] = Dq;
-    const RowRange rr_full = row_range(d, tt, b, q);
-    RowRange rr = rr_full;
-    if (!own_ok || !rr.softmax) rr.lo = rr.hi = 0;      // zero / uniform rows: no gradient reaches the scores
-    if (SINGLE && t < kTile) { s_lo[t] = 0; s_hi[t] = 0; s_flag[t] = 0; s_lse[t] = kPosBig; s_D[t] = 0.f; }
-    int blo, bhi;
-    block_range(rr.lo, rr.hi, sh, blo, bhi);            // (contains a __syncthreads: the defaults above are in place)
     if (SINGLE && own_ok && g == 0) {
         s_lo[m_own] = rr_full.lo; s_hi[m_own] = rr_full.hi; s_flag[m_own] = rr_full.softmax | (rr_full.uniform << 1);
-        s_lse[m_own] = L; s_D[m_own] = Dq;
+        s_lse[m_own] = Lq; s_D[m_own] = Dq;
     }
     f32x4 dq[NT];
 #pragma unroll
     for (int dt = 0; dt < NT; dt++) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const T* Kb = K + b * a.k.sb + h * a.k.sh;
-    const T* Vb = V + b * a.v.sb + h * a.v.sh;
-    attn_dq_loop<T, DH>(d, fq, fdo, rr, L, Dq, blo, bhi, Kb, Vb, sK, sV, dq);
+    attn_dq_loop<T, DH, St>(d, fq, fdo, rr, Lq, Dq, blo, bhi, Kb, Vb, sK, sV, dq, staged_k0);
     if (own_ok) store_acc_row<T, DH>(dQ + ((long long)b * a.n_q + q) * a.inner + h * DH, dq, 1.f, g);
 
     // ---- own rows = keys (the sample's queries are all in this tile): dK, dV ----
@@ -355,12 +427,18 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
             const int key = k0 + m_own;
             const bool kok = key < a.n_kv;
             OwnFrag<T, DH> fk, fv;
-            fk.load(kok ? Kb + (long long)key * a.k.sr : nullptr, g);
-            fv.load(kok ? Vb + (long long)key * a.v.sr : nullptr, g);
+            if (FAST && k0 == staged_k0) {          // the tile is still in LDS from the dQ pass (when that pass touched no other tile)
+                const bool one_tile = bhi <= staged_k0 + kTile;
+                if (one_tile) { fk.template load_tile<L>(sK, m_own, g, kok); fv.template load_tile<L>(sV, m_own, g, kok); }
+                else { fk.load(kok ? Kb + (long long)key * a.k.sr : nullptr, g); fv.load(kok ? Vb + (long long)key * a.v.sr : nullptr, g); }
+            } else {
+                fk.load(kok ? Kb + (long long)key * a.k.sr : nullptr, g);
+                fv.load(kok ? Vb + (long long)key * a.v.sr : nullptr, g);
+            }
             f32x4 acc_k[NT], acc_v[NT];
 #pragma unroll
             for (int dt = 0; dt < NT; dt++) { acc_k[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_v[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            attn_dkv_step<T, DH>(key, fk, fv, sQ, sDO, s_lo, s_hi, s_flag, s_lse, s_D, acc_k, acc_v);
+            attn_dkv_step<T, DH, L>(key, fk, fv, sQ, sDO, s_lo, s_hi, s_flag, s_lse, s_D, acc_k, acc_v);
             if (kok) {
                 store_acc_row<T, DH>(dK + b * a.dk.sb + (long long)key * a.dk.sr + h * a.dk.sh, acc_k, 1.f, g);
                 store_acc_row<T, DH>(dV + b * a.dv.sb + (long long)key * a.dv.sr + h * a.dv.sh, acc_v, 1.f, g);
@@ -372,8 +450,6 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
 // =====================================================================================================
 // host side
 // =====================================================================================================
-constexpr int kFusedStages = 4;
-
 bool xa_fused_supported(int dtype, int dim_head, int dim, int inner) {
     if (dtype == FF_DTYPE_BF16) return (dim_head == 64 || dim_head == 128) && dim % 8 == 0 && inner % 8 == 0;
     if (dtype == FF_DTYPE_F32) return (dim_head == 16 || dim_head == 32 || dim_head == 64 || dim_head == 128) && dim % 4 == 0 && inner % 4 == 0;
@@ -382,10 +458,10 @@ bool xa_fused_supported(int dtype, int dim_head, int dim, int inner) {
 
 template <typename T, int DH, int BM> static size_t fwd_lds(int dim) {
     const int dimp = (dim + kBK - 1) / kBK * kBK;
-    return region0_bytes<T, DH, BM, kFusedStages, BM + 2 * kTile>() + (size_t)2 * dimp * sizeof(T) + (size_t)2 * BM * sizeof(float) + 8 * sizeof(int);
+    return Carve<T, DH, BM, ring_stages<BM, DH>(), 1, 2, 2>::fixed + (size_t)2 * dimp * sizeof(T) + (size_t)2 * BM * sizeof(float) + 8 * sizeof(int);
 }
 template <typename T, int DH, int BM> static size_t bwd_lds() {
-    return region0_bytes<T, DH, BM, kFusedStages, 4 * kTile>() + (size_t)5 * kTile * 4 + 8 * sizeof(int);
+    return Carve<T, DH, BM, ring_stages<BM, DH>(), 1, 3, 4>::fixed + (size_t)5 * kTile * 4 + 8 * sizeof(int);
 }
 
 template <typename KernelT> static int allow_lds(KernelT kernel, size_t lds, const char* what) {
@@ -416,7 +492,7 @@ template <typename T, int DH, int BM>
 static int launch_fwd(const XaFusedArgs& a, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K, const void* V,
                       const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st) {
     const size_t lds = fwd_lds<T, DH, BM>(a.dim);
-    auto kernel = xa_qattn_fwd_kernel<T, DH, BM, kFusedStages>;
+    auto kernel = xa_qattn_fwd_kernel<T, DH, BM>;
     FF_TRY(allow_lds(kernel, lds, "xa_qattn_fwd"));
     const dim3 grid(cdiv(a.n_q, BM), a.heads, a.batch);
     kernel<<<grid, dim3(256), lds, st>>>(a, (const T*)y, (const T*)gamma, (const T*)beta, (const T*)Wq, (const T*)K, (const T*)V, tt, (T*)yn, (T*)Qs,
@@ -440,7 +516,7 @@ template <typename T, int DH, int BM, bool SINGLE>
 static int launch_bwd(const XaFusedArgs& a, const void* dy1, const void* Wo, const void* gate, const void* Qs, const void* K, const void* V,
                       const int* tt, const void* O, const float* lse, void* dO, void* dQ, void* dK, void* dV, float* Dsum, hipStream_t st) {
     const size_t lds = bwd_lds<T, DH, BM>();
-    auto kernel = xa_dattn_bwd_kernel<T, DH, BM, kFusedStages, SINGLE>;
+    auto kernel = xa_dattn_bwd_kernel<T, DH, BM, SINGLE>;
     FF_TRY(allow_lds(kernel, lds, "xa_dattn_bwd"));
     const dim3 grid(cdiv(a.n_q, BM), a.heads, a.batch);
     kernel<<<grid, dim3(256), lds, st>>>(a, (const T*)dy1, (const T*)Wo, (const T*)gate, (const T*)Qs, (const T*)K, (const T*)V, tt, (const T*)O, lse,

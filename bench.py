@@ -41,16 +41,36 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
+# The five workloads of BASELINE.json `configs` as concrete synthetic inputs.  B is the headline (the config the
+# metric is quoted on); the others are reached with --config and print the same JSON contract with their own `config.workload`.
+CONFIGS = {
+    "A": dict(lm="gpt2", clip="openai/clip-vit-base-patch32", batch=2, seq_len=32, xattn_every=1, images=1, frames=0, dtype="f32",
+              what="flamingo-tiny (gpt2 124M + CLIP ViT-B/32), 1 image, seq_len 32, batch 2 (the reference's CPU-runnable plumbing case, here on the GPU in fp32)"),
+    "B": dict(lm="gpt2-large", clip="openai/clip-vit-large-patch14", batch=32, seq_len=32, xattn_every=1, images=1, frames=0, dtype="bf16",
+              what="flamingo-mini (gpt2-large + CLIP ViT-L/14), 1 image (224x224) + 32 tokens per sequence"),
+    "C": dict(lm="facebook/opt-1.3b", clip="openai/clip-vit-large-patch14", batch=32, seq_len=32, xattn_every=2, images=1, frames=0, dtype="bf16",
+              what="facebook/opt-1.3b + CLIP ViT-L/14, xattn_every=2 (12 gated blocks), 1 image + 32 tokens per sequence (global batch 256 = 32 per GPU x 8)"),
+    "D": dict(lm="gpt2-large", clip="openai/clip-vit-large-patch14", batch=32, seq_len=32, xattn_every=1, images=1, frames=4, dtype="bf16",
+              what="video path: gpt2-large + CLIP ViT-L/14, one 4-frame clip (4 x 224x224, resampler_num_time_embeds=4, 1092 resampler keys) + 32 tokens per sequence"),
+    "E": dict(lm="facebook/opt-6.7b", clip="openai/clip-vit-large-patch14", batch=4, seq_len=1024, xattn_every=1, images=4, frames=0, dtype="bf16",
+              what="facebook/opt-6.7b + CLIP ViT-L/14, few-shot interleaved: 4 images + 1024 tokens per sequence, media tags at 0/256/512/768"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--seq-len", type=int, default=32)
-    ap.add_argument("--lm", default="gpt2-large")
-    ap.add_argument("--clip", default="openai/clip-vit-large-patch14")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS), help="BASELINE.json workload (B = headline); the flags below override its fields")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--lm", default=None)
+    ap.add_argument("--clip", default=None)
+    ap.add_argument("--xattn-every", type=int, default=None)
+    ap.add_argument("--images", type=int, default=None, help="images per sequence (media tags spread evenly over the sequence)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per image (0 = still images, 5-D pixel tensor; > 0 = 6-D video tensor)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"], help="fused = ff_adamw_step (this library), torch = torch.optim.AdamW(fused=True)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -64,17 +84,23 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
-    return ap.parse_args()
+    args = ap.parse_args()
+    for k, v in CONFIGS[args.config].items():
+        if k != "what" and getattr(args, k) is None:
+            setattr(args, k, v)
+    args.what = CONFIGS[args.config]["what"]
+    return args
 
 
 def build_model(args, device, dtype):
     from flamingo_mini_amd import FlamingoConfig, FlamingoModel
     from flamingo_mini_amd.backbones import CLIP_VISION, GPT2, OPT
     dim = GPT2[args.lm][0] if args.lm in GPT2 else OPT[args.lm][0]
-    cfg = FlamingoConfig(lm=args.lm, clip_model_type=args.clip, dim=dim, dim_visual=CLIP_VISION[args.clip][0],
+    cfg = FlamingoConfig(lm=args.lm, clip_model_type=args.clip, dim=dim, dim_visual=CLIP_VISION[args.clip][0], xattn_every=args.xattn_every,
                          random_init_backbones=True)
     torch.manual_seed(1234)                                   # same weights on every rank (DDP broadcasts; here: same seed)
-    model = FlamingoModel(cfg)
+    with torch.device(device):                                # random init straight on the GPU (opt-6.7b + 32 gated blocks are 11 G parameters)
+        model = FlamingoModel(cfg)
     with torch.no_grad():
         for hook in model.flamingo.get_modified_layers():
             hook.xattn_block.alpha_attn.fill_(0.5)
@@ -84,11 +110,12 @@ def build_model(args, device, dtype):
 
 def synthetic_batch(args, cfg, device, dtype, rank):
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    px = torch.randn((args.batch, 1, 3, 224, 224), generator=g).to(device=device, dtype=dtype)
+    shape = (args.batch, args.images) + ((args.frames,) if args.frames > 0 else ()) + (3, 224, 224)     # (b N [T] c h w)
+    px = torch.randn(shape, generator=g).to(device=device, dtype=dtype)
     vocab = 50257 if args.lm.startswith("gpt2") else 50272
     ids = torch.randint(0, vocab, (args.batch, args.seq_len), generator=g).to(device)
     ml = torch.zeros((args.batch, args.seq_len), dtype=torch.long, device=device)
-    ml[:, 0] = 1
+    ml[:, [i * (args.seq_len // args.images) for i in range(args.images)]] = 1          # one tag per image, evenly spread (0/256/512/768 in config E)
     return dict(pixel_values=px, input_ids=ids, media_locations=ml, attention_mask=torch.ones_like(ids), labels=ids)
 
 
@@ -302,7 +329,7 @@ def main():
                     f.write(" ".join(map(str, k)) + f" {g['launches'] / prof_steps:.1f} {g['ms'] / g['launches'] * 1e3:.1f} "
                             f"{g['flops'] / (g['ms'] * 1e-3) / 1e12:.1f} {g['ms'] / prof_steps:.3f}\n")
         ms_per_step = elapsed / args.steps * 1e3
-        images = args.batch * world * args.steps
+        images = args.batch * args.images * world * args.steps        # a video clip counts as one image (its frames share one set of 64 latents)
         roofline = None
         if groups:
             key, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
@@ -329,11 +356,13 @@ def main():
                         "measured": f"HIP events around every launch in {prof_steps} eager steps of the same workload run right after the "
                                     f"timed region ({eager_ms:.2f} ms/step with the instrumentation)"}
         result = {
-            "metric": "images/sec (fwd+bwd) flamingo-mini bs=32",
+            "metric": "images/sec (fwd+bwd) flamingo-mini bs=32" if args.config == "B" else f"images/sec (fwd+bwd) config {args.config} bs={args.batch}",
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"flamingo-mini ({args.lm} + {args.clip}), 1 image (224x224) + {args.seq_len} tokens per sequence, "
+            "config": {"name": args.config,
+                       "workload": f"{args.what}; {args.lm} + {args.clip}, {args.images} image(s)" + (f" x {args.frames} frames" if args.frames else "")
+                                   + f" + {args.seq_len} tokens per sequence, xattn_every {args.xattn_every}, "
                                    f"per-GPU batch {args.batch}; step = fwd + bwd + grad all-reduce"
                                    + ("" if args.no_optimizer else f" + AdamW ({args.optimizer})")
                                    + ("; step replayed from a captured HIP graph" if use_graph else "; eager launches") + "; random-init weights, gates alpha=0.5",

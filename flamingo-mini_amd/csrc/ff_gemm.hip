@@ -146,10 +146,8 @@ FF_DEV void epilogue8(const GemmParams& P, const GemmProblem& pr, int m, int n, 
 
 // Epilogue of one bf16 output tile parked in LDS as fp32 (see gemm_bf16_dma_kernel): thread -> 8 consecutive columns of a row,
 // rows strided over the 256 threads in a rolled loop, so the code exists once and every global access is a 16-byte piece of a row.
-// own_split >= 0: split-K, this workgroup arrived last at the tile - the other slices' fp32 partial tiles are added from their slabs
-// (always in slice order 0, 1, 2, ..., whichever slice happens to do the adding: the sum is bit-reproducible).
 template <int BM, int BN>
-FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const float* ct, int m_base, int n_base, int own_split = -1, int z = 0) {
+FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const float* ct, int m_base, int n_base) {
     constexpr int TPR = BN / 8, RPP = 256 / TPR;
     const int t = threadIdx.x, tr = t / TPR, col = (t % TPR) * 8, n = n_base + col;
     if (n >= P.N) return;
@@ -166,25 +164,6 @@ FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const
             const int ch = col >> 2, sw = r & 15;
             const f32x4 lo = *(const f32x4*)(ct + r * BN + ((ch ^ sw) << 2)), hi = *(const f32x4*)(ct + r * BN + (((ch + 1) ^ sw) << 2));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (own_split >= 0) {
-                float tsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const float* src = P.partial + ((long long)z * P.split_k * P.M + m) * P.N + n;
-                const long long slab = (long long)P.M * P.N;
-                for (int sp = 0; sp < P.split_k; sp++) {
-                    if (sp == own_split) {
-#pragma unroll
-                        for (int e = 0; e < 8; e++) tsum[e] += v[e];
-                    } else {
-                        const f32x4 a0 = *(const f32x4*)(src + sp * slab);
-                        f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
-                        if (nv == 8) a1 = *(const f32x4*)(src + sp * slab + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { tsum[e] += a0[e]; tsum[e + 4] += a1[e]; }
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = tsum[e];
-            }
             epilogue8<bf16, F>(P, pr, m, n, nv, vec, gate, v);
         }
     };
@@ -207,14 +186,14 @@ FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const
     GemmParams Q;                                                                                                                     \
     Q.M = P.M; Q.N = P.N; Q.K = P.K; Q.split_k = P.split_k; Q.k_per_split = P.k_per_split; Q.nz = P.nz;                              \
     Q.xcd_ms = P.xcd_ms; Q.xcd_ns = P.xcd_ns; Q.a_map = P.a_map; Q.b_map = P.b_map; Q.c_map = P.c_map; Q.r_map = P.r_map;             \
-    Q.scale = P.scale; Q.act = P.act; Q.act_bwd = P.act_bwd; Q.c_vec8 = P.c_vec8; Q.partial = P.partial; Q.counters = P.counters;      \
+    Q.scale = P.scale; Q.act = P.act; Q.act_bwd = P.act_bwd; Q.c_vec8 = P.c_vec8; Q.partial = P.partial;                              \
     GemmProblem pr = P.p[0];                                                                                                          \
     FF_PIN(Q.M); FF_PIN(Q.N); FF_PIN(Q.K); FF_PIN(Q.split_k); FF_PIN(Q.k_per_split); FF_PIN(Q.nz); FF_PIN(Q.xcd_ms); FF_PIN(Q.xcd_ns); \
     FF_PIN(Q.a_map.ld); FF_PIN(Q.a_map.seg_stride); FF_PIN(Q.a_map.rows_per_seg);                                                     \
     FF_PIN(Q.b_map.ld); FF_PIN(Q.b_map.seg_stride); FF_PIN(Q.b_map.rows_per_seg);                                                     \
     FF_PIN(Q.c_map.ld); FF_PIN(Q.c_map.seg_stride); FF_PIN(Q.c_map.rows_per_seg);                                                     \
     FF_PIN(Q.r_map.ld); FF_PIN(Q.r_map.seg_stride); FF_PIN(Q.r_map.rows_per_seg);                                                     \
-    FF_PIN(Q.scale); FF_PIN(Q.act); FF_PIN(Q.act_bwd); FF_PIN(Q.c_vec8); FF_PIN(Q.partial); FF_PIN(Q.counters);                       \
+    FF_PIN(Q.scale); FF_PIN(Q.act); FF_PIN(Q.act_bwd); FF_PIN(Q.c_vec8); FF_PIN(Q.partial);                                           \
     FF_PIN(pr.A); FF_PIN(pr.B); FF_PIN(pr.C); FF_PIN(pr.aux_out); FF_PIN(pr.aux_in); FF_PIN(pr.residual); FF_PIN(pr.gate)
 
 // XCD-aware tile order: consecutive logical tiles (same A row panel) land on the same XCD / L2.
@@ -362,11 +341,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, cons
 
     FF_TL(3);
     const int c = l & 15, g = l >> 4;
-    int own_split = -1;
-    if (Q.split_k > 1) {
-        // Split-K without a second launch: every slice publishes its fp32 partial tile (plain stores -> agent-scope release) and draws
-        // a ticket from the tile's counter; the slice that arrives last acquires, adds the other slices' slabs and runs the epilogue.
-        // Correct for any placement of a tile's slices over XCDs / CUs (per-XCD L2s are not coherent, a CU's L1 is never refreshed).
+    if (Q.split_k > 1) {   // fp32 partial slab; gemm_splitk_epilogue_kernel reduces the slabs and applies the epilogue
 #pragma unroll
         for (int i = 0; i < MT; i++) {
             const int m = m_base + wm * WM + i * 16 + c;
@@ -378,18 +353,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, cons
                 *(f32x4*)(Q.partial + ((long long)(tc.z * Q.split_k + tc.split) * Q.M + m) * Q.N + n) = acc[i][j];
             }
         }
-        int* ticket = (int*)(smem_raw + (size_t)NS * STAGE * sizeof(bf16));      // one word behind the operand ring (same LDS object)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every storing wave drains its own stores
-        __syncthreads();
-        if (t == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the write-back must be complete before the ticket is drawn
-            ticket[0] = __hip_atomic_fetch_add(Q.counters + (tc.z * tiles_m + tc.tm) * tiles_n + tc.tn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (ticket[0] != Q.split_k - 1) return;
-        if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // drop this CU's stale lines; the barrier below extends it to all waves
-        own_split = tc.split;
+        return;
     }
     // The operand ring is dead: park the fp32 tile in it (16-byte chunks XOR-swizzled by row) and let one rolled loop apply the
     // epilogue on row-contiguous 8-element pieces.  Applying it per accumulator fragment inlined the activation code 64 times
@@ -408,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, cons
     }
     __syncthreads();
     FF_TL(4);
-    tile_epilogue_bf16<BM, BN>(Q, pr, ct, m_base, n_base, own_split, tc.z);
+    tile_epilogue_bf16<BM, BN>(Q, pr, ct, m_base, n_base);
     FF_TL(5);
 }
 
@@ -639,10 +603,7 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     if (t128 >= 200 && t128 < 450 && a_layout == 0 && (long long)cdiv(M, 64) * cdiv(N, 128) * nz >= 400) p = TilePlan{6412, 1};
     else if (t128 >= 200) p = TilePlan{128, 1};
     else if (K >= 2048) {
-        // the slices of a tile are reduced inside the launch by its last-arriving workgroup: aim for ONE round of workgroups (tiles * s <= 256
-        // CUs) so nobody waits for a second round's slabs.  FF_GEMM_SPLIT_ROUNDS=0: the older 1.5-round rule (more, shorter slices).
-        static const int one_round = env_int("FF_GEMM_SPLIT_ROUNDS", 1);
-        int s = one_round ? (int)std::min<long long>(8, std::max<long long>(2, 256 / t128)) : (int)std::min<long long>(8, std::max<long long>(2, cdiv(384, t128)));
+        int s = (int)std::min<long long>(8, std::max<long long>(2, cdiv(384, t128)));
         while (s > 1 && K / (64 * s) < 8) s--;
         p = TilePlan{128, s};
     } else if (t64 >= 200) p = TilePlan{64, 1};
@@ -657,7 +618,7 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
 static bool big_tile(const GemmParams& P) { return P.tile == 128; }
 
 template <int BM, int BN, int AL, int BL, int NS> static int launch_bf16_dma(const GemmParams& P, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16) + 16;     // + the split-K ticket word
+    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
     static bool attr_done = false;
     if (!attr_done) {
         if (lds > 64 * 1024) {
@@ -702,11 +663,9 @@ int gemm_pick_split(int dtype, int M, int N, int K, int nz) {
     return std::max(s, 1);
 }
 
-static size_t slab_bytes(int M, int N, int nz, int split_k) { return align_up((size_t)split_k * nz * M * N * sizeof(float)); }
-static size_t counter_bytes(int M, int N, int nz) { return align_up((size_t)cdiv(M, 64) * cdiv(N, 64) * nz * sizeof(int)); }   // smallest tile: upper bound
 size_t gemm_workspace_bytes(int dtype, int M, int N, int K, int nz, int split_k) {
     if (split_k <= 0) split_k = gemm_pick_split(dtype, M, N, K, nz);
-    return split_k > 1 ? slab_bytes(M, N, nz, split_k) + counter_bytes(M, N, nz) : 0;
+    return split_k > 1 ? (size_t)split_k * nz * M * N * sizeof(float) : 0;
 }
 
 int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipStream_t st) {
@@ -727,11 +686,6 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         FF_CHECK(workspace && ws_bytes >= need, FF_ERR_WORKSPACE, "gemm split-K workspace: need %zu have %zu", need, ws_bytes);
         FF_CHECK(P.N % 4 == 0, FF_ERR_UNSUPPORTED, "gemm split-K needs N %% 4 == 0 (N=%d)", P.N);
         P.partial = (float*)workspace;
-        P.counters = (int*)((char*)workspace + slab_bytes(P.M, P.N, P.nz, P.split_k));
-        if (dtype == FF_DTYPE_BF16) {       // the tickets must be zero at every launch (a memset node when the launch is captured into a graph)
-            hipError_t e = hipMemsetAsync(P.counters, 0, counter_bytes(P.M, P.N, P.nz), st);
-            FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "gemm split-K: hipMemsetAsync: %s", hipGetErrorString(e));
-        }
     }
     {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
         const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 ? 128 : 64) : kFBM;
@@ -780,11 +734,12 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
     }
     prof_end(prof_id, st);   // the record covers the MFMA main kernel only (what rocprofv3 lists under the same name)
     FF_TRY(rc);
-    if (P.split_k > 1 && dtype != FF_DTYPE_BF16) {      // fp32 (verification precision): slabs reduced by a second launch
+    if (P.split_k > 1) {
         const long long total = (long long)P.nz * P.M * ((P.N + 7) / 8);
         FF_CHECK(total < (1LL << 31), FF_ERR_UNSUPPORTED, "gemm split-K output too large (M=%d N=%d nz=%d)", P.M, P.N, P.nz);
         const int grid = (int)((total + 255) / 256);
-        hipLaunchKernelGGL(gemm_splitk_epilogue_kernel<float>, dim3(grid), dim3(256), 0, st, P);
+        if (dtype == FF_DTYPE_BF16) hipLaunchKernelGGL(gemm_splitk_epilogue_kernel<bf16>, dim3(grid), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL(gemm_splitk_epilogue_kernel<float>, dim3(grid), dim3(256), 0, st, P);
         FF_TRY(check_launch("gemm_splitk_epilogue"));
     }
     return FF_OK;

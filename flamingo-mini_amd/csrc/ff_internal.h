@@ -26,7 +26,6 @@ struct GemmParams {
     int tile;   // block tile chosen by the host (bf16: 128 = 128x128, 64 = 64x64, 6412 = 64x128)
     int xcd_ms, xcd_ns;   // XCD partition of the tile grid (ms * ns sub-grids, one per XCD)
     float* partial;
-    int* counters;   // bf16 split-K: one arrival ticket per output tile (zeroed by the launcher); the last slice to arrive reduces the tile
     int a_vec_ok, b_vec_ok;
     int c_vec8;   // bf16 epilogue may use 16-byte accesses on C / aux / residual
     int nz;

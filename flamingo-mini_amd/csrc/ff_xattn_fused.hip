@@ -19,6 +19,14 @@
 
 namespace ff {
 
+#ifdef FF_XA_TIMELINE   // debug build: per-workgroup phase timestamps (100 MHz constant clock), read with ff_debug_xa_timeline_read
+__device__ unsigned long long g_xa_timeline[4096 * 8];
+#define FF_XTL(i) do { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+                       if (threadIdx.x == 0 && wg_ < 4096) g_xa_timeline[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FF_XTL(i) do { } while (0)
+#endif
+
 namespace {
 
 template <typename T> struct IsBf16 { static constexpr bool value = false; };
@@ -41,6 +49,18 @@ struct DmaStage64 {
         wait_vmcnt<0>();
     }
 };
+// 16 bytes held in registers -> Vec<T>::N floats
+FF_DEV void unpack16(const uint4& r, float (&v)[8], bf16) {
+    const bf16x8 x = __builtin_bit_cast(bf16x8, r);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (float)x[e];
+}
+FF_DEV void unpack16(const uint4& r, float (&v)[4], float) {
+    const f32x4 x = __builtin_bit_cast(f32x4, r);
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = x[e];
+}
+
 template <typename T, int DH, bool FAST> struct StageOf { typedef SyncStage<T, DH> type; };
 template <> struct StageOf<bf16, 64, true> { typedef DmaStage64 type; };
 
@@ -153,6 +173,7 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
                                                            T* __restrict__ Qs, T* __restrict__ O, float* __restrict__ mean,
                                                            float* __restrict__ rstd, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FF_XTL(0);
     const XaFusedArgs a = fetch_args(a_in);
     constexpr bool FAST = Fast<T, DH>::value;
     constexpr int NS = ring_stages<BM, DH>(), NT = DH / 16, VN = Vec<T>::N;
@@ -194,62 +215,84 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
         }
     }
 
+    FF_XTL(1);
     // ---- LayerNorm statistics of the tile's rows: one pass over the rows, sums shifted by the row's first element ----
     for (int i = t; i < dimp; i += 256) {
         s_g[i] = i < a.dim ? gamma[i] : from_f32<T>(0.f);
         s_b[i] = i < a.dim ? beta[i] : from_f32<T>(0.f);
     }
     {
-        constexpr int TPR = 256 / BM, NB = 8;     // threads per row (adjacent lanes of one wave), loads in flight per thread
+        // A row is read ONCE, in batches of NB 16-byte pieces per thread that are all in flight together; the sums are shifted by the row's
+        // first element (x0), so the one-pass variance has the accuracy of the two-pass form.  The normalised rows (an operand of
+        // d to_q.weight) are written from the same registers, the pieces of a row shared out over the heads' workgroups.
+        constexpr int TPR = 256 / BM, NB = 24;    // threads per row (adjacent lanes of one wave), pieces in flight per thread
         const int r = t / TPR, sub = t % TPR;
         const bool rok = r < n_rows;
         const long long grow = (long long)b * a.n_q + row0 + (rok ? r : 0);
         const T* yr = y + grow * a.dim;
         const int nchunk = a.dim / VN;
-        const float x0 = to_f32(yr[0]);
-        float s1 = 0.f, s2 = 0.f;
-        for (int base = sub; base < nchunk; base += TPR * NB) {
-            float v[NB][VN];
+        const bool one_batch = nchunk <= TPR * NB;
+        float x0 = 0.f, s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 0.f;
+        uint4 raw[NB];
+        for (int base = 0; base < nchunk; base += TPR * NB) {
 #pragma unroll
             for (int u = 0; u < NB; u++) {
-                const int ch = base + u * TPR;
-                if (ch < nchunk) Vec<T>::load(yr + ch * VN, v[u]);
-                else
-#pragma unroll
-                    for (int e = 0; e < VN; e++) v[u][e] = x0;
+                const int ch = base + sub + u * TPR;
+                if (ch < nchunk) raw[u] = *(const uint4*)(yr + ch * VN);
+            }
+            if (base == 0) {
+                float first[VN];
+                unpack16(raw[0], first, T());
+                x0 = __shfl(first[0], (t & 63) - sub, 64);      // element 0 of the row sits in the first piece of the row's first thread
             }
 #pragma unroll
-            for (int u = 0; u < NB; u++)
+            for (int u = 0; u < NB; u++) {
+                const int ch = base + sub + u * TPR;
+                if (ch < nchunk) {
+                    float v[VN];
+                    unpack16(raw[u], v, T());
 #pragma unroll
-                for (int e = 0; e < VN; e++) {
-                    const float dlt = v[u][e] - x0;
-                    s1 += dlt;
-                    s2 += dlt * dlt;
+                    for (int e = 0; e < VN; e++) {
+                        const float dlt = v[e] - x0;
+                        s1 += dlt;
+                        s2 += dlt * dlt;
+                    }
                 }
+            }
         }
 #pragma unroll
         for (int o = TPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        const float sh1 = s1 / (float)a.dim;
-        const float mu = x0 + sh1;
-        const float rs = rsqrtf(fmaxf(s2 / (float)a.dim - sh1 * sh1, 0.f) + a.eps);
+        {
+            const float sh1 = s1 / (float)a.dim;
+            mu = x0 + sh1;
+            rs = rsqrtf(fmaxf(s2 / (float)a.dim - sh1 * sh1, 0.f) + a.eps);
+        }
         if (sub == 0) {
             s_mean[r] = rok ? mu : 0.f;
             s_rstd[r] = rok ? rs : 0.f;
             if (rok && h == 0) { mean[grow] = mu; rstd[grow] = rs; }
         }
-        if (rok && h == 0 && yn) {        // the normalised rows themselves are an operand of d to_q.weight: written once per row tile
+        if (rok && yn) {
             T* ynr = yn + grow * a.dim;
-            for (int ch = sub; ch < nchunk; ch += TPR) {
-                float v[VN], gv[VN], bv[VN];
-                Vec<T>::load(yr + ch * VN, v);
-                Vec<T>::load(gamma + ch * VN, gv);
-                Vec<T>::load(beta + ch * VN, bv);
+            for (int base = 0; base < nchunk; base += TPR * NB) {
 #pragma unroll
-                for (int e = 0; e < VN; e++) v[e] = (v[e] - mu) * rs * gv[e] + bv[e];
-                Vec<T>::store(ynr + ch * VN, v);
+                for (int u = 0; u < NB; u++) {
+                    const int ch = base + sub + u * TPR;
+                    if (ch < nchunk && (u % a.heads) == h) {                 // this head's share of the row's pieces
+                        float v[VN], gv[VN], bv[VN];
+                        if (one_batch) unpack16(raw[u], v, T());
+                        else Vec<T>::load(yr + ch * VN, v);
+                        Vec<T>::load(gamma + ch * VN, gv);
+                        Vec<T>::load(beta + ch * VN, bv);
+#pragma unroll
+                        for (int e = 0; e < VN; e++) v[e] = (v[e] - mu) * rs * gv[e] + bv[e];
+                        Vec<T>::store(ynr + ch * VN, v);
+                    }
+                }
             }
         }
     }
+    FF_XTL(2);
     __syncthreads();      // statistics + gamma / beta visible
 
     // ---- q[m][n] = sum_k LN(y)[m][k] Wq[h*DH + n][k] ----
@@ -282,11 +325,13 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
             }
         }
     }
+    FF_XTL(3);
     __syncthreads();      // the operand ring is dead: its memory becomes the Q tile (and, on the synchronous path, the K / V tiles)
     if (w * 16 < BM) park_rows<T, DH, L>(sQ, acc, a.scale, w, c, g);
     __syncthreads();
     tile_to_global<T, DH, L>(sQ, Qs + ((long long)b * a.n_q + row0) * a.inner + h * DH, a.inner, n_rows);   // saved for backward
 
+    FF_XTL(4);
     // ---- O = softmax_masked(q K^T) V for the wave's 16 own queries ----
     OwnFrag<T, DH> fq;
     fq.template load_tile<L>(sQ, m_own, g, own_ok);
@@ -295,12 +340,14 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
     for (int dt = 0; dt < NT; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = kNegBig, lsum = 0.f;
     attn_fwd_loop<T, DH, St>(d, fq, rr, blo, bhi, Kb, Vb, sK, sV, o, m, lsum, staged_k0);
+    FF_XTL(5);
     lsum = group_sum(lsum);
     if (own_ok) {
         const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
         store_acc_row<T, DH>(O + ((long long)b * a.n_q + q) * a.inner + h * DH, o, inv, g);
         if (g == 0) lse[((long long)b * a.heads + h) * a.n_q + q] = lsum > 0.f ? m + __logf(lsum) : kPosBig;
     }
+    FF_XTL(6);
 }
 
 // =====================================================================================================
@@ -313,6 +360,7 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
                                                            const float* __restrict__ lse, T* __restrict__ dO_out, T* __restrict__ dQ,
                                                            T* __restrict__ dK, T* __restrict__ dV, float* __restrict__ Dsum) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FF_XTL(0);
     const XaFusedArgs a = fetch_args(a_in);
     constexpr bool FAST = Fast<T, DH>::value;
     constexpr int NS = ring_stages<BM, DH>(), NT = DH / 16;
@@ -364,6 +412,7 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
     const long long sidx = ((long long)b * a.heads + h) * a.n_q + q;
     const float Lq = own_ok ? lse[sidx] : kPosBig;
 
+    FF_XTL(1);
     // ---- dO[m][n] = tanh(alpha) * sum_k dy1[m][k] Wo[k][h*DH + n] ----
     f32x4 acc[NT];
 #pragma unroll
@@ -387,6 +436,7 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
             }
         }
     }
+    FF_XTL(2);
     __syncthreads();      // operand ring dead -> dO tile (and, on the synchronous path, the Q / K / V tiles)
     const float gt = tanhf(to_f32(gate[0]));
     if (w * 16 < BM) park_rows<T, DH, L>(sDO, acc, gt, w, c, g);
@@ -402,6 +452,7 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
     __syncthreads();
     if (!SINGLE && dO_out) tile_to_global<T, DH, L>(sDO, dO_out + ((long long)b * a.n_q + row0) * a.inner + h * DH, a.inner, n_rows);
 
+    FF_XTL(3);
     // ---- own rows = queries: D = sum_d dO * O, dQ ----
     OwnFrag<T, DH> fq, fdo, fo;
     fq.template load_tile<L>(sQ, m_own, g, own_ok);
@@ -418,7 +469,9 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
 #pragma unroll
     for (int dt = 0; dt < NT; dt++) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     attn_dq_loop<T, DH, St>(d, fq, fdo, rr, Lq, Dq, blo, bhi, Kb, Vb, sK, sV, dq, staged_k0);
+    FF_XTL(4);
     if (own_ok) store_acc_row<T, DH>(dQ + ((long long)b * a.n_q + q) * a.inner + h * DH, dq, 1.f, g);
+    FF_XTL(5);
 
     // ---- own rows = keys (the sample's queries are all in this tile): dK, dV ----
     if constexpr (SINGLE) {
@@ -445,6 +498,7 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
             }
         }
     }
+    FF_XTL(6);
 }
 
 // =====================================================================================================
@@ -543,3 +597,9 @@ int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1,
 }
 
 }  // namespace ff
+
+#ifdef FF_XA_TIMELINE
+extern "C" int ff_debug_xa_timeline_read(unsigned long long* out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff::g_xa_timeline), sizeof(unsigned long long) * 8 * n_blocks);
+}
+#endif

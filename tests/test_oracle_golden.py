@@ -101,3 +101,45 @@ def test_mask_quirks_pinned():
 def test_flop_model_matches_survey():
     assert abs(O.resampler_flops_fwd(32, 1, 257, 1024) / 1e9 - 369.3) < 0.1
     assert abs(O.xattn_block_flops_fwd(32, 32, 1280, 1024) / 1e9 - 33.96) < 0.01
+
+
+# ---------------------------------------------------------------------------------------------------
+# The torch CPU restatement (oracle/torch_port.py: what bench.py times as `cpu_baseline`, all host cores, backward by autograd)
+# is held to the same reference-generated vectors.
+# ---------------------------------------------------------------------------------------------------
+def _t(a, grad=False):
+    import torch
+    return torch.from_numpy(np.asarray(a, np.float64)).requires_grad_(grad)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "rs_*.npz"))), ids=os.path.basename)
+def test_resampler_torch_port_matches_reference(path):
+    from oracle import torch_port as TP
+    z, p, x, dy, kw, tol = load_rs(path)
+    pt = {k: _t(v, True) for k, v in p.items()}
+    xt = _t(x, True)
+    y = TP.resampler(xt, pt, **kw)
+    assert rel(y.detach().numpy(), z["y"]) < tol
+    y.backward(_t(dy))
+    assert rel(xt.grad.numpy().reshape(z["dx"].shape), z["dx"]) < tol
+    for k in pt:
+        assert rel(pt[k].grad.numpy(), z["g." + k]) < tol, k
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "xa_*.npz"))), ids=os.path.basename)
+def test_xattn_block_torch_port_matches_reference(path):
+    import torch
+    from oracle import torch_port as TP
+    z, p, y, vf, dy, kw, n_visual, tol = load_xa(path)
+    pt = {k: _t(v, True) for k, v in p.items()}
+    yt, vft = _t(y, True), _t(vf, True)
+    ml = torch.from_numpy(np.asarray(z["ml"], np.int64))
+    out, (k, v) = TP.gated_xattn_block(yt, vft, ml, pt, n_visual=n_visual, **kw)
+    assert rel(out.detach().numpy(), z["y_out"]) < tol and rel(k.detach().numpy(), z["k"]) < tol and rel(v.detach().numpy(), z["v"]) < tol
+    out.backward(_t(dy))
+    assert rel(yt.grad.numpy(), z["dy_in"]) < tol and rel(vft.grad.numpy(), z["dvf"]) < tol
+    for k_ in pt:
+        assert rel(pt[k_].grad.numpy(), z["g." + k_]) < tol, k_
+    with torch.no_grad():
+        out_c, _ = TP.gated_xattn_block(yt[:, -1:], None, ml, pt, n_visual=n_visual, previous_kv=(k, v), **kw)
+    assert rel(out_c.numpy(), z["y_out_cached_last"]) < tol

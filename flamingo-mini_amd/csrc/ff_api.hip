@@ -594,10 +594,12 @@ static int kvp_check(const ff_kvproj_desc* d) {
     return FF_OK;
 }
 static size_t kvp_gemm_ws(const ff_kvproj_desc* d) {
-    const int z = kGemmMaxZ;
-    return align_up(std::max({gemm_workspace_bytes(d->dtype, d->rows, d->kv_dim, d->dim_visual, z, 0),
-                              gemm_workspace_bytes(d->dtype, d->kv_dim, d->dim_visual, d->rows, z, 0),
-                              gemm_workspace_bytes(d->dtype, d->rows, d->dim_visual, d->kv_dim, z, 0)}));
+    size_t w = 0;
+    for (int z = 1; z <= kGemmMaxZ; z++)      // the last group may hold fewer layers (and then pick a split-K plan)
+        w = std::max({w, gemm_workspace_bytes(d->dtype, d->rows, d->kv_dim, d->dim_visual, z, 0),
+                      gemm_workspace_bytes(d->dtype, d->kv_dim, d->dim_visual, d->rows, z, 0),
+                      gemm_workspace_bytes(d->dtype, d->rows, d->dim_visual, d->kv_dim, z, 0)});
+    return align_up(w);
 }
 static size_t kvp_ws_bytes(const ff_kvproj_desc* d, bool with_dvf) {
     const size_t es = d->dtype == FF_DTYPE_BF16 ? 2 : 4;

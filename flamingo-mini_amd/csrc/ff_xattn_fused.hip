@@ -195,52 +195,73 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
     float* s_rstd = s_mean + BM;
     int* sh = (int*)(s_rstd + BM);
 
-    // ---- which keys this tile's queries see; the first key tile starts travelling to LDS right away ----
+    // ---- every load the prologue needs is issued before the first wait: the rows of y (ONE pass, NB 16-byte pieces per thread in
+    // flight), gamma / beta, and text_time for the key ranges ----
+    constexpr int TPR = 256 / BM, NB = 24;    // threads per row (adjacent lanes of one wave), pieces in flight per thread
+    const int r = t / TPR, sub = t % TPR;
+    const bool rok = r < n_rows;
+    const long long grow = (long long)b * a.n_q + row0 + (rok ? r : 0);
+    const T* yr = y + grow * a.dim;
+    const int nchunk = a.dim / VN;
+    const bool one_batch = nchunk <= TPR * NB;
+    uint4 raw[NB];
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        const int ch = sub + u * TPR;
+        if (ch < nchunk) raw[u] = *(const uint4*)(yr + ch * VN);
+    }
+    uint4 gb_raw[2];
+    const int gb_chunks = dimp / VN;          // gamma pieces, then beta pieces; zero past `dim`
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int i = t + it * 256;
+        const int ch = i < gb_chunks ? i : i - gb_chunks;
+        gb_raw[it] = uint4{0, 0, 0, 0};
+        if (i < 2 * gb_chunks && ch < nchunk) gb_raw[it] = *(const uint4*)((i < gb_chunks ? gamma : beta) + ch * VN);
+    }
+    for (int i = t + 512; i < 2 * gb_chunks; i += 256) {      // very wide models only: the rest goes global -> LDS piece by piece
+        const int ch = i < gb_chunks ? i : i - gb_chunks;
+        uint4 v = {0, 0, 0, 0};
+        if (ch < nchunk) v = *(const uint4*)((i < gb_chunks ? gamma : beta) + ch * VN);
+        *(uint4*)((i < gb_chunks ? s_g : s_b) + ch * VN) = v;
+    }
     const ff_attn_desc d = attn_view(a, DH);
     const int m_own = w * 16 + c;                      // the lane's own row of the tile
     const bool own_ok = m_own < n_rows;                // (false for the helper waves of a 32-row tile)
     const int q = row0 + m_own;
     RowRange rr = row_range(d, tt, b, q);
     if (!own_ok) { rr.lo = rr.hi = 0; rr.softmax = 0; rr.uniform = 0; }
+    {
+        int i = t;
+#pragma unroll
+        for (int it = 0; it < 2; it++, i += 256)
+            if (i < 2 * gb_chunks) *(uint4*)((i < gb_chunks ? s_g + i * VN : s_b + (i - gb_chunks) * VN)) = gb_raw[it];
+    }
     int blo, bhi;
-    block_range(rr.lo, rr.hi, sh, blo, bhi);
+    block_range(rr.lo, rr.hi, sh, blo, bhi);           // (a barrier: gamma / beta are in LDS for everyone behind it)
     const T* Kb = K + b * a.k.sb + h * a.k.sh;
     const T* Vb = V + b * a.v.sb + h * a.v.sh;
     int staged_k0 = -1;
-    if constexpr (FAST) {
+    if constexpr (FAST) {     // the first key tile starts travelling to LDS now and lands while the projection runs
         if (blo < bhi) {
             staged_k0 = (blo / kTile) * kTile;
             DmaStage64::issue(sK, Kb, a.k.sr, staged_k0, a.n_kv);
             DmaStage64::issue(sV, Vb, a.v.sr, staged_k0, a.n_kv);
         }
     }
-
     FF_XTL(1);
-    // ---- LayerNorm statistics of the tile's rows: one pass over the rows, sums shifted by the row's first element ----
-    for (int i = t; i < dimp; i += 256) {
-        s_g[i] = i < a.dim ? gamma[i] : from_f32<T>(0.f);
-        s_b[i] = i < a.dim ? beta[i] : from_f32<T>(0.f);
-    }
+
+    // ---- LayerNorm statistics: sums shifted by the row's first element (x0), so the one-pass variance has two-pass accuracy ----
     {
-        // A row is read ONCE, in batches of NB 16-byte pieces per thread that are all in flight together; the sums are shifted by the row's
-        // first element (x0), so the one-pass variance has the accuracy of the two-pass form.  The normalised rows (an operand of
-        // d to_q.weight) are written from the same registers, the pieces of a row shared out over the heads' workgroups.
-        constexpr int TPR = 256 / BM, NB = 24;    // threads per row (adjacent lanes of one wave), pieces in flight per thread
-        const int r = t / TPR, sub = t % TPR;
-        const bool rok = r < n_rows;
-        const long long grow = (long long)b * a.n_q + row0 + (rok ? r : 0);
-        const T* yr = y + grow * a.dim;
-        const int nchunk = a.dim / VN;
-        const bool one_batch = nchunk <= TPR * NB;
-        float x0 = 0.f, s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 0.f;
-        uint4 raw[NB];
+        float x0 = 0.f, s1 = 0.f, s2 = 0.f;
         for (int base = 0; base < nchunk; base += TPR * NB) {
+            if (base > 0) {
 #pragma unroll
-            for (int u = 0; u < NB; u++) {
-                const int ch = base + sub + u * TPR;
-                if (ch < nchunk) raw[u] = *(const uint4*)(yr + ch * VN);
-            }
-            if (base == 0) {
+                for (int u = 0; u < NB; u++) {
+                    const int ch = base + sub + u * TPR;
+                    if (ch < nchunk) raw[u] = *(const uint4*)(yr + ch * VN);
+                }
+            } else {
                 float first[VN];
                 unpack16(raw[0], first, T());
                 x0 = __shfl(first[0], (t & 63) - sub, 64);      // element 0 of the row sits in the first piece of the row's first thread
@@ -262,16 +283,16 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
         }
 #pragma unroll
         for (int o = TPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        {
-            const float sh1 = s1 / (float)a.dim;
-            mu = x0 + sh1;
-            rs = rsqrtf(fmaxf(s2 / (float)a.dim - sh1 * sh1, 0.f) + a.eps);
-        }
+        const float sh1 = s1 / (float)a.dim;
+        const float mu_r = x0 + sh1;
+        const float rs_r = rsqrtf(fmaxf(s2 / (float)a.dim - sh1 * sh1, 0.f) + a.eps);
         if (sub == 0) {
-            s_mean[r] = rok ? mu : 0.f;
-            s_rstd[r] = rok ? rs : 0.f;
-            if (rok && h == 0) { mean[grow] = mu; rstd[grow] = rs; }
+            s_mean[r] = rok ? mu_r : 0.f;
+            s_rstd[r] = rok ? rs_r : 0.f;
+            if (rok && h == 0) { mean[grow] = mu_r; rstd[grow] = rs_r; }
         }
+        // The normalised rows are an operand of d to_q.weight: written from the registers that still hold the row, the pieces of a row
+        // shared out over the heads' workgroups (gamma / beta from LDS: published by the barrier in block_range).
         if (rok && yn) {
             T* ynr = yn + grow * a.dim;
             for (int base = 0; base < nchunk; base += TPR * NB) {
@@ -282,10 +303,10 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
                         float v[VN], gv[VN], bv[VN];
                         if (one_batch) unpack16(raw[u], v, T());
                         else Vec<T>::load(yr + ch * VN, v);
-                        Vec<T>::load(gamma + ch * VN, gv);
-                        Vec<T>::load(beta + ch * VN, bv);
+                        Vec<T>::load(s_g + ch * VN, gv);
+                        Vec<T>::load(s_b + ch * VN, bv);
 #pragma unroll
-                        for (int e = 0; e < VN; e++) v[e] = (v[e] - mu) * rs * gv[e] + bv[e];
+                        for (int e = 0; e < VN; e++) v[e] = (v[e] - mu_r) * rs_r * gv[e] + bv[e];
                         Vec<T>::store(ynr + ch * VN, v);
                     }
                 }
@@ -293,7 +314,7 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
         }
     }
     FF_XTL(2);
-    __syncthreads();      // statistics + gamma / beta visible
+    __syncthreads();      // statistics visible
 
     // ---- q[m][n] = sum_k LN(y)[m][k] Wq[h*DH + n][k] ----
     f32x4 acc[NT];

@@ -13,7 +13,21 @@ import torch
 
 from . import ffi
 
-_grad_ready_callbacks: list = []   # called with the flat gradient buffer of a fused module right after its backward is enqueued
+# called as cb(flat, owners) right after the kernels that fill a fused module's flat gradient buffer are enqueued;
+# owners = [(parameter, offset in elements, numel)]: which slice of `flat` autograd was handed as that parameter's gradient
+_grad_ready_callbacks: list = []
+
+
+def _owners(params, flat=None):
+    offs, _ = _flat_offsets(params)
+    return [(p, o, p.numel()) for p, o in zip(params, offs)]
+
+
+def _announce(flat, params) -> None:
+    if _grad_ready_callbacks:
+        owners = _owners(params)
+        for cb in _grad_ready_callbacks:
+            cb(flat, owners)
 
 
 def add_grad_ready_callback(fn: Callable[[torch.Tensor], None]) -> None:
@@ -87,8 +101,7 @@ class _WgradQueue:
                                              ffi.ptr_array(params), grad_ptrs, ws.data_ptr(), ws.numel(), ffi.stream_handle(dev)),
                   "ff_xattn_wgrad_grouped")
         for e in group:
-            for cb in _grad_ready_callbacks:
-                cb(e["flat"])
+            _announce(e["flat"], e["own"])
         self.done.extend(group)
 
 
@@ -181,8 +194,7 @@ class _ResamplerFn(torch.autograd.Function):
         ffi.check(lib.ff_resampler_bwd(desc, x_f.data_ptr(), ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(),
                                        ffi.ptr_array(grads), ffi.ptr(dx_f), scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)),
                   "ff_resampler_bwd")
-        for cb in _grad_ready_callbacks:
-            cb(flat)
+        _announce(flat, params)
         return (dx_f, None, *grads)
 
 
@@ -243,8 +255,7 @@ class _XattnBlockFn(torch.autograd.Function):
         ffi.check(lib.ff_xattn_block_bwd(desc, y.data_ptr(), vf.data_ptr(), tt.data_ptr(), ffi.ptr_array(params), dout.data_ptr(),
                                          saved.data_ptr(), saved.numel(), ffi.ptr_array(grads), dy.data_ptr(), ffi.ptr(dvf),
                                          scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_bwd")
-        for cb in _grad_ready_callbacks:
-            cb(flat)
+        _announce(flat, params)
         return (dy, dvf, None, None, None, *grads)
 
 
@@ -281,8 +292,7 @@ class _KvProjectFn(torch.autograd.Function):
         ws = _empty_bytes(lib.ff_kv_project_workspace_bytes(desc, 1 if dvf is not None else 0), vf.device)
         ffi.check(lib.ff_kv_project_bwd(desc, vf.data_ptr(), ffi.ptr_array(weights), ffi.ptr_array(dkvs), ffi.ptr_array(grads), ffi.ptr(dvf),
                                         ws.data_ptr(), ws.numel(), ffi.stream_handle(vf.device)), "ff_kv_project_bwd")
-        for cb in _grad_ready_callbacks:
-            cb(flat)
+        _announce(flat, weights)
         return (dvf, *grads)
 
 
@@ -347,7 +357,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
             offs, _ = _flat_offsets(own)
             deferred = (4, 6, 9, 10)                       # attn.to_q, attn.to_out, ffw.1, ffw.3 in the block's parameter order
             own_index = {i: (i if i < _KV_PARAM else i - 1) for i in deferred}
-            _wgrad_queue.push(dict(key=key, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, flat=flat,
+            _wgrad_queue.push(dict(key=key, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, flat=flat, own=own,
                                    grad_ptrs=[None if g is None else g.data_ptr() for g in grads],
                                    wparams=[params[i] for i in deferred],
                                    wslices=[(offs[own_index[i]], params[i].numel()) for i in deferred]))
@@ -356,8 +366,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
                                             ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(), ffi.ptr_array(grads),
                                             dy.data_ptr(), dkv.data_ptr(), scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)),
                   "ff_xattn_block_bwd_kv")
-        for cb in _grad_ready_callbacks:
-            cb(flat)
+        _announce(flat, own)
         return (dy, dkv, None, None, None, *grads)
 
 

@@ -27,8 +27,7 @@ def _emit_flat(grads_np, keys, like):
     flat, views = F._flat_grads(like)
     for v, k in zip(views, keys):
         v.copy_(torch.from_numpy(np.asarray(grads_np[k])).to(v.dtype).reshape(v.shape))
-    for cb in F._grad_ready_callbacks:
-        cb(flat)
+    F._announce(flat, like)
     return tuple(views)
 
 
@@ -38,7 +37,7 @@ class _Rs(torch.autograd.Function):
         depth, heads, dim_head, q, nte, ffm, act = cfg
         p = dict(zip(rs_keys(depth), map(_np, params)))
         y, cache = O.resampler_fwd(_np(x), p, heads=heads, dim_head=dim_head, act=act)
-        ctx.stuff = (cache, p, cfg, x.dtype, [torch.empty_like(t) for t in params])
+        ctx.stuff = (cache, p, cfg, x.dtype, list(params))
         return torch.from_numpy(y).to(x.dtype)
 
     @staticmethod
@@ -55,7 +54,7 @@ class _Xa(torch.autograd.Function):
         p = dict(zip(XA_KEYS, map(_np, params)))
         ml = np.diff(tt.numpy().astype(np.int64), axis=1, prepend=0)       # text_time back to 0/1 tags
         out, kv, cache = O.gated_xattn_block_fwd(_np(y), _np(vf), ml, p, heads=heads, dim_head=dim_head, act=act, n_visual=n_visual)
-        ctx.stuff = (cache, p, cfg, y.dtype, [torch.empty_like(t) for t in params])
+        ctx.stuff = (cache, p, cfg, y.dtype, list(params))
         return torch.from_numpy(out).to(y.dtype), torch.from_numpy(kv[0]).to(y.dtype), torch.from_numpy(kv[1]).to(y.dtype)
 
     @staticmethod
@@ -87,8 +86,7 @@ class _KvProj(torch.autograd.Function):
             g2 = torch.zeros(rows.shape[0], w.shape[0], dtype=vf.dtype) if g is None else g.reshape(-1, w.shape[0])
             view.copy_(g2.t() @ rows)
             dvf += g2 @ w
-        for cb in F._grad_ready_callbacks:
-            cb(flat)
+        F._announce(flat, weights)
         return (dvf.reshape(vf.shape), *views)
 
 
@@ -102,7 +100,7 @@ class _XaHoisted(torch.autograd.Function):
         p = dict(zip(XA_KEYS, map(_np, params)))
         ml = np.diff(tt.numpy().astype(np.int64), axis=1, prepend=0)
         out, kv, cache = O.gated_xattn_block_fwd(_np(y), _np(kv4), ml, p, heads=heads, dim_head=dim_head, act=act, n_visual=n_visual)
-        ctx.stuff = (cache, p, cfg, y.dtype, [torch.empty_like(t) for i, t in enumerate(params) if i != 5])
+        ctx.stuff = (cache, p, cfg, y.dtype, [t for i, t in enumerate(params) if i != 5])
         return torch.from_numpy(out).to(y.dtype), torch.from_numpy(kv[0]).to(y.dtype), torch.from_numpy(kv[1]).to(y.dtype)
 
     @staticmethod

@@ -48,7 +48,7 @@ def _worker(rank, world, port, out_dir, hoist_kv):
     reducer = GradientAllReducer(model)
     buckets = []
     orig = reducer._on_bucket
-    reducer._on_bucket = lambda flat: (buckets.append(flat.numel()), orig(flat))[1]
+    reducer._on_bucket = lambda flat, owners=(): (buckets.append(flat.numel()), orig(flat, owners))[1]
     from flamingo_mini_amd import functional
     functional.remove_grad_ready_callback(orig)
     functional.add_grad_ready_callback(reducer._on_bucket)
@@ -56,7 +56,24 @@ def _worker(rank, world, port, out_dir, hoist_kv):
     _loss(model, z, [rank]).backward()            # each rank: one sequence of the 2-sequence batch
     reducer.finish()
     grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), nbuckets=len(buckets), **grads)
+    n_buckets = len(buckets)
+    # gradient accumulation over two micro-batches (here: the same sequence twice, each weighted 1/2): all but the last under no_sync();
+    # the result must equal the single-backward gradients above, and forgetting no_sync() must be an error, not silent divergence
+    model.zero_grad(set_to_none=True)
+    with reducer.no_sync():
+        (_loss(model, z, [rank]) / 2).backward()
+    (_loss(model, z, [rank]) / 2).backward()
+    reducer.finish()
+    acc = {"acc." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.requires_grad}
+    model.zero_grad(set_to_none=True)
+    (_loss(model, z, [rank]) / 2).backward()
+    caught = 0
+    try:
+        (_loss(model, z, [rank]) / 2).backward()
+    except RuntimeError as e:
+        caught = int("no_sync" in str(e))
+    reducer.pending.clear(); reducer.late.clear(); reducer._early.clear()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), nbuckets=n_buckets, caught=caught, **grads, **acc)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,11 +88,14 @@ def test_two_rank_gloo_matches_single_process(tmp_path, hoist_kv):
     model.zero_grad(set_to_none=True)
     ((_loss(model, z, [0]) + _loss(model, z, [1])) / 2).backward()
     n_hooks = len(model.flamingo.get_modified_layers())
-    # one flat bucket per xattn block + the resampler + the token embedding (loose hook) (+ all to_kv weights when hoisted)
-    assert int(r0["nbuckets"]) == n_hooks + 2 + int(hoist_kv)
+    # one flat bucket per xattn block + the resampler (+ all to_kv weights when hoisted); the token embedding goes through its own hook
+    assert int(r0["nbuckets"]) == n_hooks + 1 + int(hoist_kv)
     for k, p in model.named_parameters():
         if not p.requires_grad:
             continue
         ref = p.grad.numpy()
         assert np.array_equal(r0[k], r1[k]), k                                  # ranks agree bit-for-bit after the all-reduce
         assert np.linalg.norm(r0[k] - ref) <= 1e-12 * max(np.linalg.norm(ref), 1e-30) + 1e-18, k
+        assert np.array_equal(r0["acc." + k], r1["acc." + k]), k               # two accumulated micro-batches: same mean gradient
+        assert np.linalg.norm(r0["acc." + k] - ref) <= 1e-12 * max(np.linalg.norm(ref), 1e-30) + 1e-18, k
+    assert int(r0["caught"]) == 1 and int(r1["caught"]) == 1                   # accumulation without no_sync() is refused

@@ -75,7 +75,8 @@ def parse():
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"], help="fused = ff_adamw_step (this library), torch = torch.optim.AdamW(fused=True)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the step from a captured HIP graph (auto = on for 1 GPU; the all-reduce of N > 1 is not captured)")
+                    help="replay the step from a captured HIP graph (auto = on; at N > 1 the RCCL all-reduces are captured with it, and the "
+                         "step falls back to eager launches if that capture fails)")
     ap.add_argument("--profile-steps", type=int, default=3, help="instrumented eager steps after the timed region (roofline objects)")
     ap.add_argument("--stock-tuning", default="on", choices=["on", "off"],
                     help="load the pre-tuned hipBLASLt solution file for the stock CLIP / GPT-2 GEMMs (PyTorch TunableOp, tuning off)")
@@ -280,7 +281,7 @@ def main():
         model.flamingo.hoist_kv = args.hoist_kv == "on"
     params = [p for p in model.parameters_trainable()]
     n_trainable = sum(p.numel() for p in params)
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    use_graph = args.graph in ("on", "auto")
     if args.no_optimizer:
         opt = None
     elif args.optimizer == "fused":
@@ -323,10 +324,22 @@ def main():
             acc = [a + (t[i + 1] - t[i]) * 1e3 / 5 for i, a in enumerate(acc)]
         print("host ms/step: zero_grad %.2f forward %.2f backward %.2f optimizer %.2f drain %.2f" % tuple(acc), flush=True)
         return
-    if use_graph:       # forward + backward + optimizer captured once, one graph launch per step (flamingo_mini_amd/graphs.py)
+    graph_note = ""
+    if use_graph:       # forward + backward (+ gradient all-reduces) + optimizer captured once, one graph launch per step (flamingo_mini_amd/graphs.py)
         from flamingo_mini_amd import GraphedTrainStep
-        graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1))
-        step = graphed
+        try:
+            graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=reducer if world > 1 else None)
+            step = graphed
+        except Exception as e:      # e.g. a collective that cannot be captured on this software stack: run the same step eagerly
+            if world == 1 and args.graph == "on":
+                raise
+            graph_note = f"; graph capture failed ({type(e).__name__}: {str(e)[:120]}), eager launches instead"
+            torch.cuda.synchronize()
+            use_graph = False
+            if opt is not None and args.optimizer == "fused":
+                from flamingo_mini_amd import FusedAdamW
+                opt = FusedAdamW(params, lr=1e-4, capturable=False)
+            step = eager_step
     else:
         step = eager_step
 
@@ -411,7 +424,8 @@ def main():
                                    + f" + {args.seq_len} tokens per sequence, xattn_every {args.xattn_every}, "
                                    f"per-GPU batch {args.batch}; step = fwd + bwd + grad all-reduce"
                                    + ("" if args.no_optimizer else f" + AdamW ({args.optimizer})")
-                                   + ("; step replayed from a captured HIP graph" if use_graph else "; eager launches") + "; random-init weights, gates alpha=0.5",
+                                   + ("; step replayed from a captured HIP graph" + (" (RCCL all-reduces captured)" if world > 1 else "") if use_graph else "; eager launches")
+                                   + graph_note + "; random-init weights, gates alpha=0.5",
                        "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                        "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph, "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned},
             "roofline": roofline,

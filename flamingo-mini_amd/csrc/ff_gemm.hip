@@ -196,11 +196,6 @@ FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const
     FF_PIN(Q.scale); FF_PIN(Q.act); FF_PIN(Q.act_bwd); FF_PIN(Q.c_vec8); FF_PIN(Q.partial);                                           \
     FF_PIN(pr.A); FF_PIN(pr.B); FF_PIN(pr.C); FF_PIN(pr.aux_out); FF_PIN(pr.aux_in); FF_PIN(pr.residual); FF_PIN(pr.gate)
 
-// XCD-aware tile order: consecutive logical tiles (same A row panel) land on the same XCD / L2.
-FF_DEV int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 struct TileCoord {
     int z, split, tm, tn;

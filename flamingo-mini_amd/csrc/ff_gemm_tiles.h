@@ -5,6 +5,13 @@
 
 namespace ff {
 
+// XCD-aware work order: workgroup b runs on XCD b % 8 (observed, used for speed only); the remap hands every XCD a contiguous chunk
+// of the logical work list (bijective for any size), so neighbours in the list share an L2.
+FF_DEV int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 kernel
 // ------------------------------------------------------------------------------------------------
@@ -27,29 +34,30 @@ template <int BR> FF_DEV int mswz(int k) {      // chunk XOR of k-row `k` in an 
     return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);
 }
 
-template <int BR, int LAYOUT>
+// NW = number of waves that share the issue of a tile (w = 0 .. NW-1 among them); 4 = the whole workgroup.
+template <int BR, int LAYOUT, int NW = 4>
 FF_DEV void dma_tile(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const RowMap& map, int row_base, int row_lim, int k0, int k_end, int w, int l) {
     if (LAYOUT == 0) {   // wave instruction = 8 rows x 128 B
         const int cp = l & 7;
 #pragma unroll
-        for (int p = 0; p < BR / 32; p++) {
-            const int row = p * 32 + w * 8 + (l >> 3);
+        for (int p = 0; p < BR / (NW * 8); p++) {
+            const int row = p * (NW * 8) + w * 8 + (l >> 3);
             const int k = k0 + ((cp ^ (row & 7)) << 3);
             unsigned off = kOobOffset;
             if (row_base + row < row_lim && k < k_end) off = (unsigned)(map.off(row_base + row) + k) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + (p * 32 + w * 8) * kBK), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + (p * (NW * 8) + w * 8) * kBK), 16, off, 0, 0, 0);
         }
     } else {             // wave instruction = 1 KiB of consecutive k-rows (BR*2 bytes each)
         constexpr int CPR = BR / 8;            // 16-byte chunks per k-row
         constexpr int RPI = 64 / CPR;          // k-rows per wave instruction
         const int cp = l % CPR;
 #pragma unroll
-        for (int p = 0; p < kBK / (4 * RPI); p++) {
-            const int kr = p * 4 * RPI + w * RPI + l / CPR;
+        for (int p = 0; p < kBK / (NW * RPI); p++) {
+            const int kr = p * NW * RPI + w * RPI + l / CPR;
             const int col = row_base + ((cp ^ mswz<BR>(kr)) << 3);
             unsigned off = (unsigned)(map.off(min(k0 + kr, k_end - 1)) + col) * 2u;
             if (k0 + kr >= k_end || col >= row_lim) off = kOobOffset;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + (p * 4 * RPI + w * RPI) * BR), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + (p * NW * RPI + w * RPI) * BR), 16, off, 0, 0, 0);
         }
     }
 }
@@ -57,32 +65,32 @@ FF_DEV void dma_tile(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const RowMap& map
 
 // Fast path of dma_tile for k-steps that lie fully inside [k_begin, k_end) (and plain row maps for M-major operands):
 // the per-lane byte offsets are loop invariants computed once; a k-step only advances the scalar soffset.
-template <int BR, int LAYOUT>
+template <int BR, int LAYOUT, int NW = 4>
 FF_DEV void dma_prepare(const RowMap& map, int row_base, int row_lim, int w, int l, unsigned* voff) {
     if (LAYOUT == 0) {
         const int cp = l & 7;
 #pragma unroll
-        for (int p = 0; p < BR / 32; p++) {
-            const int row = p * 32 + w * 8 + (l >> 3);
+        for (int p = 0; p < BR / (NW * 8); p++) {
+            const int row = p * (NW * 8) + w * 8 + (l >> 3);
             voff[p] = row_base + row < row_lim ? (unsigned)map.off(row_base + row) * 2u + (unsigned)((cp ^ (row & 7)) << 4) : kOobOffset;
         }
     } else {
         constexpr int CPR = BR / 8, RPI = 64 / CPR;
         const int cp = l % CPR;
 #pragma unroll
-        for (int p = 0; p < BR / 32; p++) {
-            const int kr = p * 4 * RPI + w * RPI + l / CPR;
+        for (int p = 0; p < BR / (NW * 8); p++) {
+            const int kr = p * NW * RPI + w * RPI + l / CPR;
             const int col = row_base + ((cp ^ mswz<BR>(kr)) << 3);
             voff[p] = col < row_lim ? (unsigned)((long long)kr * map.ld + col) * 2u : kOobOffset;
         }
     }
 }
-template <int BR, int LAYOUT>
+template <int BR, int LAYOUT, int NW = 4>
 FF_DEV void dma_tile_fast(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const unsigned* voff, unsigned soff, int w) {
-    constexpr int ROWS_PER_PASS_ELEMS = LAYOUT == 0 ? 32 * kBK : (4 * (64 / (BR / 8))) * BR;   // LDS elements covered by one pass of 4 waves
-    constexpr int WAVE_ELEMS = ROWS_PER_PASS_ELEMS / 4;
+    constexpr int ROWS_PER_PASS_ELEMS = LAYOUT == 0 ? (NW * 8) * kBK : (NW * (64 / (BR / 8))) * BR;   // LDS elements covered by one pass of the NW waves
+    constexpr int WAVE_ELEMS = ROWS_PER_PASS_ELEMS / NW;
 #pragma unroll
-    for (int p = 0; p < BR / 32; p++)
+    for (int p = 0; p < BR / (NW * 8); p++)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + p * ROWS_PER_PASS_ELEMS + w * WAVE_ELEMS), 16, voff[p], soff, 0, 0);
 }
 

@@ -21,8 +21,7 @@ namespace ff {
 
 #ifdef FF_XA_TIMELINE   // debug build: per-workgroup phase timestamps (100 MHz constant clock), read with ff_debug_xa_timeline_read
 __device__ unsigned long long g_xa_timeline[4096 * 8];
-#define FF_XTL(i) do { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
-                       if (threadIdx.x == 0 && wg_ < 4096) g_xa_timeline[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FF_XTL(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_xa_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FF_XTL(i) do { } while (0)
 #endif
@@ -99,34 +98,47 @@ template <int PER_TILE, int MAXY> FF_DEV void wait_tiles(int younger) {
     }
 }
 
-// D[n][m] += B_tile[n][k] * A_tile[m][k] over k = [0, dim) for the wave's 16 rows m of the A tile and all DH columns n, operands
-// through the LDS-DMA ring.  `transform(fa, kk)` is applied to every A fragment (8 consecutive k starting at kk) - the LayerNorm
-// prologue of the forward kernel.  BL: layout of the B operand (0: stored [DH][dim], 1: stored [dim][ldb], columns n_base..).
+// D[n][m] += B_tile[n][k] * A_tile[m][k] over k = [0, dim) (dim % 64 == 0) for the wave's 16 rows m of the A tile and all DH columns n,
+// operands through the LDS-DMA ring.  `transform(fa, kk)` is applied to every A fragment (8 consecutive k starting at kk) - the
+// LayerNorm prologue of the forward kernel.  BL: layout of the B operand (0: stored [DH][dim], 1: stored [dim][ldb], columns n_base..).
+// A 32-row tile has MFMA work for two waves only: those two compute, the other two are the tile's DMA engine (issuing a tile piece
+// costs an in-order wave 100+ cycles, which would otherwise sit on the compute waves' critical path).
 template <int DH, int BM, int NS, int BL, typename F>
 FF_DEV void project_bf16(bf16* ring, const bf16* Ab, long long lda, int row0, int row_lim, const bf16* Bb, long long ldb, int n_base, int n_lim,
                          int dim, int w, int l, f32x4 (&acc)[DH / 16], F transform) {
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = DH * kBK, STAGE = A_ELEMS + B_ELEMS, NT = DH / 16;
-    constexpr int PER_TILE = BM / 32 + DH / 32;
+    constexpr int NWC = BM / 16;                            // computing waves (16 rows each)
+    constexpr int NWP = NWC == 4 ? 4 : 4 - NWC;             // issuing waves: everybody, or the waves without rows
+    constexpr int PA = BM / (NWP * 8), PB = DH / (NWP * 8), PER_TILE = PA + PB;      // DMA instructions per issuing wave per k-step
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
+    const bool computes = w < NWC, issues = NWC == 4 || w >= NWC;          // wave-uniform
+    const int wp = NWC == 4 ? w : w - NWC;
     const RowMap a_map{lda, 0, 0}, b_map{ldb, 0, 0};
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7fffffff, 0x00020000);
-    const int nk = (dim + kBK - 1) / kBK;
+    const int nk = dim / kBK;
+    unsigned va[PA], vb[PB];
+    if (issues) {
+        dma_prepare<BM, 0, NWP>(a_map, row0, row_lim, wp, l, va);
+        dma_prepare<DH, BL, NWP>(b_map, n_base, n_lim, wp, l, vb);
+    }
+    const unsigned b_step = BL == 0 ? 2u : (unsigned)ldb * 2u;             // bytes per unit of k
     auto issue = [&](int tile) {
         bf16* st = ring + (tile % NS) * STAGE;
-        const int k0 = tile * kBK;
-        dma_tile<BM, 0>(ra, st, a_map, row0, row_lim, k0, dim, w, l);
-        dma_tile<DH, BL>(rb, st + A_ELEMS, b_map, n_base, n_lim, k0, dim, w, l);
+        const unsigned k0 = (unsigned)tile * kBK;
+        dma_tile_fast<BM, 0, NWP>(ra, st, va, k0 * 2u, wp);
+        dma_tile_fast<DH, BL, NWP>(rb, st + A_ELEMS, vb, k0 * b_step, wp);
     };
+    if (issues) {
 #pragma unroll
-    for (int s = 0; s < NS - 1; s++)
-        if (s < nk) issue(s);
-    const bool active = w * 16 < BM;        // wave-uniform: a 32-row tile keeps two waves as DMA helpers only
+        for (int s = 0; s < NS - 1; s++)
+            if (s < nk) issue(s);
+    }
     for (int kt = 0; kt < nk; kt++) {
-        wait_tiles<PER_TILE, NS - 2>(min(nk - 1 - kt, NS - 2));
+        if (issues) wait_tiles<PER_TILE, NS - 2>(min(nk - 1 - kt, NS - 2));
         __builtin_amdgcn_s_barrier();       // tile kt is in LDS for everyone; stage (kt - 1) % NS is free
-        if (kt + NS - 1 < nk) issue(kt + NS - 1);
-        if (active) {
+        if (issues && kt + NS - 1 < nk) issue(kt + NS - 1);
+        if (computes) {
             const bf16* sA = ring + (kt % NS) * STAGE;
             const bf16* sB = sA + A_ELEMS;
 #pragma unroll
@@ -138,6 +150,7 @@ FF_DEV void project_bf16(bf16* ring, const bf16* Ab, long long lda, int row0, in
             }
         }
     }
+    if (NWC != 4) wait_vmcnt<0>();          // (issuing waves: nothing of theirs is in flight any more; keeps the tail uniform)
 }
 
 // acc[j][r] = value (row m = w*16 + c, column j*16 + g*4 + r) -> LDS tile in layout L
@@ -180,7 +193,10 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
     typedef typename StageOf<T, DH, FAST>::type St;
     typedef typename St::L L;
     typedef Carve<T, DH, BM, NS, 1, 2, 2> CV;        // parks Q; K, V tiles
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // work list = (sample, query tile, head) with the head fastest: the workgroups that read the same rows of y / dy1 sit on one XCD
+    const int n_qt = (a.n_q + BM - 1) / BM;
+    const int lin = xcd_remap(blockIdx.x, n_qt * a.heads * a.batch);
+    const int h = lin % a.heads, qt = (lin / a.heads) % n_qt, b = lin / (a.heads * n_qt);
     const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int row0 = qt * BM;
@@ -204,12 +220,11 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
     const T* yr = y + grow * a.dim;
     const int nchunk = a.dim / VN;
     const bool one_batch = nchunk <= TPR * NB;
+    const int ppt = nchunk / TPR;             // pieces per thread: the same for every thread of a row (dim % (8 * VN) == 0)
     uint4 raw[NB];
 #pragma unroll
-    for (int u = 0; u < NB; u++) {
-        const int ch = sub + u * TPR;
-        if (ch < nchunk) raw[u] = *(const uint4*)(yr + ch * VN);
-    }
+    for (int u = 0; u < NB; u++)
+        if (u < ppt) raw[u] = *(const uint4*)(yr + (sub + u * TPR) * VN);
     uint4 gb_raw[2];
     const int gb_chunks = dimp / VN;          // gamma pieces, then beta pieces; zero past `dim`
 #pragma unroll
@@ -255,12 +270,11 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
     {
         float x0 = 0.f, s1 = 0.f, s2 = 0.f;
         for (int base = 0; base < nchunk; base += TPR * NB) {
+            const int left = ppt - base / TPR;           // wave-uniform
             if (base > 0) {
 #pragma unroll
-                for (int u = 0; u < NB; u++) {
-                    const int ch = base + sub + u * TPR;
-                    if (ch < nchunk) raw[u] = *(const uint4*)(yr + ch * VN);
-                }
+                for (int u = 0; u < NB; u++)
+                    if (u < left) raw[u] = *(const uint4*)(yr + (base + sub + u * TPR) * VN);
             } else {
                 float first[VN];
                 unpack16(raw[0], first, T());
@@ -268,8 +282,7 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
             }
 #pragma unroll
             for (int u = 0; u < NB; u++) {
-                const int ch = base + sub + u * TPR;
-                if (ch < nchunk) {
+                if (u < left) {
                     float v[VN];
                     unpack16(raw[u], v, T());
 #pragma unroll
@@ -296,10 +309,11 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
         if (rok && yn) {
             T* ynr = yn + grow * a.dim;
             for (int base = 0; base < nchunk; base += TPR * NB) {
+                const int left = ppt - base / TPR;
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
                     const int ch = base + sub + u * TPR;
-                    if (ch < nchunk && (u % a.heads) == h) {                 // this head's share of the row's pieces
+                    if (u < left && (u % a.heads) == h) {                    // this head's share of the row's pieces
                         float v[VN], gv[VN], bv[VN];
                         if (one_batch) unpack16(raw[u], v, T());
                         else Vec<T>::load(yr + ch * VN, v);
@@ -388,7 +402,10 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
     typedef typename StageOf<T, DH, FAST>::type St;
     typedef typename St::L L;
     typedef Carve<T, DH, BM, NS, 1, 3, 4> CV;        // parks dO; Q, K, V tiles (+ O on the DMA path)
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // work list = (sample, query tile, head) with the head fastest: the workgroups that read the same rows of y / dy1 sit on one XCD
+    const int n_qt = (a.n_q + BM - 1) / BM;
+    const int lin = xcd_remap(blockIdx.x, n_qt * a.heads * a.batch);
+    const int h = lin % a.heads, qt = (lin / a.heads) % n_qt, b = lin / (a.heads * n_qt);
     const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int row0 = qt * BM;
@@ -526,8 +543,9 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
 // host side
 // =====================================================================================================
 bool xa_fused_supported(int dtype, int dim_head, int dim, int inner) {
-    if (dtype == FF_DTYPE_BF16) return (dim_head == 64 || dim_head == 128) && dim % 8 == 0 && inner % 8 == 0;
-    if (dtype == FF_DTYPE_F32) return (dim_head == 16 || dim_head == 32 || dim_head == 64 || dim_head == 128) && dim % 4 == 0 && inner % 4 == 0;
+    // the LayerNorm pass hands every thread of a row the same number of 16-byte pieces: dim % (8 threads x elements per piece) == 0
+    if (dtype == FF_DTYPE_BF16) return (dim_head == 64 || dim_head == 128) && dim % 64 == 0 && inner % 8 == 0;
+    if (dtype == FF_DTYPE_F32) return (dim_head == 16 || dim_head == 32 || dim_head == 64 || dim_head == 128) && dim % 32 == 0 && inner % 4 == 0;
     return false;
 }
 
@@ -569,7 +587,7 @@ static int launch_fwd(const XaFusedArgs& a, const void* y, const void* gamma, co
     const size_t lds = fwd_lds<T, DH, BM>(a.dim);
     auto kernel = xa_qattn_fwd_kernel<T, DH, BM>;
     FF_TRY(allow_lds(kernel, lds, "xa_qattn_fwd"));
-    const dim3 grid(cdiv(a.n_q, BM), a.heads, a.batch);
+    const dim3 grid(cdiv(a.n_q, BM) * a.heads * a.batch);
     kernel<<<grid, dim3(256), lds, st>>>(a, (const T*)y, (const T*)gamma, (const T*)beta, (const T*)Wq, (const T*)K, (const T*)V, tt, (T*)yn, (T*)Qs,
                                          (T*)O, mean, rstd, lse);
     return check_launch("xa_qattn_fwd");
@@ -593,7 +611,7 @@ static int launch_bwd(const XaFusedArgs& a, const void* dy1, const void* Wo, con
     const size_t lds = bwd_lds<T, DH, BM>();
     auto kernel = xa_dattn_bwd_kernel<T, DH, BM, SINGLE>;
     FF_TRY(allow_lds(kernel, lds, "xa_dattn_bwd"));
-    const dim3 grid(cdiv(a.n_q, BM), a.heads, a.batch);
+    const dim3 grid(cdiv(a.n_q, BM) * a.heads * a.batch);
     kernel<<<grid, dim3(256), lds, st>>>(a, (const T*)dy1, (const T*)Wo, (const T*)gate, (const T*)Qs, (const T*)K, (const T*)V, tt, (const T*)O, lse,
                                          (T*)dO, (T*)dQ, (T*)dK, (T*)dV, Dsum);
     return check_launch("xa_dattn_bwd");

@@ -81,7 +81,8 @@ class GradientAllReducer:
         if self.cuda:
             ready = torch.cuda.Event()
             ready.record()                                   # after the kernels producing `flat` on the compute stream
-            flat.record_stream(self.stream)
+            if not torch.cuda.is_current_stream_capturing():
+                flat.record_stream(self.stream)              # (inside a graph capture all memory is the graph's own static pool)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
                 work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)

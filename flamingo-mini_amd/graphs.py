@@ -10,8 +10,10 @@ allocation, no host synchronisation), so forward + backward + optimizer can be c
 
 Requirements: fixed shapes, an optimizer whose step is capture-safe (FusedAdamW(capturable=True) or
 torch.optim.AdamW(capturable=True)), and no data-dependent host control flow in the model (true for FlamingoModel's
-training forward).  Gradient all-reduce (data_parallel.GradientAllReducer) is not captured: with more than one rank use the
-eager step.
+training forward).  With `reducer=` (data_parallel.GradientAllReducer) the gradient all-reduces are part of the capture: they are
+issued on the reducer's side stream, which forks from and rejoins the capturing stream through events, so the replayed graph
+contains the RCCL kernels and their overlap with backward (PyTorch captures NCCL / RCCL collectives; the communicator must already
+exist, which the eager warm-up steps guarantee).
 """
 from __future__ import annotations
 
@@ -22,10 +24,10 @@ import torch
 
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
-                 warmup: int = 3, loss_fn: Optional[Callable] = None):
+                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a GPU")
-        self.model, self.optimizer = model, optimizer
+        self.model, self.optimizer, self.reducer = model, optimizer, reducer
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self._loss_fn = loss_fn or (lambda out: out.loss)
         side = torch.cuda.Stream()
@@ -45,6 +47,8 @@ class GraphedTrainStep:
         self.model.zero_grad(set_to_none=True)              # gradients are re-created (not accumulated) by every backward
         loss = self._loss_fn(self.model(**self.static))
         loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()                           # the capturing stream waits for the collectives before the optimizer reads .grad
         if self.optimizer is not None:
             self.optimizer.step()
         return loss

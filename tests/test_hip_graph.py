@@ -58,3 +58,95 @@ def test_graph_replay_equals_eager_steps(dtype):
     for (n, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
         assert rel(pg, pe) < (1e-4 if dtype == torch.float32 else 3e-2), n
     assert {float(s["step"]) for s in opt_g.state_dict()["state"].values()} == {6.0}
+
+
+class _ToyHoisted(torch.nn.Module):
+    """Resampler + two gated blocks on K / V projected up front (the training layout of FlamingoModel): exercises the deferred,
+    grouped weight gradients and every kind of gradient bucket the reducer sees."""
+
+    def __init__(self):
+        super().__init__()
+        from flamingo_mini_amd import GatedCrossAttentionBlock, PerceiverResampler
+        self.resampler = PerceiverResampler(dim=64, depth=1, heads=2, dim_head=32, num_latents=8, num_time_embeds=2)
+        self.blocks = torch.nn.ModuleList(GatedCrossAttentionBlock(dim=64, dim_visual=64, dim_head=32, heads=2, n_visual=8) for _ in range(2))
+        self.loose = torch.nn.Parameter(torch.ones(64))          # an un-fused trainable parameter (the token embedding's role)
+        with torch.no_grad():
+            for b in self.blocks:
+                b.alpha_attn.fill_(0.5)
+                b.alpha_ffw.fill_(-0.25)
+
+    def forward(self, x_f, y, media_locations):
+        from flamingo_mini_amd import functional as F
+        vf = self.resampler(x_f).unsqueeze(1)
+        kvs = F.kv_project(vf, [b.attn.to_kv.weight for b in self.blocks])
+        h = y * self.loose
+        for b, kv in zip(self.blocks, kvs):
+            h, _ = b(h, vf, media_locations, hoisted_kv=kv)
+        return h.float().pow(2).mean()
+
+
+@pytest.fixture
+def one_rank_rccl():
+    import os
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_rccl_reducer_on_one_rank_eager_and_captured(one_rank_rccl, dtype):
+    """The NCCL (= RCCL) branch of GradientAllReducer on a 1-rank group: side-stream all-reduces (ReduceOp.AVG) issued from inside
+    backward, joined by finish(); then the same step captured into a HIP graph WITH its collectives and replayed.  On one rank the
+    average is the identity, so all three variants must produce the same losses and parameters."""
+    from flamingo_mini_amd import FusedAdamW, GraphedTrainStep
+    from flamingo_mini_amd.data_parallel import GradientAllReducer
+    torch.manual_seed(0)
+    plain = _ToyHoisted().cuda().to(dtype)
+    reduced, graphed = copy.deepcopy(plain), copy.deepcopy(plain)
+    ml = torch.zeros(2, 16, dtype=torch.int64, device="cuda"); ml[:, 0] = 1
+    batches = [dict(x_f=dev(rnd((2, 1, 24, 64), 30 + i), dtype), y=dev(rnd((2, 16, 64), 40 + i), dtype), media_locations=ml) for i in range(5)]
+
+    def eager_steps(model, reducer):
+        opt = FusedAdamW(model.parameters(), lr=1e-2)
+        out = []
+        for b in batches:
+            model.zero_grad(set_to_none=True)
+            loss = model(**b)
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            opt.step()
+            out.append(float(loss))
+        return out
+
+    base = eager_steps(plain, None)
+    r1 = GradientAllReducer(reduced, force_collectives=True)
+    assert r1.cuda and r1.active
+    calls = []
+    orig = r1._reduce_async
+    r1._reduce_async = lambda flat, owners: (calls.append(flat.numel()), orig(flat, owners))[1]
+    with_rccl = eager_steps(reduced, r1)
+    r1.close()
+    assert len(calls) == 5 * 5          # per step: resampler, to_kv bucket, 2 blocks, the loose parameter
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    for a, b in zip(base, with_rccl):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), (base, with_rccl)
+    for (n, pa), (_, pb) in zip(plain.named_parameters(), reduced.named_parameters()):
+        assert rel(pb, pa) < (1e-5 if dtype == torch.float32 else 2e-2), n
+
+    r2 = GradientAllReducer(graphed, force_collectives=True)
+    opt_g = FusedAdamW(graphed.parameters(), lr=1e-2, capturable=True)
+    step = GraphedTrainStep(graphed, opt_g, batches[0], warmup=1, loss_fn=lambda out: out, reducer=r2)     # one eager step on batch 0, then the capture
+    replayed = [None] + [float(step(b)) for b in batches[1:]]
+    r2.close()
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    for a, b in zip(base[1:], replayed[1:]):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), (base, replayed)
+    for (n, pa), (_, pb) in zip(plain.named_parameters(), graphed.named_parameters()):
+        assert rel(pb, pa) < (1e-4 if dtype == torch.float32 else 3e-2), n

@@ -4,6 +4,7 @@
 //     p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // Reference training recipe: `--optim adamw_torch`, lr 1e-4 (training/train.sh:10-13).  HBM-bound: 7 streams per element.
 #include <algorithm>
+#include <type_traits>
 #include "ff_common.h"
 #include "ff_internal.h"
 
@@ -17,14 +18,19 @@ struct AdamTable {
     const void* g[kAdamTensors];
     void* m[kAdamTensors];
     void* v[kAdamTensors];
+    float* w[kAdamTensors];  // fp32 master copies of the parameters (mixed-precision mode), else unused
     long long n[kAdamTensors];
     int block_start[kAdamTensors + 1];
     int count;
     float lr, beta1, beta2, eps, decay, bc1, bc2_sqrt, grad_scale;
     const float* step_dev;   // capturable mode: the step count lives on the device (HIP-graph replays cannot change kernel arguments)
+    const float* lr_dev;     // ... and so does the learning rate, when a scheduler is to stay effective under replay
 };
 
-template <typename T, int VEC>
+// T: storage type of the parameters' compute copy and of the gradients; ST: storage type of the two moments; MASTER: the update
+// is applied to an fp32 master copy (t.w) and the compute copy is its rounding - what `--fp16` / bf16 autocast training keeps
+// (training/train.sh:24), so that steps far below bf16 resolution of a weight (lr 1e-4) are not lost.
+template <typename T, typename ST, bool MASTER, int VEC>
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
     int ti = 0;
 #pragma unroll 1
@@ -33,25 +39,51 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
     const long long base = (long long)((int)blockIdx.x - t.block_start[ti]) * kAdamChunk;
     T* p = (T*)t.p[ti];
     const T* g = (const T*)t.g[ti];
-    T* m = (T*)t.m[ti];
-    T* v = (T*)t.v[ti];
+    ST* m = (ST*)t.m[ti];
+    ST* v = (ST*)t.v[ti];
+    float* w = t.w[ti];
     float bc1 = t.bc1, bc2_sqrt = t.bc2_sqrt;
     if (t.step_dev) {
         const float step = *t.step_dev;
         bc1 = 1.f - powf(t.beta1, step);
         bc2_sqrt = sqrtf(1.f - powf(t.beta2, step));
     }
-    const float step_size = t.lr / bc1, keep = 1.f - t.lr * t.decay;
-    const bool vec = VEC > 1 && n % VEC == 0 && ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0;
+    const float lr = t.lr_dev ? *t.lr_dev : t.lr;
+    const float step_size = lr / bc1, keep = 1.f - lr * t.decay;
+    bool vec = VEC > 1 && n % VEC == 0 && ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0;
+    if (MASTER) vec = vec && (uintptr_t)w % 16 == 0;
+    auto ldv = [&](auto* q, long long i, float (&o)[VEC]) {      // VEC consecutive elements of any storage type as floats
+        typedef std::remove_cv_t<std::remove_pointer_t<decltype(q)>> Q;
+        constexpr int QN = Vec<Q>::N;
+#pragma unroll
+        for (int c = 0; c < VEC / QN; c++) {
+            float part[QN];
+            Vec<Q>::load(q + i + c * QN, part);
+#pragma unroll
+            for (int e = 0; e < QN; e++) o[c * QN + e] = part[e];
+        }
+    };
+    auto stv = [&](auto* q, long long i, const float (&o)[VEC]) {
+        typedef std::remove_pointer_t<decltype(q)> Q;
+        constexpr int QN = Vec<Q>::N;
+#pragma unroll
+        for (int c = 0; c < VEC / QN; c++) {
+            float part[QN];
+#pragma unroll
+            for (int e = 0; e < QN; e++) part[e] = o[c * QN + e];
+            Vec<Q>::store(q + i + c * QN, part);
+        }
+    };
     for (long long i = base + (long long)threadIdx.x * VEC; i < min(n, base + kAdamChunk); i += 256 * VEC) {
         float pf[VEC], gf[VEC], mf[VEC], vf[VEC];
         if (vec) {
-            Vec<T>::load(p + i, pf); Vec<T>::load(g + i, gf); Vec<T>::load(m + i, mf); Vec<T>::load(v + i, vf);
+            if (MASTER) ldv(w, i, pf); else ldv(p, i, pf);
+            ldv(g, i, gf); ldv(m, i, mf); ldv(v, i, vf);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; e++) {
                 const bool ok = i + e < n;
-                pf[e] = ok ? to_f32(p[i + e]) : 0.f; gf[e] = ok ? to_f32(g[i + e]) : 0.f;
+                pf[e] = ok ? (MASTER ? w[i + e] : to_f32(p[i + e])) : 0.f; gf[e] = ok ? to_f32(g[i + e]) : 0.f;
                 mf[e] = ok ? to_f32(m[i + e]) : 0.f; vf[e] = ok ? to_f32(v[i + e]) : 0.f;
             }
         }
@@ -64,26 +96,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
             pf[e] -= step_size * mf[e] / (sqrtf(vf[e]) / bc2_sqrt + t.eps);
         }
         if (vec) {
-            Vec<T>::store(p + i, pf); Vec<T>::store(m + i, mf); Vec<T>::store(v + i, vf);
+            stv(p, i, pf); stv(m, i, mf); stv(v, i, vf);
+            if (MASTER) stv(w, i, pf);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; e++)
-                if (i + e < n) { p[i + e] = from_f32<T>(pf[e]); m[i + e] = from_f32<T>(mf[e]); v[i + e] = from_f32<T>(vf[e]); }
+                if (i + e < n) {
+                    p[i + e] = from_f32<T>(pf[e]); m[i + e] = from_f32<ST>(mf[e]); v[i + e] = from_f32<ST>(vf[e]);
+                    if (MASTER) w[i + e] = pf[e];
+                }
         }
     }
 }
 
-}  // namespace ff
-
-extern "C" int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const void* const* grads, void* const* exp_avg,
-                             void* const* exp_avg_sq, const long long* numels, ff_stream_t stream) {
-    using namespace ff;
+static int adamw_launch(const ff_adamw_desc* d, int state_dtype, void* const* params, const void* const* grads, void* const* exp_avg,
+                        void* const* exp_avg_sq, float* const* master, const float* lr_dev, const long long* numels, hipStream_t stream) {
     FF_CHECK(d && params && grads && exp_avg && exp_avg_sq && numels, FF_ERR_SHAPE, "ff_adamw_step: null argument");
     FF_CHECK(d->dtype == FF_DTYPE_F32 || d->dtype == FF_DTYPE_BF16, FF_ERR_UNSUPPORTED, "ff_adamw_step: dtype %d", d->dtype);
+    FF_CHECK(state_dtype == d->dtype || state_dtype == FF_DTYPE_F32, FF_ERR_UNSUPPORTED, "ff_adamw_step: moments must be stored in the parameter dtype or in fp32");
+    FF_CHECK(!master || d->dtype == FF_DTYPE_BF16, FF_ERR_UNSUPPORTED, "ff_adamw_step: fp32 master copies go with bf16 parameters");
     FF_CHECK(d->n_tensors >= 0 && (d->step >= 1 || d->step_dev), FF_ERR_SHAPE, "ff_adamw_step: n_tensors=%d step=%d", d->n_tensors, d->step);
     AdamTable t;
     t.lr = d->lr; t.beta1 = d->beta1; t.beta2 = d->beta2; t.eps = d->eps; t.decay = d->weight_decay;
     t.step_dev = d->step_dev;
+    t.lr_dev = lr_dev;
     t.bc1 = 1.f - powf(d->beta1, (float)std::max(d->step, 1));
     t.bc2_sqrt = sqrtf(1.f - powf(d->beta2, (float)std::max(d->step, 1)));
     t.grad_scale = d->grad_scale == 0.f ? 1.f : d->grad_scale;
@@ -92,8 +128,9 @@ extern "C" int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const 
         int cnt = 0, blocks = 0;
         while (i < d->n_tensors && cnt < kAdamTensors) {
             if (numels[i] > 0) {
-                FF_CHECK(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i], FF_ERR_SHAPE, "ff_adamw_step: tensor %d has a null pointer", i);
+                FF_CHECK(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i] && (!master || master[i]), FF_ERR_SHAPE, "ff_adamw_step: tensor %d has a null pointer", i);
                 t.p[cnt] = params[i]; t.g[cnt] = grads[i]; t.m[cnt] = exp_avg[i]; t.v[cnt] = exp_avg_sq[i]; t.n[cnt] = numels[i];
+                t.w[cnt] = master ? master[i] : nullptr;
                 t.block_start[cnt] = blocks;
                 blocks += cdiv(numels[i], kAdamChunk);
                 cnt++;
@@ -103,9 +140,26 @@ extern "C" int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const 
         if (!cnt) break;
         t.block_start[cnt] = blocks;
         t.count = cnt;
-        if (d->dtype == FF_DTYPE_BF16) adamw_kernel<bf16, 8><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(t);
-        else adamw_kernel<float, 4><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(t);
+        const dim3 grid(blocks), block(256);
+        if (d->dtype == FF_DTYPE_F32) adamw_kernel<float, float, false, 4><<<grid, block, 0, stream>>>(t);
+        else if (master) {
+            FF_CHECK(state_dtype == FF_DTYPE_F32, FF_ERR_UNSUPPORTED, "ff_adamw_step: fp32 master copies go with fp32 moments");
+            adamw_kernel<bf16, float, true, 8><<<grid, block, 0, stream>>>(t);
+        } else if (state_dtype == FF_DTYPE_F32) adamw_kernel<bf16, float, false, 8><<<grid, block, 0, stream>>>(t);
+        else adamw_kernel<bf16, bf16, false, 8><<<grid, block, 0, stream>>>(t);
         FF_TRY(check_launch("adamw"));
     }
     return FF_OK;
+}
+
+}  // namespace ff
+
+extern "C" int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const void* const* grads, void* const* exp_avg,
+                             void* const* exp_avg_sq, const long long* numels, ff_stream_t stream) {
+    return ff::adamw_launch(d, d ? d->dtype : 0, params, grads, exp_avg, exp_avg_sq, nullptr, nullptr, numels, (hipStream_t)stream);
+}
+extern "C" int ff_adamw_step_mixed(const ff_adamw_desc* d, int state_dtype, void* const* params, const void* const* grads, void* const* exp_avg,
+                                   void* const* exp_avg_sq, float* const* master, const float* lr_dev, const long long* numels,
+                                   ff_stream_t stream) {
+    return ff::adamw_launch(d, state_dtype, params, grads, exp_avg, exp_avg_sq, master, lr_dev, numels, (hipStream_t)stream);
 }

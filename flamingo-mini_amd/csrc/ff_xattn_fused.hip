@@ -99,20 +99,29 @@ template <int PER_TILE, int MAXY> FF_DEV void wait_tiles(int younger) {
 }
 
 // D[n][m] += B_tile[n][k] * A_tile[m][k] over k = [0, dim) (dim % 64 == 0) for the wave's 16 rows m of the A tile and all DH columns n,
-// operands through the LDS-DMA ring.  `transform(fa, kk)` is applied to every A fragment (8 consecutive k starting at kk) - the
-// LayerNorm prologue of the forward kernel.  BL: layout of the B operand (0: stored [DH][dim], 1: stored [dim][ldb], columns n_base..).
+// operands through the LDS-DMA ring.  BL: layout of the B operand (0: stored [DH][dim], 1: stored [dim][ldb], columns n_base..).
+// `pro` is the A-operand prologue (the forward kernel's LayerNorm; NoPrologue otherwise).
+// A 64-row tile: all four waves compute 16 rows each and share the DMA issue; the prologue is applied to the A fragments.
 // A 32-row tile has MFMA work for two waves only: those two compute, the other two are the tile's DMA engine (issuing a tile piece
-// costs an in-order wave 100+ cycles, which would otherwise sit on the compute waves' critical path).
-template <int DH, int BM, int NS, int BL, typename F>
+// costs an in-order wave 100+ cycles, which would otherwise sit on the compute waves' critical path) - and they also apply the
+// prologue, in place in LDS, one k-step ahead of the compute waves.
+struct NoPrologue {
+    static constexpr bool active = false;
+    FF_DEV void frag(bf16x8&, int, int) const {}
+    template <int BM> FF_DEV void tile(bf16*, int, int, int) const {}
+};
+
+template <int DH, int BM, int NS, int BL, typename P>
 FF_DEV void project_bf16(bf16* ring, const bf16* Ab, long long lda, int row0, int row_lim, const bf16* Bb, long long ldb, int n_base, int n_lim,
-                         int dim, int w, int l, f32x4 (&acc)[DH / 16], F transform) {
+                         int dim, int w, int l, f32x4 (&acc)[DH / 16], const P& pro) {
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = DH * kBK, STAGE = A_ELEMS + B_ELEMS, NT = DH / 16;
     constexpr int NWC = BM / 16;                            // computing waves (16 rows each)
-    constexpr int NWP = NWC == 4 ? 4 : 4 - NWC;             // issuing waves: everybody, or the waves without rows
+    constexpr bool SPLIT = NWC != 4;                        // producer / consumer waves
+    constexpr int NWP = SPLIT ? 4 - NWC : 4;                // issuing waves
     constexpr int PA = BM / (NWP * 8), PB = DH / (NWP * 8), PER_TILE = PA + PB;      // DMA instructions per issuing wave per k-step
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
-    const bool computes = w < NWC, issues = NWC == 4 || w >= NWC;          // wave-uniform
-    const int wp = NWC == 4 ? w : w - NWC;
+    const bool computes = w < NWC, issues = !SPLIT || w >= NWC;            // wave-uniform
+    const int wp = SPLIT ? w - NWC : w;
     const RowMap a_map{lda, 0, 0}, b_map{ldb, 0, 0};
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7fffffff, 0x00020000);
@@ -129,29 +138,84 @@ FF_DEV void project_bf16(bf16* ring, const bf16* Ab, long long lda, int row0, in
         dma_tile_fast<BM, 0, NWP>(ra, st, va, k0 * 2u, wp);
         dma_tile_fast<DH, BL, NWP>(rb, st + A_ELEMS, vb, k0 * b_step, wp);
     };
-    if (issues) {
+    auto compute = [&](int kt, bool frag_prologue) {
+        const bf16* sA = ring + (kt % NS) * STAGE;
+        const bf16* sB = sA + A_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < kBK / 32; ks++) {
+            bf16x8 fa = frag_read2<BM, 0>(sA, w * 16, ks);
+            if (frag_prologue) pro.frag(fa, kt * kBK + ks * 32 + ((l >> 4) << 3), w * 16 + (l & 15));
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[j] = mfma_bf16(frag_read2<DH, BL>(sB, j * 16, ks), fa, acc[j]);   // D[n][m]
+        }
+    };
+    if constexpr (!SPLIT) {
 #pragma unroll
         for (int s = 0; s < NS - 1; s++)
             if (s < nk) issue(s);
-    }
-    for (int kt = 0; kt < nk; kt++) {
-        if (issues) wait_tiles<PER_TILE, NS - 2>(min(nk - 1 - kt, NS - 2));
-        __builtin_amdgcn_s_barrier();       // tile kt is in LDS for everyone; stage (kt - 1) % NS is free
-        if (issues && kt + NS - 1 < nk) issue(kt + NS - 1);
-        if (computes) {
-            const bf16* sA = ring + (kt % NS) * STAGE;
-            const bf16* sB = sA + A_ELEMS;
-#pragma unroll
-            for (int ks = 0; ks < kBK / 32; ks++) {
-                bf16x8 fa = frag_read2<BM, 0>(sA, w * 16, ks);
-                transform(fa, kt * kBK + ks * 32 + ((l >> 4) << 3));
-#pragma unroll
-                for (int j = 0; j < NT; j++) acc[j] = mfma_bf16(frag_read2<DH, BL>(sB, j * 16, ks), fa, acc[j]);   // D[n][m]
-            }
+        for (int kt = 0; kt < nk; kt++) {
+            wait_tiles<PER_TILE, NS - 2>(min(nk - 1 - kt, NS - 2));
+            __builtin_amdgcn_s_barrier();       // tile kt is in LDS for everyone; stage (kt - 1) % NS is free
+            if (kt + NS - 1 < nk) issue(kt + NS - 1);
+            compute(kt, P::active);
         }
+    } else {
+        // barrier B(kt) closes step kt: the compute waves are done with tile kt (its stage may be refilled) and the issuing waves
+        // have tile kt + 1 landed and run through the prologue.
+        if (issues) {
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+                if (s < nk) issue(s);
+            wait_tiles<PER_TILE, NS - 1>(min(nk - 1, NS - 1));
+            if (P::active) pro.template tile<BM>(ring, 0, wp, l);
+        }
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; kt++) {
+            if (computes) compute(kt, false);
+            else if (kt + 1 < nk) {
+                wait_tiles<PER_TILE, NS - 2>(min(nk - 2 - kt, NS - 2));
+                if (P::active) pro.template tile<BM>(ring + ((kt + 1) % NS) * STAGE, (kt + 1) * kBK, wp, l);
+            }
+            __builtin_amdgcn_s_barrier();
+            if (issues && kt + NS < nk) issue(kt + NS);
+        }
+        wait_vmcnt<0>();
     }
-    if (NWC != 4) wait_vmcnt<0>();          // (issuing waves: nothing of theirs is in flight any more; keeps the tail uniform)
 }
+
+// LayerNorm as the prologue of the Q projection: statistics and gamma / beta come from LDS (written by the workgroup beforehand)
+        struct LnPrologue {
+            static constexpr bool active = true;
+            const bf16 *s_g, *s_b;
+            const float *s_mean, *s_rstd;
+            // fragment form: 8 consecutive k (from kk) of tile row m, applied by the computing wave that owns the row
+            FF_DEV void frag(bf16x8& fa, int kk, int m) const {
+                const float mu = s_mean[m], rs = s_rstd[m];
+                float gv[8], bv[8];
+                Vec<bf16>::load(s_g + kk, gv);
+                Vec<bf16>::load(s_b + kk, bv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) fa[e] = (bf16)(((float)fa[e] - mu) * rs * gv[e] + bv[e]);
+            }
+            // tile form: the [BMT][64] K-major swizzled A tile of k-step k0, normalised in place by the 2 issuing waves (128 threads)
+            template <int BMT> FF_DEV void tile(bf16* sA, int k0, int wp, int l) const {
+                const int tid = wp * 64 + l;
+#pragma unroll
+                for (int it = 0; it < BMT * 8 / 128; it++) {
+                    const int i = tid + it * 128, row = i >> 3, slot = i & 7;
+                    const int kk = k0 + ((slot ^ (row & 7)) << 3);
+                    const float mu = s_mean[row], rs = s_rstd[row];
+                    bf16* p = sA + row * kBK + slot * 8;
+                    float v[8], gv[8], bv[8];
+                    Vec<bf16>::load(p, v);
+                    Vec<bf16>::load(s_g + kk, gv);
+                    Vec<bf16>::load(s_b + kk, bv);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = (v[e] - mu) * rs * gv[e] + bv[e];
+                    Vec<bf16>::store(p, v);
+                }
+            }
+        };
 
 // acc[j][r] = value (row m = w*16 + c, column j*16 + g*4 + r) -> LDS tile in layout L
 template <typename T, int DH, typename L> FF_DEV void park_rows(T* tile, const f32x4 (&acc)[DH / 16], float scale, int w, int c, int g) {
@@ -310,10 +374,13 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
             T* ynr = yn + grow * a.dim;
             for (int base = 0; base < nchunk; base += TPR * NB) {
                 const int left = ppt - base / TPR;
+                int owner = 0;                                               // u % heads without a division per piece
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
                     const int ch = base + sub + u * TPR;
-                    if (u < left && (u % a.heads) == h) {                    // this head's share of the row's pieces
+                    const bool mine = owner == h;
+                    owner = owner + 1 == a.heads ? 0 : owner + 1;
+                    if (u < left && mine) {                                  // this head's share of the row's pieces
                         float v[VN], gv[VN], bv[VN];
                         if (one_batch) unpack16(raw[u], v, T());
                         else Vec<T>::load(yr + ch * VN, v);
@@ -336,15 +403,7 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
     for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float mu = m_own < BM ? s_mean[m_own] : 0.f, rs = m_own < BM ? s_rstd[m_own] : 0.f;
     if constexpr (IsBf16<T>::value) {
-        auto ln = [&](bf16x8& fa, int kk) {
-            float gv[8], bv[8];
-            Vec<bf16>::load(s_g + kk, gv);
-            Vec<bf16>::load(s_b + kk, bv);
-#pragma unroll
-            for (int e = 0; e < 8; e++) fa[e] = (bf16)(((float)fa[e] - mu) * rs * gv[e] + bv[e]);
-        };
-        project_bf16<DH, BM, NS, 0>((bf16*)smem, y + (long long)b * a.n_q * a.dim, a.dim, row0, a.n_q, Wq + (long long)h * DH * a.dim, a.dim, 0,
-                                    DH, a.dim, w, l, acc, ln);
+        const LnPrologue ln{s_g, s_b, s_mean, s_rstd};
     } else {
         if (w * 16 < BM) {
             const float* yr = y + ((long long)b * a.n_q + row0 + (own_ok ? m_own : 0)) * a.dim;
@@ -456,9 +515,8 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
 #pragma unroll
     for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (IsBf16<T>::value) {
-        auto none = [](bf16x8&, int) {};
         project_bf16<DH, BM, NS, 1>((bf16*)smem, dy1 + (long long)b * a.n_q * a.dim, a.dim, row0, a.n_q, Wo, a.inner, h * DH, (h + 1) * DH,
-                                    a.dim, w, l, acc, none);
+                                    a.dim, w, l, acc, NoPrologue());
     } else {
         if (w * 16 < BM) {
             const float* dr = dy1 + ((long long)b * a.n_q + row0 + (own_ok ? m_own : 0)) * a.dim;

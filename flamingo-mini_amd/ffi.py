@@ -125,6 +125,7 @@ _SIGNATURES = {
     "ff_shifted_ce_fwd": (_I, [_I, _I, _I, _I, _P, _P, C.c_longlong, _P, _P, _P]),
     "ff_shifted_ce_bwd": (_I, [_I, _I, _I, _I, _P, _P, C.c_longlong, _P, _P, _P, _P]),
     "ff_adamw_step": (_I, [C.POINTER(AdamWDesc), _P, _P, _P, _P, _P, _P]),
+    "ff_adamw_step_mixed": (_I, [C.POINTER(AdamWDesc), _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ff_xattn_block_bwd_kv": (_I, [C.POINTER(XattnDesc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
     "ff_kv_project_workspace_bytes": (_SZ, [C.POINTER(KvProjDesc), _I]),
     "ff_kv_project_fwd": (_I, [C.POINTER(KvProjDesc), _P, _P, _P, _P, _SZ, _P]),

@@ -60,5 +60,7 @@ class GraphedTrainStep:
             for k, v in batch.items():
                 if torch.is_tensor(v):
                     self.static[k].copy_(v, non_blocking=True)
+        if self.optimizer is not None and hasattr(self.optimizer, "sync_device_hyperparams"):
+            self.optimizer.sync_device_hyperparams()        # an LR scheduler may have changed group["lr"] since the capture
         self.graph.replay()
         return self.loss

@@ -294,20 +294,65 @@ class FlamingoModel(PreTrainedModel):
     @torch.no_grad()
     def greedy_generate(self, input_ids, media_locations, attention_mask, pixel_values=None, visual_features=None,
                         max_length: int = 150, eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None):
-        """Cached greedy decoding: the first step runs CLIP + resampler and fills the xattn / LM caches, later steps feed
-        one token and reuse the cross-attention K/V (the caption tokens/sec path)."""
-        ids, ml, am = input_ids, media_locations, attention_mask
+        """Cached greedy decoding (the caption tokens/sec path); see generate()."""
+        return self.generate(input_ids, media_locations=media_locations, attention_mask=attention_mask, pixel_values=pixel_values,
+                             visual_features=visual_features, max_length=max_length, eos_token_id=eos_token_id, pad_token_id=pad_token_id)
+
+    def _decode_step(self, step_ids, ml, am, past, pixel_values, visual_features):
+        out = self.flamingo(input_ids=step_ids, attention_mask=am, media_locations=ml, use_cache=True, past_key_values=past,
+                            pixel_values=pixel_values if past is None else None, visual_features=visual_features if past is None else None)
+        return out.logits[:, -1].float(), out.past_key_values
+
+    @staticmethod
+    def _filter_logits(logits, temperature, top_k, top_p):
+        """temperature / top-k / nucleus filtering as in transformers' logits warpers."""
+        if temperature != 1.0:
+            logits = logits / temperature
+        if top_k and top_k > 0:
+            kth = logits.topk(min(top_k, logits.shape[-1]), dim=-1).values[..., -1, None]
+            logits = logits.masked_fill(logits < kth, float("-inf"))
+        if top_p < 1.0:
+            srt, idx = logits.sort(dim=-1, descending=True)
+            cum = srt.softmax(-1).cumsum(-1)
+            drop = cum - srt.softmax(-1) >= top_p               # keep the smallest prefix whose mass reaches top_p
+            logits = logits.masked_fill(drop.scatter(-1, idx, drop), float("-inf"))
+        return logits
+
+    @torch.no_grad()
+    def generate(self, inputs=None, media_locations=None, attention_mask=None, pixel_values=None, visual_features=None,
+                 max_length: int = 150, num_beams: int = 1, do_sample: bool = False, temperature: float = 1.0, top_k: int = 0,
+                 top_p: float = 1.0, eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None, bos_token_id: Optional[int] = None,
+                 early_stopping: bool = True, length_penalty: float = 1.0, use_cache: bool = True, generator: Optional[torch.Generator] = None,
+                 input_ids=None, **unsupported):
+        """Text generation with the cached cross-attention path: the first step runs CLIP + resampler and fills the xattn K/V and LM caches,
+        every later step feeds one token (reference: HF `generate` through prepare_inputs_for_generation / _reorder_cache, :464-548).
+        transformers >= 4.50 no longer gives PreTrainedModel a `generate`, so the decoding strategies the reference's callers use are
+        implemented here: greedy, multinomial sampling (do_sample, temperature, top_k, top_p) and beam search (num_beams, length_penalty,
+        early_stopping).  Unknown generation arguments raise instead of being ignored."""
+        if unsupported:
+            raise TypeError(f"generate(): unsupported generation arguments {sorted(unsupported)}")
+        if not use_cache:
+            raise ValueError("generate() always decodes with the cross-attention / LM caches (use_cache=True)")
+        ids = inputs if inputs is not None else input_ids
+        assert ids is not None and media_locations is not None, "generate() needs input ids and media_locations"
+        am = attention_mask if attention_mask is not None else torch.ones_like(ids)
+        ml = media_locations
+        pad = pad_token_id if pad_token_id is not None else eos_token_id
+        if num_beams > 1:
+            if do_sample:
+                raise ValueError("beam search with sampling is not implemented")
+            return self._beam_search(ids, ml, am, pixel_values, visual_features, max_length, num_beams, eos_token_id, pad, early_stopping, length_penalty)
         finished = torch.zeros(ids.shape[0], dtype=torch.bool, device=ids.device)
-        past = None
-        step_ids = ids
+        past, step_ids = None, ids
         while ids.shape[1] < max_length:
-            out = self.flamingo(input_ids=step_ids, attention_mask=am, media_locations=ml, use_cache=True, past_key_values=past,
-                                pixel_values=pixel_values if past is None else None,
-                                visual_features=visual_features if past is None else None)
-            past = out.past_key_values
-            nxt = out.logits[:, -1].argmax(-1)
+            logits, past = self._decode_step(step_ids, ml, am, past, pixel_values, visual_features)
+            if do_sample:
+                probs = self._filter_logits(logits, temperature, top_k, top_p).softmax(-1)
+                nxt = torch.multinomial(probs, 1, generator=generator)[:, 0]
+            else:
+                nxt = logits.argmax(-1)
             if eos_token_id is not None:
-                nxt = torch.where(finished, torch.full_like(nxt, pad_token_id if pad_token_id is not None else eos_token_id), nxt)
+                nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
                 finished = finished | (nxt == eos_token_id)
             ids = torch.cat([ids, nxt[:, None]], dim=1)
             ml = torch.cat([ml, torch.zeros_like(ml[:, :1])], dim=1)
@@ -317,10 +362,82 @@ class FlamingoModel(PreTrainedModel):
                 break
         return ids
 
+    def _beam_search(self, ids, ml, am, pixel_values, visual_features, max_length, nb, eos, pad, early_stopping, length_penalty):
+        """Standard beam search over the cached decode path.  The prompt runs once per sequence; its caches are then replicated per beam
+        (xattn K/V: repeat_interleave; LM cache: Cache.batch_repeat_interleave) and re-ordered every step (_reorder_cache)."""
+        b, L0 = ids.shape
+        dev = ids.device
+        logits, past = self._decode_step(ids, ml, am, None, pixel_values, visual_features)
+        logp = logits.log_softmax(-1)
+        V = logp.shape[-1]
+        xattn_past, lm_past = past
+        xattn_past = tuple(tuple(_repeat_leading(t, nb) for t in kv) for kv in xattn_past)
+        if hasattr(lm_past, "batch_repeat_interleave"):
+            lm_past.batch_repeat_interleave(nb)
+        else:
+            lm_past = tuple(tuple(_repeat_leading(t, nb) for t in layer) for layer in lm_past)
+        past = (xattn_past, lm_past)
+        seqs = _repeat_leading(ids, nb)                                   # (b * nb, L)
+        ml, am = _repeat_leading(ml, nb), _repeat_leading(am, nb)
+        scores = torch.full((b, nb), float("-inf"), device=dev)
+        scores[:, 0] = 0.0                                                # all beams of a sequence start identical: only one may branch
+        logp = _repeat_leading(logp, nb)
+        done_hyps = [[] for _ in range(b)]                                # (normalised score, token list) per sequence
+        is_done = [False] * b
+        while True:
+            cand = (scores.reshape(-1, 1) + logp).reshape(b, nb * V)
+            top_s, top_i = cand.topk(2 * nb, dim=-1)
+            cur_len = seqs.shape[1] + 1
+            next_scores = torch.full((b, nb), float("-inf"), device=dev)
+            next_tok = torch.full((b, nb), pad if pad is not None else 0, dtype=torch.long, device=dev)
+            next_src = torch.arange(nb, device=dev).repeat(b, 1)
+            top_s_c, top_i_c = top_s.cpu(), top_i.cpu()
+            for bi in range(b):
+                if is_done[bi]:
+                    continue
+                k = 0
+                for rank in range(2 * nb):
+                    s_, i_ = float(top_s_c[bi, rank]), int(top_i_c[bi, rank])
+                    beam, tok = i_ // V, i_ % V
+                    if eos is not None and tok == eos:
+                        if rank < nb:
+                            done_hyps[bi].append((s_ / (cur_len ** length_penalty), seqs[bi * nb + beam].tolist() + [tok]))
+                        continue
+                    next_scores[bi, k], next_tok[bi, k], next_src[bi, k] = s_, tok, beam
+                    k += 1
+                    if k == nb:
+                        break
+                if len(done_hyps[bi]) >= nb:
+                    done_hyps[bi] = sorted(done_hyps[bi], key=lambda t: -t[0])[:nb]
+                    best_open = float(next_scores[bi].max()) / (cur_len ** length_penalty)
+                    if early_stopping or done_hyps[bi][-1][0] >= best_open:
+                        is_done[bi] = True
+            beam_idx = (next_src + torch.arange(b, device=dev)[:, None] * nb).reshape(-1)
+            seqs = torch.cat([seqs.index_select(0, beam_idx), next_tok.reshape(-1, 1)], dim=1)
+            scores = next_scores
+            if all(is_done) or seqs.shape[1] >= max_length:
+                break
+            past = self._reorder_cache(past, beam_idx)
+            ml = torch.cat([ml, torch.zeros_like(ml[:, :1])], dim=1)
+            am = torch.cat([am, torch.ones_like(am[:, :1])], dim=1)
+            logits, past = self._decode_step(seqs[:, -1:], ml, am, past, None, None)
+            logp = logits.log_softmax(-1)
+        out = []
+        for bi in range(b):
+            hyps = list(done_hyps[bi])
+            if not is_done[bi]:                                           # length limit: the open beams count as hypotheses too
+                hyps += [(float(scores[bi, k]) / (seqs.shape[1] ** length_penalty), seqs[bi * nb + k].tolist()) for k in range(nb)
+                         if float(scores[bi, k]) > float("-inf")]
+            out.append(max(hyps, key=lambda t: t[0])[1])
+        width = max(len(o) for o in out)
+        fill = pad if pad is not None else 0
+        return torch.tensor([o + [fill] * (width - len(o)) for o in out], dtype=torch.long, device=dev)
+
     @torch.no_grad()
     def generate_captions(self, processor, pixel_values=None, images=None, prompt: str = "<image>", max_length: int = 150,
                           num_beams: int = 1, device=None, **kwargs):
-        """Caption a batch of images; the prompt is replicated for every image."""
+        """Caption a batch of images; the prompt is replicated for every image (reference :550-605).  `kwargs` are generation
+        arguments (do_sample, temperature, top_k, top_p, length_penalty, ...) and go to generate(), which rejects unknown ones."""
         if device is None:
             device = self.device
         if images is not None:
@@ -334,13 +451,12 @@ class FlamingoModel(PreTrainedModel):
         input_ids = input_ids[:1].expand(batch_size, -1).contiguous()
         media_locations = media_locations[:1].expand(batch_size, -1).contiguous()
         attention_mask = attention_mask[:1].expand(batch_size, -1).contiguous()
-        if num_beams != 1:
-            raise NotImplementedError("beam search needs transformers' GenerationMixin; this build decodes greedily")
         lm_cfg = self.flamingo.lm.config
         if pixel_values.ndim == 4:
             pixel_values = pixel_values[:, None]       # (b c h w) -> one image per sequence
-        out_ids = self.greedy_generate(input_ids, media_locations, attention_mask, pixel_values=pixel_values, max_length=max_length,
-                                       eos_token_id=lm_cfg.eos_token_id, pad_token_id=lm_cfg.eos_token_id)
+        out_ids = self.generate(inputs=input_ids, media_locations=media_locations, attention_mask=attention_mask, pixel_values=pixel_values,
+                                num_beams=num_beams, early_stopping=True, use_cache=True, bos_token_id=lm_cfg.bos_token_id,
+                                eos_token_id=lm_cfg.eos_token_id, pad_token_id=lm_cfg.eos_token_id, max_length=max_length, **kwargs)
         captions = processor.tokenizer.batch_decode(out_ids, skip_special_tokens=True)
         return [processor.remove_tags(t) for t in captions]
 

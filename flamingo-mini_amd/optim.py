@@ -3,8 +3,14 @@ of a dtype — same update rule, defaults and state_dict layout (`step`, `exp_av
 optimizer checkpoints interchange.  The reference trains with `--optim adamw_torch` (training/train.sh:10-13) on
 `model.parameters_trainable()`.
 
-`capturable=True` keeps the step count in a device scalar per parameter group (bias corrections are computed in the kernel),
-so `step()` can be captured into a HIP graph and replayed (graphs.GraphedTrainStep); `state_dict()` reads the count back."""
+`capturable=True` keeps the step count AND the learning rate in device scalars per parameter group (bias corrections are computed
+in the kernel), so `step()` can be captured into a HIP graph and replayed (graphs.GraphedTrainStep) while an LR scheduler keeps
+changing `group["lr"]`: call `sync_device_hyperparams()` (GraphedTrainStep does) before a replay.  `state_dict()` reads the count back.
+
+Mixed precision (the reference trains with `--fp16` autocast = fp32 master weights and fp32 moments, training/train.sh:24):
+`master_dtype=torch.float32` keeps an fp32 master copy of every bf16 parameter in the optimizer state (`state["master"]`); the kernel
+updates the master copy and writes its bf16 rounding into the parameter in the same pass, so steps far below the bf16 resolution of a
+weight (lr 1e-4) accumulate instead of vanishing.  `state_dtype=torch.float32` alone keeps only the two moments in fp32."""
 from __future__ import annotations
 
 import ctypes as C
@@ -17,9 +23,14 @@ from . import ffi
 
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 grad_scale: float = 1.0, capturable: bool = False):
+                 grad_scale: float = 1.0, capturable: bool = False, master_dtype=None, state_dtype=None):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
+        if master_dtype not in (None, torch.float32) or state_dtype not in (None, torch.float32):
+            raise ValueError("master_dtype / state_dtype: None (the parameter's dtype) or torch.float32")
+        if master_dtype is not None:
+            state_dtype = torch.float32                   # fp32 masters go with fp32 moments
+        self.master_dtype, self.state_dtype = master_dtype, state_dtype
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale, capturable=capturable))
 
     @torch.no_grad()
@@ -40,16 +51,27 @@ class FusedAdamW(torch.optim.Optimizer):
                     if g.dtype != p.dtype or not g.is_contiguous():
                         raise ffi.FusionLibraryError("FusedAdamW needs contiguous gradients of the parameter's dtype")
                     grad_ptrs[i] = g.data_ptr()
+                lr_dev = None
                 if capturable:
                     step, step_dev = 0, group["_step_dev"][bucket["device"]].data_ptr()
+                    lr_dev = group["_lr_dev"][bucket["device"]].data_ptr()
                 else:
                     bucket["step"] += 1                   # the per-parameter `step` entries are refreshed lazily (_sync_host_steps)
                     step, step_dev = bucket["step"], None
                 desc = ffi.AdamWDesc(bucket["dtype_code"], n, step, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
                                      group["weight_decay"], group["grad_scale"], step_dev)
-                ffi.check(lib.ff_adamw_step(desc, bucket["param_ptrs"], grad_ptrs, bucket["m_ptrs"], bucket["v_ptrs"], bucket["numels"],
-                                            ffi.stream_handle(bucket["device"])), "ff_adamw_step")
+                ffi.check(lib.ff_adamw_step_mixed(desc, bucket["state_code"], bucket["param_ptrs"], grad_ptrs, bucket["m_ptrs"], bucket["v_ptrs"],
+                                                  bucket["w_ptrs"], lr_dev, bucket["numels"], ffi.stream_handle(bucket["device"])),
+                          "ff_adamw_step_mixed")
         return loss
+
+    def sync_device_hyperparams(self) -> None:
+        """capturable mode: copy `group["lr"]` into the device scalar the captured kernels read (call before replaying a graph)."""
+        for group in self.param_groups:
+            for dev, t in group.get("_lr_dev", {}).items():
+                if group.get("_lr_on_dev", {}).get(dev) != group["lr"]:
+                    t.fill_(float(group["lr"]))
+                    group.setdefault("_lr_on_dev", {})[dev] = group["lr"]
 
     def _buckets(self, gi, group):
         """Parameters with a gradient, grouped by (dtype, device, step count); the pointer tables of everything that does not
@@ -67,15 +89,21 @@ class FusedAdamW(torch.optim.Optimizer):
             if not p.is_contiguous():
                 raise ffi.FusionLibraryError("FusedAdamW needs contiguous parameters")
             st = self.state[p]
+            mixed = p.dtype == torch.bfloat16          # fp32 parameters are their own master copy and already have fp32 moments
+            sdt = self.state_dtype if (mixed and self.state_dtype is not None) else p.dtype
             if not st:
                 st["step"] = torch.zeros((), dtype=torch.float32)
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            table.setdefault((p.dtype, p.device, int(st["step"])), []).append(p)
+                st["exp_avg"] = torch.zeros_like(p, dtype=sdt, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, dtype=sdt, memory_format=torch.preserve_format)
+            if mixed and self.master_dtype is not None and "master" not in st:
+                st["master"] = p.detach().to(torch.float32)
+            has_master = "master" in st
+            table.setdefault((p.dtype, p.device, int(st["step"]), st["exp_avg"].dtype, has_master), []).append(p)
         buckets = []
-        for (dtype, device, step), params in table.items():
+        for (dtype, device, step, sdt, has_master), params in table.items():
             n = len(params)
-            buckets.append(dict(params=params, device=device, dtype_code=ffi.dtype_code(dtype), step=step,
+            buckets.append(dict(params=params, device=device, dtype_code=ffi.dtype_code(dtype), step=step, state_code=ffi.dtype_code(sdt),
+                                w_ptrs=ffi.ptr_array([self.state[p]["master"] for p in params]) if has_master else None,
                                 param_ptrs=ffi.ptr_array(params), grad_ptrs=(C.c_void_p * n)(),
                                 m_ptrs=ffi.ptr_array([self.state[p]["exp_avg"] for p in params]),
                                 v_ptrs=ffi.ptr_array([self.state[p]["exp_avg_sq"] for p in params]),
@@ -87,10 +115,15 @@ class FusedAdamW(torch.optim.Optimizer):
     def _advance_device_steps(self, group):
         """One float32 step counter per (group, device), advanced by a device-side add (captured along with the update)."""
         counters = group.setdefault("_step_dev", {})
+        lrs = group.setdefault("_lr_dev", {})
         for p in group["params"]:
             if p.grad is not None and p.device not in counters:
                 host_steps = [int(self.state[q]["step"]) for q in group["params"] if q in self.state and "step" in self.state[q]]
                 counters[p.device] = torch.full((), float(max(host_steps, default=0)), dtype=torch.float32, device=p.device)
+                lrs[p.device] = torch.full((), float(group["lr"]), dtype=torch.float32, device=p.device)
+                group.setdefault("_lr_on_dev", {})[p.device] = group["lr"]
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_device_hyperparams()
         for counter in counters.values():
             counter += 1
 
@@ -118,5 +151,6 @@ class FusedAdamW(torch.optim.Optimizer):
                         self.state[p]["step"] = torch.tensor(step, dtype=torch.float32)
         out = super().state_dict()
         for g in out["param_groups"]:
-            g.pop("_step_dev", None)
+            for k in ("_step_dev", "_lr_dev", "_lr_on_dev"):
+                g.pop(k, None)
         return out

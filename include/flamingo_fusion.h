@@ -289,6 +289,13 @@ typedef struct ff_adamw_desc {
 } ff_adamw_desc;
 int ff_adamw_step(const ff_adamw_desc* d, void* const* params, const void* const* grads, void* const* exp_avg,
                   void* const* exp_avg_sq, const long long* numels, ff_stream_t stream);
+/* Mixed-precision variant (the reference trains with `--fp16` autocast, i.e. fp32 master weights and fp32 Adam moments,
+ * training/train.sh:24): parameters / gradients in d->dtype, the two moments in `state_dtype` (d->dtype or FF_DTYPE_F32), and -
+ * for bf16 parameters - optional fp32 `master` copies: the update is applied to the master copy and the bf16 parameter is its
+ * rounding, written by the same kernel.  `lr_dev` (optional device scalar) replaces d->lr, so a learning-rate schedule stays
+ * effective when the launch is replayed from a captured HIP graph. */
+int ff_adamw_step_mixed(const ff_adamw_desc* d, int state_dtype, void* const* params, const void* const* grads, void* const* exp_avg,
+                        void* const* exp_avg_sq, float* const* master, const float* lr_dev, const long long* numels, ff_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------------------

@@ -78,3 +78,75 @@ def test_fused_adamw_capturable_and_graph_replay():
     steps = {float(s["step"]) for s in o_graph.state_dict()["state"].values()}
     assert steps == {4.0}
     assert "_step_dev" not in o_graph.state_dict()["param_groups"][0]
+
+
+def test_fused_adamw_fp32_master_weights_keep_small_updates():
+    """master_dtype=fp32 (what the reference's `--fp16` autocast training keeps, training/train.sh:24): the fp32 master copy follows the
+    float64 AdamW rule and the bf16 parameter is its rounding; with bf16-only storage the same small steps (lr 1e-4 on weights ~1) are
+    below the weight's bf16 resolution and vanish."""
+    from flamingo_mini_amd import FusedAdamW
+    hp = dict(lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    shapes = [(1280,), (257, 9), (1,)]
+    base = [dev(np.sign(rnd(s, 70 + i)) * (1.0 + 0.25 * np.abs(rnd(s, 80 + i))), torch.bfloat16) for i, s in enumerate(shapes)]
+    with_master = [torch.nn.Parameter(t.clone()) for t in base]
+    bf16_only = [torch.nn.Parameter(t.clone()) for t in base]
+    opt_m = FusedAdamW(with_master, master_dtype=torch.float32, **hp)
+    opt_b = FusedAdamW(bf16_only, **hp)
+    ref = [(as64(t), np.zeros(t.shape), np.zeros(t.shape)) for t in base]
+    n_steps = 40
+    for step in range(1, n_steps + 1):
+        for i, (a, b) in enumerate(zip(with_master, bf16_only)):
+            g = dev(np.abs(rnd(a.shape, 1000 * step + i, 0.5)) + 0.1, torch.bfloat16)          # same sign every step: the updates add up
+            a.grad, b.grad = g, g.clone()
+            ref[i] = O.adamw_step(*ref[i][:1], as64(g), *ref[i][1:], step, lr=hp["lr"], beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0)
+        opt_m.step()
+        opt_b.step()
+    for i, (a, b) in enumerate(zip(with_master, bf16_only)):
+        st = opt_m.state[a]
+        assert st["master"].dtype == torch.float32 and st["exp_avg"].dtype == torch.float32 and st["exp_avg_sq"].dtype == torch.float32
+        assert rel(st["master"], ref[i][0]) < 2e-6 and rel(st["exp_avg"], ref[i][1]) < 1e-5 and rel(st["exp_avg_sq"], ref[i][2]) < 1e-5
+        assert torch.equal(a.detach(), st["master"].to(torch.bfloat16))                        # the parameter IS the rounded master copy
+        moved_master = float((st["master"].double() - base[i].double()).abs().mean())
+        assert moved_master > 0.5 * n_steps * hp["lr"]                                         # ~ n_steps * lr, as AdamW with steady gradients does
+        assert float((b.detach().double() - base[i].double()).abs().mean()) < 0.1 * moved_master   # bf16 storage: (almost) every step rounded away
+    fp32_state = [torch.nn.Parameter(t.clone()) for t in base]                                # moments in fp32, no master copy
+    opt_s = FusedAdamW(fp32_state, state_dtype=torch.float32, **hp)
+    for p in fp32_state:
+        p.grad = torch.ones_like(p)
+    opt_s.step()
+    assert all(opt_s.state[p]["exp_avg"].dtype == torch.float32 and "master" not in opt_s.state[p] for p in fp32_state)
+
+
+def test_learning_rate_schedule_survives_graph_replay():
+    """capturable=True keeps lr in a device scalar: changing group["lr"] between replays of a captured step must act like eager steps."""
+    from flamingo_mini_amd import FusedAdamW
+    shapes = [(130,), (33, 40)]
+    lrs = [1e-2, 5e-3, 2e-2, 1e-3]
+
+    def make():
+        ps = [torch.nn.Parameter(dev(rnd(s, 10 + i))) for i, s in enumerate(shapes)]
+        for i, p in enumerate(ps):
+            p.grad = dev(rnd(p.shape, 20 + i, 0.1))
+        return ps
+
+    p_e, p_g = make(), make()
+    o_e, o_g = FusedAdamW(p_e, lr=lrs[0]), FusedAdamW(p_g, lr=lrs[0], capturable=True)
+    for lr in lrs:
+        o_e.param_groups[0]["lr"] = lr
+        o_e.step()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        o_g.step()                                    # step 1 (lr = lrs[0]) eagerly
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o_g.step()
+    for lr in lrs[1:]:
+        o_g.param_groups[0]["lr"] = lr
+        o_g.sync_device_hyperparams()
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(p_e, p_g):
+        assert rel(b, a) < 1e-6

@@ -178,3 +178,42 @@ def test_greedy_generate_cached_equals_uncached(family):
         cml = torch.cat([cml, torch.zeros_like(cml[:, :1])], 1)
         cam = torch.cat([cam, torch.ones_like(cam[:, :1])], 1)
     assert torch.equal(gen, cur)
+
+
+@pytest.mark.parametrize("family", ["opt", "gpt2"])
+def test_generation_strategies_cpu_with_oracle_checker(family):
+    """generate(): greedy, sampling and beam search over the cached decode path (reference: HF generate via prepare_inputs_for_generation /
+    _reorder_cache, modeling_flamingo.py:464-605).  Plumbing check on CPU with the fused entry points on the oracle."""
+    import oracle_backend
+    oracle_backend.install()
+    try:
+        model, z = build(torch.float64, "cpu", family)
+        model.eval()
+        px = torch.from_numpy(z["px"]).double()
+        ids, ml = torch.from_numpy(z["ids"])[:, :4], torch.from_numpy(z["ml"])[:, :4]
+        am = torch.ones_like(ids)
+        kw = dict(media_locations=ml, attention_mask=am, pixel_values=px, max_length=9)
+        greedy = model.generate(ids, **kw)
+        assert greedy.shape == (2, 9) and torch.equal(greedy, model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9))
+        assert torch.equal(model.generate(ids, do_sample=True, top_k=1, **kw), greedy)          # top-1 sampling is greedy
+        g = torch.Generator().manual_seed(3)
+        s1 = model.generate(ids, do_sample=True, temperature=0.7, top_p=0.9, generator=g, **kw)
+        g = torch.Generator().manual_seed(3)
+        s2 = model.generate(ids, do_sample=True, temperature=0.7, top_p=0.9, generator=g, **kw)
+        assert torch.equal(s1, s2) and int(s1.max()) < 97
+
+        def seq_logprob(seq):       # total log-probability of the generated suffix, uncached forward
+            L = seq.shape[1]
+            mlf = torch.cat([ml, torch.zeros(2, L - 4, dtype=ml.dtype)], 1)
+            with torch.no_grad():
+                lg = model(input_ids=seq, attention_mask=torch.ones_like(seq), media_locations=mlf, pixel_values=px).logits.log_softmax(-1)
+            return lg[:, 3:-1].gather(-1, seq[:, 4:, None])[..., 0].sum(1)
+
+        beams = model.generate(ids, num_beams=3, **kw)
+        assert beams.shape == (2, 9)
+        assert bool((seq_logprob(beams) >= seq_logprob(greedy) - 1e-9).all())                   # beam search never does worse than greedy
+        assert torch.equal(model.generate(ids, num_beams=1, **kw), greedy)
+        with pytest.raises(TypeError):
+            model.generate(ids, no_repeat_ngram_size=2, **kw)
+    finally:
+        oracle_backend.uninstall()

@@ -481,7 +481,7 @@ class FlamingoModel(PreTrainedModel):
                              past_key_values=(xattn_past, None))
         logp = out2.logits[:, n_reuse - 1:-1].float().log_softmax(-1)
         tgt = input_ids[topk][:, n_reuse:]
-        tok = logp.gather(-1, tgt[..., None])[..., 0] * attention_mask[topk][:, n_reuse:]
+        tok = logp.gather(-1, tgt[..., None])[..., 0]     # every position after the shared prefix counts, padded or not (reference :699-703: unmasked sum)
         scores = torch.full([n_choices], torch.finfo(torch.float).min, device=tok.device)
         scores[topk] = tok.sum(1)
         return scores.detach()

@@ -404,6 +404,8 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
     const float mu = m_own < BM ? s_mean[m_own] : 0.f, rs = m_own < BM ? s_rstd[m_own] : 0.f;
     if constexpr (IsBf16<T>::value) {
         const LnPrologue ln{s_g, s_b, s_mean, s_rstd};
+        project_bf16<DH, BM, NS, 0>((bf16*)smem, y + (long long)b * a.n_q * a.dim, a.dim, row0, a.n_q, Wq + (long long)h * DH * a.dim, a.dim, 0,
+                                    DH, a.dim, w, l, acc, ln);
     } else {
         if (w * 16 < BM) {
             const float* yr = y + ((long long)b * a.n_q + row0 + (own_ok ? m_own : 0)) * a.dim;

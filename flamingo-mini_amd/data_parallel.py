@@ -66,7 +66,9 @@ class GradientAllReducer:
     def _on_bucket(self, flat: torch.Tensor, owners=()):
         if not (self.active and self._sync):
             return
-        if any(p.grad is not None for p, _, _ in owners):
+        es = flat.element_size()
+        if any(p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + off * es for p, off, _ in owners):     # (a deferred gradient that autograd
+            # has already adopted IS its slice of `flat`: that is not accumulation)
             # accumulation: autograd is about to ADD these slices to existing .grad tensors - the flat buffer is not the gradient
             for p, _, _ in owners:
                 if id(p) in self._early:

@@ -104,7 +104,7 @@ def test_fused_adamw_fp32_master_weights_keep_small_updates():
     for i, (a, b) in enumerate(zip(with_master, bf16_only)):
         st = opt_m.state[a]
         assert st["master"].dtype == torch.float32 and st["exp_avg"].dtype == torch.float32 and st["exp_avg_sq"].dtype == torch.float32
-        assert rel(st["master"], ref[i][0]) < 2e-6 and rel(st["exp_avg"], ref[i][1]) < 1e-5 and rel(st["exp_avg_sq"], ref[i][2]) < 1e-5
+        assert rel(st["master"], ref[i][0]) < 2e-6 and rel(st["exp_avg"], ref[i][1]) < 1e-5 and rel(st["exp_avg_sq"], ref[i][2]) < 5e-5
         assert torch.equal(a.detach(), st["master"].to(torch.bfloat16))                        # the parameter IS the rounded master copy
         moved_master = float((st["master"].double() - base[i].double()).abs().mean())
         assert moved_master > 0.5 * n_steps * hp["lr"]                                         # ~ n_steps * lr, as AdamW with steady gradients does

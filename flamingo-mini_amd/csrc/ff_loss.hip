@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void shifted_ce_fwd_kernel(int L, int V, const
         const float l = M + logf(S);
         lse[r] = l;
         const long long tgt = labels[(long long)b * L + i + 1];
-        loss_row[r] = tgt == ignore_index ? 0.f : l - to_f32(row[tgt]);
+        // a label outside [0, V) that is not ignore_index (e.g. the <EOC> id with an un-resized embedding) is an error: torch's
+        // cross_entropy asserts on the device; here the row's loss becomes NaN (no out-of-bounds read), which no reduction can hide
+        loss_row[r] = tgt == ignore_index ? 0.f : ((tgt < 0 || tgt >= V) ? __builtin_nanf("") : l - to_f32(row[tgt]));
     }
 }
 
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void shifted_ce_bwd_kernel(int L, int V, const
     const bool last = i == L - 1;
     const int r = b * (L - 1) + i;
     const long long tgt = last ? -1 : labels[(long long)b * L + i + 1];
-    const float gr = (last || tgt == ignore_index) ? 0.f : g[r], l = last ? 0.f : lse[r];
+    const float gr = (last || tgt == ignore_index) ? 0.f : ((tgt < 0 || tgt >= V) ? __builtin_nanf("") : g[r]), l = last ? 0.f : lse[r];   // bad label: NaN row
     auto dval = [&](int c, float x) { return gr == 0.f ? 0.f : (__expf(x - l) - (c == tgt ? 1.f : 0.f)) * gr; };
     int head = (int)(((16u - (unsigned)((unsigned long long)row & 15u)) & 15u) / sizeof(T));
     head = head < V ? head : V;

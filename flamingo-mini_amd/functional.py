@@ -114,7 +114,7 @@ def _flat_offsets(params: Sequence[torch.Tensor]):
     for p in params:
         offs.append(total)
         total += (p.numel() + align - 1) // align * align
-    return offs, total
+    return offs, (total + 1023) // 1024 * 1024       # whole buffer: a multiple of 1024 elements, so it splits evenly over 1/2/4/8 ranks (reduce-scatter)
 
 
 def _flat_grads(params: Sequence[torch.Tensor]):
@@ -492,8 +492,8 @@ def shifted_cross_entropy(logits: torch.Tensor, labels: torch.Tensor, reduction:
     if reduction == "sum":
         return rows.sum()
     if reduction == "mean":
-        count = (labels[..., 1:] != ignore_index).sum().clamp_min(1)
-        return rows.sum() / count
+        count = (labels[..., 1:] != ignore_index).sum()
+        return rows.sum() / count            # an all-ignored batch gives 0 / 0 = NaN, like F.cross_entropy(reduction="mean")
     raise ValueError(f"unknown reduction {reduction}")
 
 

@@ -99,3 +99,61 @@ def test_two_rank_gloo_matches_single_process(tmp_path, hoist_kv):
         assert np.array_equal(r0["acc." + k], r1["acc." + k]), k               # two accumulated micro-batches: same mean gradient
         assert np.linalg.norm(r0["acc." + k] - ref) <= 1e-12 * max(np.linalg.norm(ref), 1e-30) + 1e-18, k
     assert int(r0["caught"]) == 1 and int(r1["caught"]) == 1                   # accumulation without no_sync() is refused
+
+
+# ---------------------------------------------------------------------------------------------------
+# ShardedAdamW: reduce-scatter -> update of this rank's slice -> all-gather, per gradient bucket
+# ---------------------------------------------------------------------------------------------------
+HP = dict(lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+
+
+def _torch_adamw(p, g, m, v, master, step):
+    """The AdamW rule on flat CPU tensors (what ff_adamw_step_mixed does on the GPU): injected through update_fn on the gloo ranks."""
+    import math
+    b1, b2 = HP["betas"]
+    p.mul_(1.0 - HP["lr"] * HP["weight_decay"])
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    p.addcdiv_(m, (v.sqrt() / math.sqrt(1.0 - b2 ** step)).add_(HP["eps"]), value=-HP["lr"] / (1.0 - b1 ** step))
+
+
+def _sharded_worker(rank, world, port, out_dir, hoist_kv):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from flamingo_mini_amd.data_parallel import ShardedAdamW
+    model, z = _build_tiny(hoist_kv)
+    opt = ShardedAdamW(model, update_fn=_torch_adamw, **HP)
+    for _ in range(3):
+        opt.zero_grad()
+        _loss(model, z, [rank]).backward()
+        opt.finish_step()
+    state_elems = sum(st["m"].numel() for st in opt.buckets.values())
+    np.savez(os.path.join(out_dir, f"sharded{rank}.npz"), state_elems=state_elems,
+             **{k: p.detach().numpy().copy() for k, p in model.named_parameters() if p.requires_grad})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hoist_kv", [False, True], ids=["per-layer-kv", "hoisted-kv"])
+def test_sharded_adamw_two_ranks_equal_single_process_adamw(tmp_path, hoist_kv):
+    port = _free_port()
+    mp.start_processes(_sharded_worker, args=(2, port, str(tmp_path), hoist_kv), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "sharded0.npz"), np.load(tmp_path / "sharded1.npz")
+    model, z = _build_tiny(hoist_kv)
+    params = [p for p in model.parameters() if p.requires_grad]
+    ref = torch.optim.AdamW(params, **HP)
+    for _ in range(3):
+        model.zero_grad(set_to_none=True)
+        ((_loss(model, z, [0]) + _loss(model, z, [1])) / 2).backward()
+        ref.step()
+    fused_total = 0
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert np.array_equal(r0[k], r1[k]), k                                   # every rank holds the same parameters after the all-gather
+        want = p.detach().numpy()
+        assert np.linalg.norm(r0[k] - want) <= 1e-10 * max(np.linalg.norm(want), 1e-30) + 1e-15, k
+        fused_total += p.numel() if "embed" not in k and "wte" not in k else 0
+    # each rank keeps moments for (about) half of the fused parameters only
+    assert int(r0["state_elems"]) == int(r1["state_elems"]) and fused_total / 2 <= int(r0["state_elems"]) <= fused_total / 2 + 8 * 1024

@@ -150,3 +150,33 @@ def test_rccl_reducer_on_one_rank_eager_and_captured(one_rank_rccl, dtype):
         assert abs(a - b) <= tol * max(1.0, abs(a)), (base, replayed)
     for (n, pa), (_, pb) in zip(plain.named_parameters(), graphed.named_parameters()):
         assert rel(pb, pa) < (1e-4 if dtype == torch.float32 else 3e-2), n
+
+
+@pytest.mark.parametrize("master", [None, torch.float32], ids=["bf16-state", "fp32-master"])
+def test_sharded_adamw_on_one_rccl_rank_equals_fused_adamw(one_rank_rccl, master):
+    """ShardedAdamW's device path (reduce_scatter_tensor -> ff_adamw_step_mixed on the rank's slice -> all_gather_into_tensor, per bucket, on
+    the side stream) on a 1-rank RCCL group must reproduce GradientAllReducer-free FusedAdamW training step for step."""
+    from flamingo_mini_amd import FusedAdamW
+    from flamingo_mini_amd.data_parallel import ShardedAdamW
+    torch.manual_seed(0)
+    dtype = torch.bfloat16
+    plain = _ToyHoisted().cuda().to(dtype)
+    sharded = copy.deepcopy(plain)
+    ml = torch.zeros(2, 16, dtype=torch.int64, device="cuda"); ml[:, 0] = 1
+    batches = [dict(x_f=dev(rnd((2, 1, 24, 64), 50 + i), dtype), y=dev(rnd((2, 16, 64), 60 + i), dtype), media_locations=ml) for i in range(4)]
+    hp = dict(lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    opt_p = FusedAdamW(plain.parameters(), master_dtype=master, **hp)
+    opt_s = ShardedAdamW(sharded, master_dtype=master, force_collectives=True, **hp)
+    assert opt_s.cuda and opt_s.collectives
+    for b in batches:
+        plain.zero_grad(set_to_none=True)
+        plain(**b).backward()
+        opt_p.step()
+        opt_s.zero_grad()
+        sharded(**b).backward()
+        opt_s.finish_step()
+    torch.cuda.synchronize()
+    opt_s.close()
+    assert len(opt_s.buckets) == 4                      # resampler, the hoisted to_kv weights, two blocks
+    for (n, pa), (_, pb) in zip(plain.named_parameters(), sharded.named_parameters()):
+        assert rel(pb, pa) < 1e-2, n

@@ -41,3 +41,23 @@ def test_quick_gelu_matches_torch(dtype, n):
     (yr * w.double().cpu()).sum().backward()
     tol = 2e-6 if dtype == torch.float32 else 6e-3
     assert rel(y, yr.detach()) < tol and rel(x.grad, xr.grad) < tol
+
+
+def test_shifted_ce_flags_out_of_range_labels_and_all_ignored_batches():
+    """A label outside [0, vocab) that is not ignore_index must not read out of bounds: its row (and the mean) become NaN, as loud as
+    torch's device assert; an all-ignored batch gives NaN like F.cross_entropy(reduction='mean')."""
+    from flamingo_mini_amd import functional as F
+    logits = torch.randn(2, 5, 33, device="cuda", requires_grad=True)
+    labels = torch.randint(0, 33, (2, 5), device="cuda")
+    bad = labels.clone(); bad[1, 3] = 33
+    rows = F.shifted_cross_entropy(logits, bad, reduction="none")
+    assert torch.isnan(rows[4 + 2]) and int(torch.isnan(rows).sum()) == 1
+    loss = F.shifted_cross_entropy(logits, bad)
+    assert torch.isnan(loss)
+    loss.backward()
+    assert torch.isnan(logits.grad[1, 2]).all() and not torch.isnan(logits.grad[0]).any()
+    ignored = torch.full_like(labels, -100)
+    assert torch.isnan(F.shifted_cross_entropy(logits.detach(), ignored))
+    ok = labels.clone(); ok[0, 1:] = -100
+    ref = torch.nn.functional.cross_entropy(logits.detach()[:, :-1].reshape(-1, 33), ok[:, 1:].reshape(-1))
+    assert abs(float(F.shifted_cross_entropy(logits.detach(), ok)) - float(ref)) < 1e-5

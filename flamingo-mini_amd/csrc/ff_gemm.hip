@@ -614,14 +614,16 @@ static bool big_tile(const GemmParams& P) { return P.tile == 128; }
 
 template <int BM, int BN, int AL, int BL, int NS> static int launch_bf16_dma(const GemmParams& P, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (lds > 64 * 1024) {
+    if (lds > 64 * 1024) {      // the attribute is per device: remember it per device (benign if two threads both set it)
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<BM, BN, AL, BL, NS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm dma lds=%zu): %s", lds, hipGetErrorString(e));
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
-        attr_done = true;
     }
     const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);

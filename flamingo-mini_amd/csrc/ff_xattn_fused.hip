@@ -618,9 +618,15 @@ template <typename T, int DH, int BM> static size_t bwd_lds() {
 }
 
 template <typename KernelT> static int allow_lds(KernelT kernel, size_t lds, const char* what) {
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(%s, lds=%zu): %s", what, lds, hipGetErrorString(e));
+    if (lds > 64 * 1024) {      // per kernel instantiation (this function template) and per device; the largest request so far is remembered
+        static size_t allowed[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || allowed[dev] < lds) {
+            hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(%s, lds=%zu): %s", what, lds, hipGetErrorString(e));
+            if (dev >= 0 && dev < 64) allowed[dev] = lds;
+        }
     }
     FF_CHECK(lds <= 160 * 1024, FF_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (dim too large for the fused kernel)", what, lds);
     return FF_OK;

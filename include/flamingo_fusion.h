@@ -5,6 +5,9 @@
  * sizes and a HIP stream; no torch / C++ types; kernels are enqueued on the caller's stream and never
  * synchronise or allocate.  All tensors are caller-owned, 16-byte aligned, innermost dimension contiguous.
  * Return value: FF_OK or a negative error code; ff_last_error() gives a thread-local message.
+ * State: the compute entry points keep none between calls and may be used from several threads on distinct streams / buffers.
+ * The two debugging aids ff_gemm_profile_* and ff_gemm_set_tuning are process-global switches (measurement, tile sweeps) and are NOT
+ * thread-safe: use them from one thread, with no other call in flight.
  *
  * What each entry point replaces in the reference (dhansmair/flamingo-mini, paths relative to its root):
  *   ff_resampler_fwd/bwd     PerceiverResampler.forward + its autograd   flamingo_mini/perceiver_resampler.py:143-188

@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=3, help="instrumented eager steps after the timed region (roofline objects)")
     ap.add_argument("--stock-tuning", default="on", choices=["on", "off"],
                     help="load the pre-tuned hipBLASLt solution file for the stock CLIP / GPT-2 GEMMs (PyTorch TunableOp, tuning off)")
+    ap.add_argument("--backbone-tweaks", default="on", choices=["on", "off"],
+                    help="off = untouched Hugging Face CLIP / LM (no fused QuickGELU, no patch-conv-as-matmul, no GELU module swap) and no "
+                         "pre-tuned stock-GEMM file: isolates what the fusion path alone contributes")
     ap.add_argument("--debug-phases", action="store_true", help="print host-side issue time of each phase of 5 eager steps and exit")
     ap.add_argument("--hoist-kv", default="env", choices=["env", "on", "off"],
                     help="project K / V of all cross-attention layers up front in grouped launches (env = FF_HOIST_KV, default on)")
@@ -87,6 +90,9 @@ def parse():
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
     args = ap.parse_args()
+    if args.backbone_tweaks == "off":
+        os.environ["FLAMINGO_STOCK_BACKBONES"] = "1"
+        args.stock_tuning = "off"
     for k, v in CONFIGS[args.config].items():
         if k != "what" and getattr(args, k) is None:
             setattr(args, k, v)
@@ -399,9 +405,10 @@ def main():
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
             tot_ms = sum(v["ms"] for v in groups.values())
             tot_fl = sum(v["flops"] for v in groups.values())
-            traffic = None      # HBM bytes per launch of this kernel from the committed PMC passes (profiles/r01_pmc_traffic.json)
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = None      # HBM bytes per launch of this kernel from the latest committed PMC passes (profiles/rNN_pmc_traffic.json;
+            try:                # rocprofv3 counters cannot be collected from inside this process)
+                import glob
+                with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
                     traffic = json.load(f)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pass
@@ -427,7 +434,8 @@ def main():
                                    + ("; step replayed from a captured HIP graph" + (" (RCCL all-reduces captured)" if world > 1 else "") if use_graph else "; eager launches")
                                    + graph_note + "; random-init weights, gates alpha=0.5",
                        "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
-                       "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph, "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned},
+                       "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph, "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
+                       "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,
         }
         if attn:    # north star: throughput of the softmax(QK^T)V core as a fraction of the HBM roofline (8 TB/s spec peak)

@@ -54,7 +54,15 @@ class _QuickGELU(torch.nn.Module):
         return x * torch.sigmoid(1.702 * x)
 
 
+def stock_only() -> bool:
+    """FLAMINGO_STOCK_BACKBONES=1: leave the frozen backbones exactly as Hugging Face builds them (no op substitutions at all), so the
+    contribution of the fusion path to a benchmark can be separated from these backbone touch-ups (bench.py --backbone-tweaks off)."""
+    return os.environ.get("FLAMINGO_STOCK_BACKBONES", "0") == "1"
+
+
 def _tune_vision_encoder(model):
+    if stock_only():
+        return model
     vm = getattr(model, "vision_model", model)      # transformers < 5 nests the tower under .vision_model
     emb = vm.embeddings.patch_embedding
     if type(emb) is torch.nn.Conv2d:
@@ -68,6 +76,8 @@ def _tune_vision_encoder(model):
 def _tune_gpt2(model):
     """HF's NewGELUActivation spells the tanh GELU as ~8 elementwise kernels; torch's fused gelu(approximate='tanh') is the
     same function in one kernel (forward and backward)."""
+    if stock_only():
+        return model
     for block in model.transformer.h:
         if type(block.mlp.act).__name__ == "NewGELUActivation":
             block.mlp.act = torch.nn.GELU(approximate="tanh")

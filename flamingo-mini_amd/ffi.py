@@ -167,10 +167,18 @@ def lib() -> C.CDLL:
     return handle
 
 
+_TRACE = os.environ.get("FF_TRACE", "0") == "1"      # debugging aid: name every library call on stderr and synchronise after it
+
+
 def check(rc: int, what: str) -> None:
     if rc != FF_OK:
         msg = lib().ff_last_error().decode(errors="replace")
         raise FusionLibraryError(f"{what} failed (code {rc}): {msg}")
+    if _TRACE:
+        import sys
+        print(f"[ff] {what} enqueued", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        print(f"[ff] {what} done", file=sys.stderr, flush=True)
 
 
 def dtype_code(dt: torch.dtype) -> int:

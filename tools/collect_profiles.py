@@ -1,0 +1,82 @@
+"""Turn one tools/gpu_final.sh session (gpurun_out/<tag>/) into the committed artefacts profiles/<round>_*:
+    python tools/collect_profiles.py gpurun_out/final_r02 r02
+bench line, rocprofv3 kernel stats + summary, HBM traffic per launch (FETCH_SIZE / WRITE_SIZE passes), MFMA-busy (SQ pass)."""
+import csv, glob, json, os, shutil, subprocess, sys
+from collections import defaultdict
+
+src, rnd = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def find(sub, pat):
+    hits = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
+    assert hits, (sub, pat)
+    return hits[0]
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def is_ours(name):
+    return "ff::" in name or "_ZN2ff" in name
+
+
+stats = find("prof", "*kernel_stats.csv")
+shutil.copy(stats, os.path.join(P, f"{rnd}_bench_b32_bf16_kernel_stats.csv"))
+prof_line = json.loads(open(os.path.join(src, "prof_bench.json")).read().strip().splitlines()[-1])
+steps_total = 2 + prof_line["warmup"] + prof_line["steps"]          # 2 eager warm-up steps inside GraphedTrainStep + the replays
+with open(os.path.join(P, f"{rnd}_bench_b32_bf16_summary.md"), "w") as f:
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_rocprof.py"), stats, "--steps-total", str(steps_total)], stdout=f, check=True)
+
+# HBM traffic: counter values are KB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)
+def pmc(sub):
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    with open(find(sub, "*counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if is_ours(r["Kernel_Name"]):
+                a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
+                a[0] += 1; a[1] += float(r["Counter_Value"])
+    return acc
+
+fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
+traffic = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over one eager step of the default bench; counter values are KB; "
+                    "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 "
+                    "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated; memory-side counters include Infinity-Cache hits.", "kernels": {}}
+for k in sorted(fetch, key=lambda k: -fetch[k]["FETCH_SIZE"][1]):
+    n, f_kb = fetch[k]["FETCH_SIZE"]
+    wn, w_kb = write.get(k, {}).get("WRITE_SIZE", [1, 0.0])
+    traffic["kernels"][k] = {"launches": n, "fetch_kb_avg": round(f_kb / n, 1), "write_kb_avg": round(w_kb / max(wn, 1), 1),
+                             "hbm_bytes_per_launch": int((2 * f_kb / n + w_kb / max(wn, 1)) * 1024)}
+json.dump(traffic, open(os.path.join(P, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+
+sq = pmc("pmc_sq")
+dur = defaultdict(lambda: [0, 0.0])
+with open(find("pmc_sq", "*kernel_trace.csv")) as f:
+    for r in csv.DictReader(f):
+        if is_ours(r["Kernel_Name"]):
+            d = dur[short(r["Kernel_Name"])]
+            d[0] += 1; d[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+busy = {"_note": "rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES over one eager step of the default bench; per-launch "
+                 "averages.  mfma_busy_frac_of_kernel = SQ_VALU_MFMA_BUSY_CYCLES / (avg duration * 2.4 GHz * 1024 SIMDs): the share of the chip's SIMD-cycles "
+                 "during the kernel in which the MFMA pipe was busy (durations under counter collection are a few % longer than in the plain trace).", "kernels": {}}
+for k in sorted(sq, key=lambda k: -sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1]):
+    n = sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0]
+    us = dur[k][1] / max(dur[k][0], 1)
+    mf = sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1] / n
+    busy["kernels"][k] = {"launches": n, "avg_us": round(us, 1), "sq_busy_cu_cycles": int(sq[k]["SQ_BUSY_CU_CYCLES"][1] / n), "sq_valu_mfma_busy_cycles": int(mf),
+                          "sq_waves": int(sq[k]["SQ_WAVES"][1] / n), "mfma_busy_frac_of_kernel": round(mf / (us * 1e-6 * 2.4e9 * 1024), 3) if us else None}
+json.dump(busy, open(os.path.join(P, f"{rnd}_sq_mfma_busy.json"), "w"), indent=1)
+
+# the bench line: take `traffic` of its dominant kernel from the PMC file of the SAME session
+line = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+k = line["roofline"]["kernel"]
+line["roofline"]["traffic"] = traffic["kernels"].get(k, {}).get("hbm_bytes_per_launch")
+json.dump(line, open(os.path.join(P, f"{rnd}_bench_default.json"), "w"), indent=1)
+stock = json.loads(open(os.path.join(src, "bench_stock_backbones.json")).read().strip().splitlines()[-1])
+json.dump(stock, open(os.path.join(P, f"{rnd}_bench_stock_backbones.json"), "w"), indent=1)
+for extra in ("gemm_table.txt",):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(P, f"{rnd}_{extra}"))
+print("dominant kernel", k, "traffic", line["roofline"]["traffic"], "frac", line["roofline"]["frac"], "value", line["value"])

@@ -287,7 +287,10 @@ def main():
         model.flamingo.hoist_kv = args.hoist_kv == "on"
     params = [p for p in model.parameters_trainable()]
     n_trainable = sum(p.numel() for p in params)
-    use_graph = args.graph in ("on", "auto")
+    # KNOWN ISSUE: replaying the captured step of config E (opt-6.7b, 4 x 1024 tokens) ends in a GPU memory access fault on this
+    # software stack (ROCm 7.0.2 / torch 2.10), with the fused xattn kernels on or off; the same step runs eagerly (and configs A-D
+    # replay fine).  Not root-caused yet, so `auto` launches config E eagerly; `--graph on` still forces the capture.
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.config != "E")
     if args.no_optimizer:
         opt = None
     elif args.optimizer == "fused":

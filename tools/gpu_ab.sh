@@ -1,4 +1,5 @@
 #!/bin/bash
+ulimit -c 0   # no core files: a GPU fault must not fill the scratch disk
 # A/B on ONE box: tools/gpu_ab.sh <tag> "<ENV1>" "<ENV2>" ...   (each ENV string is exported for one bench run, e.g. "FF_XATTN_FUSED=0")
 tag=$1; shift
 out=gpurun_out/$tag; mkdir -p $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+ulimit -c 0   # no core files: a GPU fault must not fill the scratch disk
 # bench.py on every BASELINE.json config: tools/gpu_configs.sh <tag> [configs...]
 tag=$1; shift; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 for c in "$@"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+ulimit -c 0   # no core files: a GPU fault must not fill the scratch disk
 # Round-end measurement session on ONE box: full parity suite, the default bench line, the rocprofv3 kernel trace of the same command,
 # the two PMC traffic passes and the SQ MFMA-busy pass (separate runs, --kernel-trace only), the backbone-tweaks-off line.
 #   tools/gpu_final.sh <tag>          results under gpurun_out/<tag>/ ; tools/collect_profiles.py turns them into profiles/rNN_*

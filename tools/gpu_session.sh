@@ -1,4 +1,5 @@
 #!/bin/bash
+ulimit -c 0   # no core files: a GPU fault must not fill the scratch disk
 # One GPU-box session: parity tests (all, no -x), default bench with the per-shape GEMM table.  Usage: tools/gpu_session.sh <tag> [extra bench args]
 tag=${1:-run}; shift
 out=gpurun_out/$tag; mkdir -p $out

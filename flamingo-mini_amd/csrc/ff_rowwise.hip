@@ -6,6 +6,13 @@
 
 namespace ff {
 
+#ifdef FF_XA_TIMELINE   // debug build (tools/build_timeline.sh): phase timestamps of ln_bwd_fused_kernel, read with ff_debug_ln_timeline_read
+__device__ unsigned long long g_ln_timeline[4096 * 8];
+#define FF_LTL(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_ln_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FF_LTL(i) do { } while (0)
+#endif
+
 // VEC consecutive elements as floats (VEC == Vec<T>::N -> one 16-byte access, VEC == 1 -> scalar fallback)
 template <typename T, int VEC> FF_DEV void ld(const T* p, float (&o)[VEC]) {
     if constexpr (VEC == 1) o[0] = to_f32(p[0]);
@@ -169,9 +176,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, T* dx,
                                                            const T* dx_res, const T* __restrict__ dot_a, const T* __restrict__ dot_b,
                                                            float* __restrict__ partial, int rows_per_block) {
+    FF_LTL(0);
     const LnArgs a = fetch_args(a_in);
     pin_args(dy, x, add, gamma, mean, rstd, dx, dx_res, dot_a, dot_b, partial, rows_per_block);
-    extern __shared__ float sacc[];   // [2][cols]
+    extern __shared__ __attribute__((aligned(16))) float sacc[];   // [4 waves][2][cols]
+    FF_LTL(1);
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = a.cols / VEC;
@@ -270,30 +279,39 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
             }
         }
     }
-    // cross-wave accumulation of the column partials (waves take turns on the LDS image)
-    for (int ww = 0; ww < 4; ww++) {
-        if (w == ww) {
+    FF_LTL(2);
+    // cross-wave accumulation of the column partials: every wave parks its registers in its own LDS image [wave][2][cols] with 16-byte
+    // writes, one barrier, then the block adds the four images column by column on the way out.  (The first version let the waves take
+    // turns on ONE image with scalar read-modify-writes: 6.2 of the kernel's 12 us at 1024 x 1280 - tools/ln_timeline.py.)
+    {
+        float* mine = sacc + (size_t)w * 2 * a.cols;
 #pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                const int c = lane + 64 * i;
-                if (c < nchunk) {
+        for (int i = 0; i < NCH; i++) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
 #pragma unroll
-                    for (int e = 0; e < VEC; e++) {
-                        const int col = c * VEC + e;
-                        if (ww == 0) { sacc[col] = accg[i][e]; sacc[a.cols + col] = accb[i][e]; }
-                        else { sacc[col] += accg[i][e]; sacc[a.cols + col] += accb[i][e]; }
-                    }
+                for (int e = 0; e < VEC; e += 4) {
+                    *(f32x4*)(mine + c * VEC + e) = f32x4{accg[i][e], accg[i][e + 1], accg[i][e + 2], accg[i][e + 3]};
+                    *(f32x4*)(mine + a.cols + c * VEC + e) = f32x4{accb[i][e], accb[i][e + 1], accb[i][e + 2], accb[i][e + 3]};
                 }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
+    FF_LTL(3);
     const long long P = 2LL * a.cols + 2;
     float* out = partial + (long long)blockIdx.x * P;
-    for (int i = threadIdx.x; i < 2 * a.cols; i += 256) out[i] = sacc[i];
+    for (int i = threadIdx.x * 4; i < 2 * a.cols; i += 256 * 4) {      // cols % 4 == 0 on this path
+        const f32x4 s0 = *(const f32x4*)(sacc + i), s1 = *(const f32x4*)(sacc + 2 * a.cols + i);
+        const f32x4 s2 = *(const f32x4*)(sacc + 4 * a.cols + i), s3 = *(const f32x4*)(sacc + 6 * a.cols + i);
+        float* o = out + i;                                              // (the partial rows are only 8-byte aligned: P is even)
+        o[0] = (s0[0] + s1[0]) + (s2[0] + s3[0]); o[1] = (s0[1] + s1[1]) + (s2[1] + s3[1]);
+        o[2] = (s0[2] + s1[2]) + (s2[2] + s3[2]); o[3] = (s0[3] + s1[3]) + (s2[3] + s3[3]);
+    }
     da = block_sum<4>(da, red);
     db = block_sum<4>(db, red);
     if (threadIdx.x == 0) { out[2 * a.cols] = da; out[2 * a.cols + 1] = db; }
+    FF_LTL(4);
 }
 
 // out[idx] = sum over blocks of partial[block][idx]; 16 outputs x 16 block-lanes per workgroup, 8 loads in flight per thread
@@ -539,7 +557,7 @@ static int ln_fused_blocks(int rows, int& rows_per_block) {
 static bool ln_fused_ok(int dtype, int cols, bool vec) {
     if (!vec) return false;
     const int n = dtype == FF_DTYPE_BF16 ? 8 : 4;
-    return cdiv(cols / n, 64) <= 8 && (size_t)2 * cols * sizeof(float) <= 96 * 1024;
+    return cdiv(cols / n, 64) <= 8 && (size_t)8 * cols * sizeof(float) <= 150 * 1024;      // four [2][cols] fp32 images in LDS
 }
 size_t layernorm_bwd_workspace(int rows, int cols) {
     int rpb;
@@ -554,13 +572,17 @@ static int launch_ln_fused(const LnArgs& a, const void* dy, const void* x, const
     int rpb;
     const int nblk = ln_fused_blocks(a.rows, rpb);
     const int nch = cdiv(a.cols / VEC, 64);
-    const size_t lds = (size_t)2 * a.cols * sizeof(float);
+    const size_t lds = (size_t)8 * a.cols * sizeof(float);
 #define FF_LN_LAUNCH(NCH)                                                                                                                 \
     do {                                                                                                                                  \
-        static bool attr = false;                                                                                                         \
-        if (!attr && lds > 48 * 1024) {                                                                                                   \
-            hipFuncSetAttribute((const void*)ln_bwd_fused_kernel<T, VEC, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);    \
-            attr = true;                                                                                                                  \
+        if (lds > 48 * 1024) {                                                                                                            \
+            static bool attr[64] = {};                                                                                                    \
+            int dev = 0;                                                                                                                  \
+            (void)hipGetDevice(&dev);                                                                                                     \
+            if (dev < 0 || dev >= 64 || !attr[dev]) {                                                                                     \
+                hipFuncSetAttribute((const void*)ln_bwd_fused_kernel<T, VEC, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+                if (dev >= 0 && dev < 64) attr[dev] = true;                                                                               \
+            }                                                                                                                             \
         }                                                                                                                                 \
         ln_bwd_fused_kernel<T, VEC, NCH><<<dim3(nblk), dim3(256), lds, st_>>>(a, (const T*)dy, (const T*)x, (const T*)add, (const T*)gamma, \
                                                                               mean, rstd, (T*)dx, (const T*)dx_res, (const T*)dots.a,     \
@@ -725,3 +747,9 @@ extern "C" int ff_gate_grad(int dtype, int rows, int cols, const void* a, const 
 extern "C" int ff_text_time(int batch, int n_tokens, const void* media_locations, int elem_bytes, int* text_time, ff_stream_t stream) {
     return ff::text_time(batch, n_tokens, media_locations, elem_bytes, text_time, (hipStream_t)stream);
 }
+
+#ifdef FF_XA_TIMELINE
+extern "C" int ff_debug_ln_timeline_read(unsigned long long* out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff::g_ln_timeline), sizeof(unsigned long long) * 8 * n_blocks);
+}
+#endif

@@ -11,7 +11,7 @@
 namespace ff {
 
 constexpr int kAdamTensors = 32;
-constexpr int kAdamChunk = 256 * 32;   // elements per workgroup
+constexpr int kAdamChunk = 256 * 128;  // elements per workgroup (16 sweeps of 8-element vectors: the per-workgroup table lookup is amortised)
 
 struct AdamTable {
     void* p[kAdamTensors];

@@ -180,6 +180,25 @@ def caption_leg(args, model, batch, device):
             "ms_per_decode_step": round(dt / new * 1e3, 2), "note": "greedy, cached xattn K/V + LM cache, includes the prompt/CLIP/resampler step"}
 
 
+def _usable_cores() -> int:
+    """Host cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota (a container can see 64 CPUs and
+    own 8 of them - asking torch for 64 threads then oversubscribes every core)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(args):
     """the stock-PyTorch CPU restatement of the hot path (oracle/torch_port.py - the reference itself cannot travel to
     this box), fp32, torch.set_num_threads(all host cores), 2 warm-up runs + the median of 5, on a bounded sample of config B
@@ -187,18 +206,22 @@ def cpu_baseline(args):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from detgen import det, resampler_params, xattn_params
     from oracle import torch_port as TP
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     old_threads = torch.get_num_threads()
     torch.set_num_threads(cores)
 
-    def median_ms(fn, warm=2, reps=5):
-        for _ in range(warm):
-            fn()
+    def median_ms(fn, warm=2, reps=5, budget_s=25.0):
+        deadline = time.perf_counter() + budget_s   # every leg is bounded: a slow host shortens the sample instead of stalling the bench
         ts = []
-        for _ in range(reps):
+        for i in range(warm + reps):
             t0 = time.perf_counter()
             fn()
-            ts.append(time.perf_counter() - t0)
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                ts.append(dt)
+            if time.perf_counter() + dt > deadline and (ts or i >= 1):      # no time for another run: keep what was measured
+                ts = ts or [dt]
+                break
         return sorted(ts)[len(ts) // 2]
 
     b, L, d, dv, n_timed, n_blocks = 8, 32, 1280, 1024, 6, 36
@@ -223,7 +246,7 @@ def cpu_baseline(args):
     t_blk = median_ms(blocks_step) / n_timed
     hot = t_rs + n_blocks * t_blk
     out = {"value": round(b / hot, 3), "unit": "images/sec (hot path only: resampler + 36 xattn blocks, fwd+bwd, fp32)", "cores": int(cores),
-           "kind": "port", "sample": f"torch CPU restatement (oracle/torch_port.py), {cores} threads, warm-up 2 + median of 5, batch {b} of config B: "
+           "kind": "port", "sample": f"torch CPU restatement (oracle/torch_port.py), {cores} threads (affinity / cgroup quota), warm-up 2 + median of up to 5 (time-bounded), batch {b} of config B: "
                                      f"resampler fwd+bwd {t_rs:.3f}s + {n_timed} of 36 gated blocks fwd+bwd ({t_blk:.4f}s each, extrapolated x36); "
                                      "excludes the frozen CLIP / GPT-2 backbones"}
     try:     # config A (BASELINE configs[0]) end to end on the host: the drop-in model with its fused entry points pointed at the torch port

@@ -147,10 +147,13 @@ class ShardedAdamW:
         self.master_dtype = master_dtype
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.step_count = 0
-        self.buckets = {}            # key (ids of the owners' parameters) -> state
+        self.buckets = {}            # position of the bucket in the backward pass -> state
         self._work: List = []
         self._update_fn = update_fn or self._hip_update
-        fused = {id(p) for m in model.modules() if hasattr(m, "fused_params") for p in m.fused_params()}
+        fused_list = [p for m in model.modules() if hasattr(m, "fused_params") for p in m.fused_params()]
+        fused = {id(p) for p in fused_list}
+        self._canonical = {p.data_ptr(): p for p in fused_list}     # the tensors a backward hands us may be other wrappers of the same storage
+        self._arrival = 0                                           # buckets are identified by their position in the backward pass
         self.loose = [p for p in model.parameters() if p.requires_grad and id(p) not in fused]
         self._loose_work: List = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_loose) for p in self.loose]
@@ -176,9 +179,17 @@ class ShardedAdamW:
                                           None, (C.c_longlong * 1)(p.numel()), ffi.stream_handle(p.device)), "ff_adamw_step_mixed")
 
     def _bucket_state(self, flat, owners):
-        key = tuple(id(p) for p, _, _ in owners)
+        key = self._arrival                      # the order of the buckets within a backward pass is the same every step (static graph)
+        self._arrival += 1
+        sig = (flat.numel(), tuple((off, cnt) for _, off, cnt in owners))
         st = self.buckets.get(key)
+        if st is not None and st["sig"] != sig:
+            raise RuntimeError("ShardedAdamW: the gradient buckets of this backward pass do not arrive in the order of the first one")
         if st is None:
+            missing = [tuple(p.shape) for p, _, _ in owners if p.data_ptr() not in self._canonical]
+            if missing:
+                raise RuntimeError(f"ShardedAdamW: a gradient bucket names tensors {missing} that are not storage of this model's fused parameters")
+            owners = [(self._canonical[p.data_ptr()], off, cnt) for p, off, cnt in owners]
             n = flat.numel()
             assert n % self.world == 0, "flat gradient buffers are padded to a multiple of 1024 elements (functional._flat_offsets)"
             shard = n // self.world
@@ -189,7 +200,7 @@ class ShardedAdamW:
                     p.data = pflat[off:off + cnt].view(p.shape)
             lo = self.rank * shard
             sdt = torch.float32 if (self.master_dtype is not None and flat.dtype == torch.bfloat16) else flat.dtype
-            st = dict(params=[p for p, _, _ in owners], pflat=pflat, shard=shard, lo=lo, m=torch.zeros(shard, dtype=sdt, device=flat.device), v=torch.zeros(shard, dtype=sdt, device=flat.device),
+            st = dict(sig=sig, params=[p for p, _, _ in owners], pflat=pflat, shard=shard, lo=lo, m=torch.zeros(shard, dtype=sdt, device=flat.device), v=torch.zeros(shard, dtype=sdt, device=flat.device),
                       master=pflat[lo:lo + shard].to(torch.float32) if sdt != flat.dtype else None, gshard=torch.empty(shard, dtype=flat.dtype, device=flat.device))
             self.buckets[key] = st
         return st
@@ -242,6 +253,7 @@ class ShardedAdamW:
         for ev in self._work:
             torch.cuda.current_stream().wait_event(ev)
         self._work.clear()
+        self._arrival = 0
         self.step_count += 1
         if self._loose_opt is not None:
             self._loose_opt.step()

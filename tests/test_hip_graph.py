@@ -177,6 +177,6 @@ def test_sharded_adamw_on_one_rccl_rank_equals_fused_adamw(one_rank_rccl, master
         opt_s.finish_step()
     torch.cuda.synchronize()
     opt_s.close()
-    assert len(opt_s.buckets) == 4                      # resampler, the hoisted to_kv weights, two blocks
+    assert len(opt_s.buckets) == 4, {k: st["sig"][0] for k, st in opt_s.buckets.items()}     # resampler, the hoisted to_kv weights, two blocks
     for (n, pa), (_, pb) in zip(plain.named_parameters(), sharded.named_parameters()):
         assert rel(pb, pa) < 1e-2, n

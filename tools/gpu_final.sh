@@ -5,16 +5,16 @@ ulimit -c 0   # no core files: a GPU fault must not fill the scratch disk
 #   tools/gpu_final.sh <tag>          results under gpurun_out/<tag>/ ; tools/collect_profiles.py turns them into profiles/rNN_*
 tag=$1; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 cd $R
-python -m pytest tests -m gpu -q -p no:cacheprovider > $out/pytest.txt 2>&1; echo "pytest rc=$?"; tail -n 3 $out/pytest.txt
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/pytest.txt 2>&1; echo "pytest rc=$?"; tail -n 3 $out/pytest.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; echo "smoke rc=$?"; tail -n 2 $out/smoke.txt
-python bench.py --gemm-table $out/gemm_table.txt > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"; cut -c1-600 $out/bench_default.json
-python bench.py --backbone-tweaks off --no-cpu-baseline --caption-tokens 0 --profile-steps 0 > $out/bench_stock_backbones.json 2> $out/bench_stock_backbones.err; cut -c1-200 $out/bench_stock_backbones.json
+timeout 420 python bench.py --gemm-table $out/gemm_table.txt > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"; cut -c1-600 $out/bench_default.json
+timeout 240 python bench.py --backbone-tweaks off --no-cpu-baseline --caption-tokens 0 --profile-steps 0 > $out/bench_stock_backbones.json 2> $out/bench_stock_backbones.err; cut -c1-200 $out/bench_stock_backbones.json
 cd /tmp
 B="python $R/bench.py --no-cpu-baseline --caption-tokens 0 --profile-steps 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- $B --steps 5 --warmup 2 > $out/prof_bench.json 2> $out/prof.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_sq.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- $B --steps 5 --warmup 2 > $out/prof_bench.json 2> $out/prof.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_write.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_sq.err
 cd $R
 find $out -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
 # keep the merged payload small: drop the raw traces, keep stats + counter tables

@@ -279,6 +279,23 @@ def cpu_baseline(args):
     return out
 
 
+def _dump_allocator_map(path):
+    """Every allocator segment and block (address, size, state, the innermost repository / torch frames that allocated it), gzip JSON:
+    a GPU memory-access fault prints an address, this says whose buffer it is next to."""
+    import gzip
+    snap = torch.cuda.memory_snapshot()
+    segs = []
+    for sg in snap:
+        blocks = []
+        for b in sg.get("blocks", []):
+            fr = [f"{os.path.basename(f['filename'])}:{f['line']}:{f['name']}" for f in (b.get("frames") or [])[:40]
+                  if "flamingo" in f["filename"] or "bench.py" in f["filename"] or "transformers" in f["filename"]][:5]
+            blocks.append([b.get("address", 0), b["size"], b.get("requested_size", 0), b["state"], fr])
+        segs.append(dict(address=sg["address"], size=sg["total_size"], pool=str(sg.get("segment_pool_id")), stream=sg.get("stream", 0), blocks=blocks))
+    with gzip.open(path, "wt") as f:
+        json.dump(segs, f)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,6 +312,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    memsnap = os.environ.get("FF_BENCH_MEMSNAP", "")            # debugging aid: allocator map (with allocation stacks) before the timed region
+    if memsnap:
+        torch.cuda.memory._record_memory_history(context="alloc", stacks="python", max_entries=400000)
 
     from flamingo_mini_amd import ffi
     from flamingo_mini_amd.data_parallel import GradientAllReducer
@@ -375,6 +395,8 @@ def main():
     else:
         step = eager_step
 
+    if memsnap:
+        _dump_allocator_map(memsnap)
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()

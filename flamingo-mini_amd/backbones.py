@@ -149,6 +149,8 @@ def load_language_model(config):
         elif not _tiny_override(config, "lm"):
             raise ValueError(f"no built-in architecture for {name}; known: {sorted(GPT2)}")
         kw.update(_tiny_override(config, "lm"))
+        if os.environ.get("FLAMINGO_LM_ATTN"):
+            kw["attn_implementation"] = os.environ["FLAMINGO_LM_ATTN"]
         return _tune_gpt2(GPT2LMHeadModel(GPT2Config(**kw)))
     from transformers import OPTConfig, OPTForCausalLM
     kw = {}
@@ -159,4 +161,6 @@ def load_language_model(config):
     elif not _tiny_override(config, "lm"):
         raise ValueError(f"no built-in architecture for {name}; known: {sorted(OPT)}")
     kw.update(_tiny_override(config, "lm"))
+    if os.environ.get("FLAMINGO_LM_ATTN"):              # debugging aid: "eager" / "sdpa" attention inside the stock LM
+        kw["attn_implementation"] = os.environ["FLAMINGO_LM_ATTN"]
     return OPTForCausalLM(OPTConfig(**kw))

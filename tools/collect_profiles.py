@@ -1,12 +1,14 @@
 """Turn one tools/gpu_final.sh session (gpurun_out/<tag>/) into the committed artefacts profiles/<round>_*:
-    python tools/collect_profiles.py gpurun_out/final_r02 r02
+    python tools/collect_profiles.py gpurun_out/final_r02 r02 [outdir]
+(tools/gpu_final.sh runs it on the GPU box with outdir = gpurun_out/<tag>/collected and drops the raw traces, which exceed what gpurun copies back)
 bench line, rocprofv3 kernel stats + summary, HBM traffic per launch (FETCH_SIZE / WRITE_SIZE passes), MFMA-busy (SQ pass)."""
 import csv, glob, json, os, shutil, subprocess, sys
 from collections import defaultdict
 
 src, rnd = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles")
+P = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
 
 
 def find(sub, pat):

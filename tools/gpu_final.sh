@@ -16,6 +16,12 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ou
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_write.err
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_sq.err
 cd $R
-find $out -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
-# keep the merged payload small: drop the raw traces, keep stats + counter tables
-find $out -name "*kernel_trace.csv" -path "*prof/*" -delete
+grep -E "^(FAILED|ERROR)" $out/pytest.txt | cut -c1-220
+if ! python tools/collect_profiles.py $out r02 $out/collected > $out/collect.txt 2>&1; then   # keep the inputs (compressed) if the post-processing failed
+  mkdir -p $out/raw; for f in $(find $out/prof $out/pmc_* -name "*kernel_stats.csv" -o -name "*counter_collection.csv" -o -path "*pmc_sq*" -name "*kernel_trace.csv"); do
+    gzip -c $f > $out/raw/$(echo $f | sed "s#$out/##; s#/#_#g").gz; done
+fi
+tail -n 2 $out/collect.txt
+# gpurun copies back at most 64 MiB: keep the collected summaries and the small logs, drop the raw traces
+rm -rf $out/prof $out/pmc_fetch $out/pmc_write $out/pmc_sq
+du -sh $out

@@ -25,6 +25,17 @@ import torch.distributed as dist
 from . import functional as F
 
 
+def _bucket_is_ours(owners, ids) -> bool:
+    """The gradient-ready callbacks are process-wide: a second model in the process (an evaluation copy, a test's reference model)
+    announces its buckets too.  A bucket belongs to a reducer iff all of its parameters are that reducer's model's."""
+    mine = [id(p) in ids for p, _, _ in owners]
+    if all(mine):
+        return True
+    if any(mine):
+        raise RuntimeError("a gradient bucket mixes parameters of the wrapped model with foreign ones")
+    return False
+
+
 class GradientAllReducer:
     def __init__(self, model: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False):
         """force_collectives: issue the collectives even in a 1-rank group (exercises the RCCL path on a single GPU)."""
@@ -39,6 +50,7 @@ class GradientAllReducer:
         self._early = set()                         # ids of parameters already reduced in this step
         self._sync = True
         fused = {id(p) for m in model.modules() if hasattr(m, "fused_params") for p in m.fused_params()}
+        self._fused_ids = fused
         self.loose = [p for p in model.parameters() if p.requires_grad and id(p) not in fused]
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_param) for p in self.loose]
         F.add_grad_ready_callback(self._on_bucket)
@@ -64,7 +76,7 @@ class GradientAllReducer:
             self._reduce_async(p.grad, [])
 
     def _on_bucket(self, flat: torch.Tensor, owners=()):
-        if not (self.active and self._sync):
+        if not (self.active and self._sync) or not owners or not _bucket_is_ours(owners, self._fused_ids):
             return
         es = flat.element_size()
         if any(p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + off * es for p, off, _ in owners):     # (a deferred gradient that autograd
@@ -150,9 +162,8 @@ class ShardedAdamW:
         self.buckets = {}            # position of the bucket in the backward pass -> state
         self._work: List = []
         self._update_fn = update_fn or self._hip_update
-        fused_list = [p for m in model.modules() if hasattr(m, "fused_params") for p in m.fused_params()]
-        fused = {id(p) for p in fused_list}
-        self._canonical = {p.data_ptr(): p for p in fused_list}     # the tensors a backward hands us may be other wrappers of the same storage
+        fused = {id(p) for m in model.modules() if hasattr(m, "fused_params") for p in m.fused_params()}
+        self._fused_ids = fused
         self._arrival = 0                                           # buckets are identified by their position in the backward pass
         self.loose = [p for p in model.parameters() if p.requires_grad and id(p) not in fused]
         self._loose_work: List = []
@@ -186,10 +197,6 @@ class ShardedAdamW:
         if st is not None and st["sig"] != sig:
             raise RuntimeError("ShardedAdamW: the gradient buckets of this backward pass do not arrive in the order of the first one")
         if st is None:
-            missing = [tuple(p.shape) for p, _, _ in owners if p.data_ptr() not in self._canonical]
-            if missing:
-                raise RuntimeError(f"ShardedAdamW: a gradient bucket names tensors {missing} that are not storage of this model's fused parameters")
-            owners = [(self._canonical[p.data_ptr()], off, cnt) for p, off, cnt in owners]
             n = flat.numel()
             assert n % self.world == 0, "flat gradient buffers are padded to a multiple of 1024 elements (functional._flat_offsets)"
             shard = n // self.world
@@ -206,7 +213,7 @@ class ShardedAdamW:
         return st
 
     def _on_bucket(self, flat: torch.Tensor, owners=()):
-        if not owners:
+        if not owners or not _bucket_is_ours(owners, self._fused_ids):
             return
         st = self._bucket_state(flat, owners)
         step = self.step_count + 1

@@ -129,7 +129,15 @@ def _sharded_worker(rank, world, port, out_dir, hoist_kv):
         _loss(model, z, [rank]).backward()
         opt.finish_step()
     state_elems = sum(st["m"].numel() for st in opt.buckets.values())
-    np.savez(os.path.join(out_dir, f"sharded{rank}.npz"), state_elems=state_elems,
+    # a second model in the same process announces its gradient buckets through the same process-wide callbacks: not ours, ignored
+    n_buckets = len(opt.buckets)
+    other, _ = _build_tiny(hoist_kv)
+    before = [p.detach().clone() for p in other.parameters() if p.requires_grad]
+    _loss(other, z, [rank]).backward()
+    foreign_ok = int(len(opt.buckets) == n_buckets and opt._arrival == 0 and
+                     all(torch.equal(a, b) for a, b in zip(before, [p for p in other.parameters() if p.requires_grad])))
+    opt.close()
+    np.savez(os.path.join(out_dir, f"sharded{rank}.npz"), state_elems=state_elems, foreign_ok=foreign_ok,
              **{k: p.detach().numpy().copy() for k, p in model.named_parameters() if p.requires_grad})
     dist.barrier()
     dist.destroy_process_group()
@@ -147,6 +155,7 @@ def test_sharded_adamw_two_ranks_equal_single_process_adamw(tmp_path, hoist_kv):
         model.zero_grad(set_to_none=True)
         ((_loss(model, z, [0]) + _loss(model, z, [1])) / 2).backward()
         ref.step()
+    assert int(r0["foreign_ok"]) == 1 and int(r1["foreign_ok"]) == 1
     fused_total = 0
     for k, p in model.named_parameters():
         if not p.requires_grad:

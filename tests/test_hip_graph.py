@@ -168,15 +168,17 @@ def test_sharded_adamw_on_one_rccl_rank_equals_fused_adamw(one_rank_rccl, master
     opt_p = FusedAdamW(plain.parameters(), master_dtype=master, **hp)
     opt_s = ShardedAdamW(sharded, master_dtype=master, force_collectives=True, **hp)
     assert opt_s.cuda and opt_s.collectives
-    for b in batches:
-        plain.zero_grad(set_to_none=True)
-        plain(**b).backward()
-        opt_p.step()
-        opt_s.zero_grad()
-        sharded(**b).backward()
-        opt_s.finish_step()
-    torch.cuda.synchronize()
-    opt_s.close()
+    try:
+        for b in batches:
+            plain.zero_grad(set_to_none=True)
+            plain(**b).backward()            # (its buckets reach opt_s's process-wide callback too and must be ignored: not its model)
+            opt_p.step()
+            opt_s.zero_grad()
+            sharded(**b).backward()
+            opt_s.finish_step()
+        torch.cuda.synchronize()
+    finally:
+        opt_s.close()
     assert len(opt_s.buckets) == 4, {k: st["sig"][0] for k, st in opt_s.buckets.items()}     # resampler, the hoisted to_kv weights, two blocks
     for (n, pa), (_, pb) in zip(plain.named_parameters(), sharded.named_parameters()):
         assert rel(pb, pa) < 1e-2, n

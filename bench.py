@@ -312,6 +312,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if os.environ.get("FF_BENCH_SDPA"):                          # debugging aid: restrict torch's SDPA backends inside the stock backbones
+        want = os.environ["FF_BENCH_SDPA"]
+        torch.backends.cuda.enable_flash_sdp(want == "flash")
+        torch.backends.cuda.enable_mem_efficient_sdp(want == "efficient")
+        torch.backends.cuda.enable_math_sdp(want == "math")
     memsnap = os.environ.get("FF_BENCH_MEMSNAP", "")            # debugging aid: allocator map (with allocation stacks) before the timed region
     if memsnap:
         torch.cuda.memory._record_memory_history(context="alloc", stacks="python", max_entries=400000)

@@ -151,6 +151,9 @@ def load_language_model(config):
         kw.update(_tiny_override(config, "lm"))
         if os.environ.get("FLAMINGO_LM_ATTN"):
             kw["attn_implementation"] = os.environ["FLAMINGO_LM_ATTN"]
+        if os.environ.get("FLAMINGO_LM_DROPOUT"):           # debugging aid: dropout probability inside the stock LM
+            kw.update(attn_pdrop=float(os.environ["FLAMINGO_LM_DROPOUT"]), resid_pdrop=float(os.environ["FLAMINGO_LM_DROPOUT"]),
+                      embd_pdrop=float(os.environ["FLAMINGO_LM_DROPOUT"]))
         return _tune_gpt2(GPT2LMHeadModel(GPT2Config(**kw)))
     from transformers import OPTConfig, OPTForCausalLM
     kw = {}

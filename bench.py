@@ -335,9 +335,10 @@ def main():
         model.flamingo.hoist_kv = args.hoist_kv == "on"
     params = [p for p in model.parameters_trainable()]
     n_trainable = sum(p.numel() for p in params)
-    # KNOWN ISSUE: replaying the captured step of config E (opt-6.7b, 4 x 1024 tokens) ends in a GPU memory access fault on this
-    # software stack (ROCm 7.0.2 / torch 2.10), with the fused xattn kernels on or off; the same step runs eagerly (and configs A-D
-    # replay fine).  Not root-caused yet, so `auto` launches config E eagerly; `--graph on` still forces the capture.
+    # Config E (4 x 1024 tokens) is launched eagerly under `auto`: replaying a captured step faults inside PyTorch-ROCm's memory-efficient
+    # SDPA kernels once the sequence reaches 1024 tokens and the stock LM has dropout active (tools/debug_e_bisect3.sh / 4.sh: the same
+    # fault with gpt2-large, with one gated block, without the optimizer; no fault with the math SDPA backend, with LM dropout 0, at 512
+    # tokens, or when only this library's kernels are captured at the same shapes).  `--graph on` still forces the capture.
     use_graph = args.graph == "on" or (args.graph == "auto" and args.config != "E")
     if args.no_optimizer:
         opt = None

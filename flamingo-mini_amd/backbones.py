@@ -166,4 +166,6 @@ def load_language_model(config):
     kw.update(_tiny_override(config, "lm"))
     if os.environ.get("FLAMINGO_LM_ATTN"):              # debugging aid: "eager" / "sdpa" attention inside the stock LM
         kw["attn_implementation"] = os.environ["FLAMINGO_LM_ATTN"]
+    if os.environ.get("FLAMINGO_LM_DROPOUT"):
+        kw.update(dropout=float(os.environ["FLAMINGO_LM_DROPOUT"]), attention_dropout=float(os.environ["FLAMINGO_LM_DROPOUT"]))
     return OPTForCausalLM(OPTConfig(**kw))

@@ -96,6 +96,7 @@ struct RsLayerStash {
 struct RsScratch {
     void *dx0, *dxn, *dO, *dkv, *dln, *dxf, *ws;
     RsLayerStash L[kMaxDepth];
+    float* lnp[3 * kMaxDepth + 1];     // partials of the postponed LayerNorm-backward reductions (null: not deferrable at this width)
     size_t ws_bytes;
 };
 static size_t rs_ws_bytes(const RsDims& s) {
@@ -134,6 +135,10 @@ static size_t rs_scratch_layout(const RsDims& s, void* base, size_t cap, bool bw
             L.dK = a.take(rows_kv * s.inner * s.es);
             L.dV = a.take(rows_kv * s.inner * s.es);
         }
+        static const int defer_ln = [] { const char* e = getenv("FF_DEFER_LN"); return e ? atoi(e) : 1; }();
+        const bool lnd = defer_ln != 0 && layernorm_bwd_deferrable(s.dt, s.D);
+        for (int i = 0; i < 3 * s.depth + 1; i++)       // [3l] ff norm, [3l+1] norm_latents, [3l+2] norm_media of layer l; [3 depth] final norm
+            o.lnp[i] = lnd ? a.take<float>(layernorm_bwd_partial_bytes(i % 3 == 2 ? s.Bn * s.F : (int)rows_q, s.D)) : nullptr;
     }
     return align_up(a.used);
 }
@@ -232,9 +237,19 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
     const size_t gws = W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4);
 
     // ---- data-gradient chain (critical path); weight-gradient operands are left in W.L[l] ----
+    // The final reductions of the LayerNorm backwards (d gamma / d beta) are not on that chain either: their partials stay in W.lnp and
+    // one launch per kLnFinishMax of them finishes all 3 depth + 1 after the chain.
+    LnPending ln_sets[3 * kMaxDepth + 1];
+    auto ln_bwd = [&](int slot, const LnArgs& a, const void* dy_, const void* x_, const void* add_, const void* gamma_, const float* mean_,
+                      const float* rstd_, void* dx_, const void* dx_res_, void* dg_, void* db_) -> int {
+        if (W.lnp[slot])
+            return layernorm_bwd(a, dy_, x_, add_, gamma_, mean_, rstd_, dx_, dx_res_, dg_, db_, W.lnp[slot], layernorm_bwd_partial_bytes(a.rows, a.cols), st,
+                                 nullptr, &ln_sets[slot]);       // (leaves ln_sets[slot].partial null if it had to run the unfused path)
+        return layernorm_bwd(a, dy_, x_, add_, gamma_, mean_, rstd_, dx_, dx_res_, dg_, db_, W.ws, gws, st);
+    };
     // final norm (:187): d x at the output of the last layer
-    FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), dout, S.x_last, nullptr, P[2], S.mean_o, S.rstd_o, W.L[s.depth - 1].dx_out, nullptr,
-                         G[2], G[3], W.ws, gws, st));
+    FF_TRY(ln_bwd(3 * s.depth, ln_args(s.dt, Mq, s.D, pD, pD, pD), dout, S.x_last, nullptr, P[2], S.mean_o, S.rstd_o, W.L[s.depth - 1].dx_out, nullptr,
+                  G[2], G[3]));
     for (int l = s.depth - 1; l >= 0; l--) {
         const void* const* p = P + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
         void* const* g = G + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
@@ -247,8 +262,7 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
         // ---- FeedForward backward (x_next = x_mid + W3 act(W1 LN(x_mid))) ----
         FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(1, pF).c(pF).act_bwd(s.act).problem(T.dx_out, p[11], T.dH, nullptr, L.Hpre).run(W.ws, gws, st));
         FF_TRY(Gemm(s.dt, Mq, s.D, s.ffi).a(0, pF).b(1, pD).c(pD).problem(T.dH, p[10], W.dxn).run(W.ws, gws, st));
-        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), W.dxn, L.x_mid, nullptr, p[8], L.mean_f, L.rstd_f, T.dx_mid, T.dx_out, g[8], g[9],
-                             W.ws, gws, st));                                                  // T.dx_mid = d x_mid
+        FF_TRY(ln_bwd(3 * l, ln_args(s.dt, Mq, s.D, pD, pD, pD), W.dxn, L.x_mid, nullptr, p[8], L.mean_f, L.rstd_f, T.dx_mid, T.dx_out, g[8], g[9]));   // T.dx_mid = d x_mid
         // ---- attention backward (x_mid = x_in + Wo O) ----
         FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, pD).b(1, pI).c(pI).problem(T.dx_mid, p[7], W.dO).run(W.ws, gws, st));
         FF_TRY(attention_bwd(rs_attn_desc(s), L.Qs, L.K, L.V, nullptr, L.O, W.dO, L.lse, T.dQs, T.dK, T.dV, attn_ws,
@@ -260,14 +274,14 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
         FF_TRY(Gemm(s.dt, Mq, s.D, s.inner).a(0, pI).b(1, pD).c(pD).res_map(kv_lat).scale(s.scale)
                    .problem(T.dQs, p[4], W.dln, nullptr, nullptr, dkv_lat_base).run(W.ws, gws, st));
         // norm_latents backward, accumulated onto the residual path: d x_in
-        FF_TRY(layernorm_bwd(ln_args(s.dt, Mq, s.D, x_map, pD, pD), W.dln, x_in, nullptr, p[2], L.mean_l, L.rstd_l, dx_below, T.dx_mid, g[2], g[3],
-                             W.ws, gws, st));
+        FF_TRY(ln_bwd(3 * l + 1, ln_args(s.dt, Mq, s.D, x_map, pD, pD), W.dln, x_in, nullptr, p[2], L.mean_l, L.rstd_l, dx_below, T.dx_mid, g[2], g[3]));
         {   // norm_media backward: d x_f accumulates over the layers (needed for d time_pos_emb even with CLIP frozen)
             LnArgs a = ln_args(s.dt, Mf, s.D, pD, kv_media, pD);
             a.add_rows_per_seg = s.F; a.add_div = s.v;
-            FF_TRY(layernorm_bwd(a, W.dkv, x_f, tpe, p[0], S.mean_m, S.rstd_m, dxf, l == s.depth - 1 ? nullptr : dxf, g[0], g[1], W.ws, gws, st));
+            FF_TRY(ln_bwd(3 * l + 2, a, W.dkv, x_f, tpe, p[0], S.mean_m, S.rstd_m, dxf, l == s.depth - 1 ? nullptr : dxf, g[0], g[1]));
         }
     }
+    FF_TRY(layernorm_bwd_finish(s.dt, ln_sets, 3 * s.depth + 1, st));
     // ---- weight gradients, grouped over up to kGemmMaxZ layers per launch ----
     for (int l0 = 0; l0 < s.depth; l0 += kGemmMaxZ) {
         const int l1 = std::min(s.depth, l0 + kGemmMaxZ);
@@ -362,13 +376,24 @@ struct XaScratch {
 // deferred (ff_xattn_block_bwd_kv_data -> ff_xattn_wgrad_grouped), in `scratch` otherwise.
 struct XaStash {
     void *dy1, *dH, *dQs;
+    float *lnp_f = nullptr, *lnp_a = nullptr;   // per-workgroup partials of the two LayerNorm backwards (their final reduction is postponed too)
 };
+// The ~5 us final reductions of the two LayerNorm backwards (d gamma, d beta, both gate gradients) are off the data-gradient chain as
+// well: in the deferred mode their partials stay in the stash and ff_xattn_wgrad_grouped finishes up to 8 of them with one launch.
+static bool xa_ln_deferrable(const XaDims& s) {      // FF_DEFER_LN=0: finish every LayerNorm backward on the spot (A/B timing)
+    static const int on = [] { const char* e = getenv("FF_DEFER_LN"); return e ? atoi(e) : 1; }();
+    return on != 0 && layernorm_bwd_deferrable(s.dt, s.d);
+}
 static size_t xa_stash_layout(const XaDims& s, void* base, size_t cap, XaStash& o) {
     Arena a(base, cap);
     const size_t M = (size_t)s.b * s.L;
     o.dy1 = a.take(M * s.d * s.es);
     o.dH = a.take(M * s.ffi * s.es);
     o.dQs = a.take(M * s.inner * s.es);
+    if (xa_ln_deferrable(s)) {
+        o.lnp_f = a.take<float>(layernorm_bwd_partial_bytes((int)M, s.d));
+        o.lnp_a = a.take<float>(layernorm_bwd_partial_bytes((int)M, s.d));
+    }
     return align_up(a.used);
 }
 static size_t xa_ws_bytes(const XaDims& s) {
@@ -495,6 +520,11 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     XaStash T{W.dy1, W.dH, W.dQs};
     const bool defer = stash != nullptr;
     if (defer) FF_CHECK(xa_stash_layout(s, stash, stash_bytes, T) <= stash_bytes, FF_ERR_WORKSPACE, "xattn_bwd: stash too small");
+    const bool defer_ln = defer && xa_ln_deferrable(s);
+    if (defer_ln)   // xattn_wgrad_grouped cannot know what happened here, so the one-pass LayerNorm backward must apply: rows 16-byte aligned
+        FF_CHECK(((uintptr_t)y | (uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)P[2] | (uintptr_t)P[7]) % 16 == 0, FF_ERR_SHAPE,
+                 "xattn_bwd (deferred weight gradients): y, d y_out, d y and the LayerNorm weights must be 16-byte aligned");
+    LnPending pend_f, pend_a;
     const int M = s.b * s.L, Mk = s.b * s.Nk;
     const RowMap pd = plain_rows(s.d), pI = plain_rows(s.inner), pF = plain_rows(s.ffi), pV = plain_rows(s.dv), pKV = plain_rows(2 * s.inner);
     const size_t attn_ws_bytes = align_up((size_t)s.b * s.H * s.L * 4);
@@ -510,7 +540,11 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
         LnDots dots;
         dots.a = S.ffw_out; dots.alpha_a = P[1]; dots.out_a = G[1];
         dots.b = S.attn_out; dots.alpha_b = P[0]; dots.out_b = G[0];
-        FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, T.dy1, dy2, G[7], G[8], W.ws, gws, st, &dots));
+        if (defer_ln) {
+            FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, T.dy1, dy2, G[7], G[8], T.lnp_f,
+                                 layernorm_bwd_partial_bytes(M, s.d), st, &dots, &pend_f));
+            FF_CHECK(pend_f.partial, FF_ERR_SHAPE, "xattn_bwd: the one-pass LayerNorm backward did not apply in the deferred mode");
+        } else FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, T.dy1, dy2, G[7], G[8], W.ws, gws, st, &dots));
     }
     // ---- y1 = y + tanh(alpha_attn) * to_out(attention) ----
     if (!defer) FF_TRY(Gemm(s.dt, s.d, s.inner, M).a(1, pd).b(1, pI).c(pI).problem(T.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
@@ -534,6 +568,12 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
         if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(W.ws, gws, st));
     }
     FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(T.dQs, P[4], W.dyn).run(W.ws, gws, st));
+    if (defer_ln) {
+        FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, T.dy1, G[2], G[3], T.lnp_a,
+                             layernorm_bwd_partial_bytes(M, s.d), st, nullptr, &pend_a));
+        FF_CHECK(pend_a.partial, FF_ERR_SHAPE, "xattn_bwd: the one-pass LayerNorm backward did not apply in the deferred mode");
+        return FF_OK;
+    }
     return layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, T.dy1, G[2], G[3], W.ws, gws, st);
 }
 
@@ -556,6 +596,9 @@ static int xattn_wgrad_grouped(const ff_xattn_desc* d, int n, const void* const*
     FF_CHECK(ws_bytes >= xa_wgrad_ws_bytes(s) && (ws || !xa_wgrad_ws_bytes(s)), FF_ERR_WORKSPACE, "xattn_wgrad_grouped: workspace too small");
     const int M = s.b * s.L;
     const RowMap pd = plain_rows(s.d), pI = plain_rows(s.inner), pF = plain_rows(s.ffi);
+    LnPending ln_sets[2 * kGemmMaxZ];
+    const bool finish_ln = xa_ln_deferrable(s);
+    const int ln_blocks = layernorm_bwd_partial_blocks(M);
     Gemm g3(s.dt, s.d, s.ffi, M), g1(s.dt, s.ffi, s.d, M), go(s.dt, s.d, s.inner, M), gq(s.dt, s.inner, s.d, M);
     g3.a(1, pd).b(1, pF).c(pF);                     // d ffw.3 = tanh(alpha_ffw) * d y2^T . act(H)
     g1.a(1, pF).b(1, pd).c(pd);                     // d ffw.1 = d H^T . LN(y1)
@@ -574,7 +617,16 @@ static int xattn_wgrad_grouped(const ff_xattn_desc* d, int n, const void* const*
         g1.problem(T.dH, S.xn_f, G[9]);
         go.problem(T.dy1, S.O, G[6], nullptr, nullptr, nullptr, P[0]);
         gq.problem(T.dQs, S.yn, G[4]);
+        if (finish_ln) {    // what xattn_bwd left open: LN(y1) backward with both gate gradients, LN(y) backward
+            FF_CHECK(G[0] && G[1] && G[2] && G[3] && G[7] && G[8], FF_ERR_SHAPE, "xattn_wgrad_grouped: null LayerNorm / gate gradient of block %d", i);
+            LnPending& f = ln_sets[2 * i];
+            f.partial = T.lnp_f; f.nblk = ln_blocks; f.cols = s.d; f.dgamma = G[7]; f.dbeta = G[8];
+            f.alpha_a = P[1]; f.out_a = G[1]; f.alpha_b = P[0]; f.out_b = G[0];
+            LnPending& q = ln_sets[2 * i + 1];
+            q.partial = T.lnp_a; q.nblk = ln_blocks; q.cols = s.d; q.dgamma = G[2]; q.dbeta = G[3];
+        }
     }
+    if (finish_ln) FF_TRY(layernorm_bwd_finish(s.dt, ln_sets, 2 * n, st));
     FF_TRY(g3.run(ws, ws_bytes, st));
     FF_TRY(g1.run(ws, ws_bytes, st));
     FF_TRY(go.run(ws, ws_bytes, st));

@@ -86,9 +86,25 @@ struct LnDots {
     const void* a = nullptr; const void* alpha_a = nullptr; void* out_a = nullptr;
     const void* b = nullptr; const void* alpha_b = nullptr; void* out_b = nullptr;
 };
+// A LayerNorm backward whose cross-workgroup reduction (d gamma, d beta, the gate gradients) is postponed: the ~5 us `final` launch
+// is not on the data-gradient chain, so callers collect these and finish up to kLnFinishMax of them with ONE launch
+// (layernorm_bwd_finish).  `partial` is the caller's buffer (layernorm_bwd_partial_bytes) and must stay alive until then.
+struct LnPending {
+    const float* partial = nullptr;     // null: nothing was postponed (the one-pass kernel did not apply; everything ran immediately)
+    int nblk = 0, cols = 0;
+    void *dgamma = nullptr, *dbeta = nullptr;
+    const void* alpha_a = nullptr; void* out_a = nullptr;
+    const void* alpha_b = nullptr; void* out_b = nullptr;
+};
+constexpr int kLnFinishMax = 8;
+bool layernorm_bwd_deferrable(int dtype, int cols);          // shape part of the condition (pointers must also be 16-byte aligned)
+size_t layernorm_bwd_partial_bytes(int rows, int cols);
+int layernorm_bwd_partial_blocks(int rows);
+// pending != null: `ws` receives the partials (>= layernorm_bwd_partial_bytes) and the final reduction is left to layernorm_bwd_finish
 int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* add, const void* gamma, const float* mean,
                   const float* rstd, void* dx, const void* dx_residual, void* dgamma, void* dbeta, void* ws,
-                  size_t ws_bytes, hipStream_t st, const LnDots* dots = nullptr);
+                  size_t ws_bytes, hipStream_t st, const LnDots* dots = nullptr, LnPending* pending = nullptr);
+int layernorm_bwd_finish(int dtype, const LnPending* sets, int n, hipStream_t st);
 size_t rows_reduce_workspace(int rows, int cols, int rows_per_batch, int rows_per_group);
 int rows_reduce(int dtype, int rows, int cols, RowMap x_map, int rows_per_batch, int rows_per_group, const void* x,
                 void* out, void* ws, size_t ws_bytes, hipStream_t st);

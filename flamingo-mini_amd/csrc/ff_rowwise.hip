@@ -317,9 +317,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
 // out[idx] = sum over blocks of partial[block][idx]; 16 outputs x 16 block-lanes per workgroup, 8 loads in flight per thread
 // (the first version - 64 x 4, 4 in flight - spent 7 us on 16 dependent round trips to read 2.6 MB)
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_final_kernel(int nblk, int cols, const float* __restrict__ partial, T* dgamma, T* dbeta,
-                                                           const T* alpha_a, T* out_a, const T* alpha_b, T* out_b) {
-    pin_args(nblk, cols, partial, dgamma, dbeta, alpha_a, out_a, alpha_b, out_b);
+FF_DEV void ln_final_body(int nblk, int cols, const float* __restrict__ partial, T* dgamma, T* dbeta, const T* alpha_a, T* out_a, const T* alpha_b,
+                          T* out_b) {
     __shared__ float red[16][17];
     const int P = 2 * cols + 2;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -346,6 +345,22 @@ __global__ __launch_bounds__(256) void ln_bwd_final_kernel(int nblk, int cols, c
             if (out_a) { const float t = tanhf(to_f32(alpha_a[0])); out_a[0] = from_f32<T>(v * (1.f - t * t)); }
         } else if (out_b) { const float t = tanhf(to_f32(alpha_b[0])); out_b[0] = from_f32<T>(v * (1.f - t * t)); }
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_final_kernel(int nblk, int cols, const float* __restrict__ partial, T* dgamma, T* dbeta,
+                                                           const T* alpha_a, T* out_a, const T* alpha_b, T* out_b) {
+    pin_args(nblk, cols, partial, dgamma, dbeta, alpha_a, out_a, alpha_b, out_b);
+    ln_final_body<T>(nblk, cols, partial, dgamma, dbeta, alpha_a, out_a, alpha_b, out_b);
+}
+// the same reduction for up to kLnFinishMax postponed LayerNorm backwards in one launch: blockIdx.y = which one
+struct LnFinishTable {
+    LnPending s[kLnFinishMax];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_final_multi_kernel(const LnFinishTable t) {
+    const LnPending& e = t.s[blockIdx.y];
+    if ((int)blockIdx.x * 16 >= 2 * e.cols + 2) return;      // (the grid is sized for the widest set)
+    ln_final_body<T>(e.nblk, e.cols, e.partial, (T*)e.dgamma, (T*)e.dbeta, (const T*)e.alpha_a, (T*)e.out_a, (const T*)e.alpha_b, (T*)e.out_b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,10 +580,17 @@ size_t layernorm_bwd_workspace(int rows, int cols) {
     return std::max(fused, col_reduce_ws(rows, cols, 1, 2));
 }
 
+bool layernorm_bwd_deferrable(int dtype, int cols) { return cols % (dtype == FF_DTYPE_BF16 ? 8 : 4) == 0 && ln_fused_ok(dtype, cols, true); }
+int layernorm_bwd_partial_blocks(int rows) {
+    int rpb;
+    return ln_fused_blocks(rows, rpb);
+}
+size_t layernorm_bwd_partial_bytes(int rows, int cols) { return (size_t)layernorm_bwd_partial_blocks(rows) * (2 * (size_t)cols + 2) * sizeof(float); }
+
 template <typename T, int VEC>
 static int launch_ln_fused(const LnArgs& a, const void* dy, const void* x, const void* add, const void* gamma, const float* mean,
                            const float* rstd, void* dx, const void* dx_res, const LnDots& dots, void* dgamma, void* dbeta, float* partial,
-                           hipStream_t st_) {
+                           hipStream_t st_, LnPending* pending) {
     int rpb;
     const int nblk = ln_fused_blocks(a.rows, rpb);
     const int nch = cdiv(a.cols / VEC, 64);
@@ -593,6 +615,11 @@ static int launch_ln_fused(const LnArgs& a, const void* dy, const void* x, const
     else FF_LN_LAUNCH(8);
 #undef FF_LN_LAUNCH
     FF_TRY(check_launch("ln_bwd_fused"));
+    if (pending) {      // the cross-workgroup reduction is left to layernorm_bwd_finish
+        pending->partial = partial; pending->nblk = nblk; pending->cols = a.cols; pending->dgamma = dgamma; pending->dbeta = dbeta;
+        pending->alpha_a = dots.alpha_a; pending->out_a = dots.out_a; pending->alpha_b = dots.alpha_b; pending->out_b = dots.out_b;
+        return FF_OK;
+    }
     const int P = 2 * a.cols + 2;
     ln_bwd_final_kernel<T><<<dim3(cdiv(P, 16)), dim3(256), 0, st_>>>(nblk, a.cols, partial, (T*)dgamma, (T*)dbeta, (const T*)dots.alpha_a,
                                                                      (T*)dots.out_a, (const T*)dots.alpha_b, (T*)dots.out_b);
@@ -601,8 +628,9 @@ static int launch_ln_fused(const LnArgs& a, const void* dy, const void* x, const
 
 int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* add, const void* gamma, const float* mean,
                   const float* rstd, void* dx, const void* dx_residual, void* dgamma, void* dbeta, void* ws, size_t ws_bytes,
-                  hipStream_t st_, const LnDots* dots_in) {
+                  hipStream_t st_, const LnDots* dots_in, LnPending* pending) {
     FF_CHECK(a.rows > 0 && a.cols > 0 && dy && x && gamma && mean && rstd, FF_ERR_SHAPE, "layernorm_bwd: null/shape");
+    if (pending) *pending = LnPending{};
     FF_CHECK(!add || (a.add_rows_per_seg > 0 && a.add_div > 0), FF_ERR_SHAPE, "layernorm_bwd: addend needs add_rows_per_seg/add_div");
     const LnDots dots = dots_in ? *dots_in : LnDots{};
     FF_CHECK(!dots.a || dx_residual, FF_ERR_SHAPE, "layernorm_bwd: dot_a is taken against dx_residual");
@@ -613,8 +641,8 @@ int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* ad
         int rpb;
         const size_t need = (size_t)ln_fused_blocks(a.rows, rpb) * (2 * (size_t)a.cols + 2) * sizeof(float);
         FF_CHECK(ws && ws_bytes >= need, FF_ERR_WORKSPACE, "layernorm_bwd workspace: need %zu have %zu", need, ws_bytes);
-        if (a.dtype == FF_DTYPE_BF16) return launch_ln_fused<bf16, 8>(a, dy, x, add, gamma, mean, rstd, dx, dx_residual, dots, dgamma, dbeta, (float*)ws, st_);
-        return launch_ln_fused<float, 4>(a, dy, x, add, gamma, mean, rstd, dx, dx_residual, dots, dgamma, dbeta, (float*)ws, st_);
+        if (a.dtype == FF_DTYPE_BF16) return launch_ln_fused<bf16, 8>(a, dy, x, add, gamma, mean, rstd, dx, dx_residual, dots, dgamma, dbeta, (float*)ws, st_, pending);
+        return launch_ln_fused<float, 4>(a, dy, x, add, gamma, mean, rstd, dx, dx_residual, dots, dgamma, dbeta, (float*)ws, st_, pending);
     }
     if (dots.a) FF_TRY(gate_grad(a.dtype, a.rows, a.cols, dx_residual, dots.a, dots.alpha_a, dots.out_a, ws, ws_bytes, st_));   // unfused fallback (plain maps)
     if (dx) {
@@ -643,6 +671,24 @@ int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* ad
         FF_TRY(check_launch("ln_bwd_param_final"));
     }
     if (dots.b) FF_TRY(gate_grad(a.dtype, a.rows, a.cols, dx, dots.b, dots.alpha_b, dots.out_b, ws, ws_bytes, st_));
+    return FF_OK;
+}
+
+int layernorm_bwd_finish(int dtype, const LnPending* sets, int n, hipStream_t st_) {
+    for (int i0 = 0; i0 < n; i0 += kLnFinishMax) {
+        LnFinishTable t = {};
+        int cnt = 0, pmax = 0;
+        for (int i = i0; i < n && i < i0 + kLnFinishMax; i++)
+            if (sets[i].partial) {
+                t.s[cnt++] = sets[i];
+                pmax = std::max(pmax, 2 * sets[i].cols + 2);
+            }
+        if (!cnt) continue;
+        const dim3 grid(cdiv(pmax, 16), cnt);
+        if (dtype == FF_DTYPE_BF16) ln_bwd_final_multi_kernel<bf16><<<grid, dim3(256), 0, st_>>>(t);
+        else ln_bwd_final_multi_kernel<float><<<grid, dim3(256), 0, st_>>>(t);
+        FF_TRY(check_launch("ln_bwd_final_multi"));
+    }
     return FF_OK;
 }
 

@@ -346,8 +346,10 @@ class _XattnBlockKvFn(torch.autograd.Function):
         grads = own_grads[:_KV_PARAM] + [None] + own_grads[_KV_PARAM:]
         dy, dkv = torch.empty_like(y), torch.empty_like(kv)
         scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
-        if _wgrad_queue.enabled and all(p.grad is None for p in own):
-            # data gradients now; d ffw.3 / d ffw.1 / d to_out / d to_q later, grouped with the neighbouring layers' (see _WgradQueue)
+        aligned = all(t.data_ptr() % 16 == 0 for t in (y, dout, params[2], params[7]))     # the deferred entry point requires it
+        if _wgrad_queue.enabled and aligned and all(p.grad is None for p in own):
+            # data gradients now; d ffw.3 / d ffw.1 / d to_out / d to_q (and the final reductions of the LayerNorm / gate gradients)
+            # later, grouped with the neighbouring layers' (see _WgradQueue)
             stash = _empty_bytes(lib.ff_xattn_wgrad_stash_bytes(desc), dev)
             ffi.check(lib.ff_xattn_block_bwd_kv_data(desc, y.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * kv.element_size(), tt.data_ptr(),
                                                      ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(), ffi.ptr_array(grads),
@@ -355,7 +357,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
                                                      scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_bwd_kv_data")
             key = (dev, y.dtype, tuple(y.shape), kv.shape[1], ctx.n_visual, tuple(ctx.cfg), params[_KV_PARAM].shape[1])
             offs, _ = _flat_offsets(own)
-            deferred = (4, 6, 9, 10)                       # attn.to_q, attn.to_out, ffw.1, ffw.3 in the block's parameter order
+            deferred = tuple(i for i in range(len(params)) if i != _KV_PARAM)      # every gradient of the block is completed by the flush
             own_index = {i: (i if i < _KV_PARAM else i - 1) for i in deferred}
             _wgrad_queue.push(dict(key=key, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, flat=flat, own=own,
                                    grad_ptrs=[None if g is None else g.data_ptr() for g in grads],

@@ -262,9 +262,13 @@ int ff_xattn_block_bwd_kv(const ff_xattn_desc* d, const void* y, const void* k, 
  * d attn.to_out.weight, d attn.to_q.weight = 1/3 of its FLOPs) are not on the critical path of backward and a single one
  * fills a third of the chip.  ff_xattn_block_bwd_kv_data is ff_xattn_block_bwd_kv without them: it leaves their operands
  * (d y1, d H, d Qs) in the caller-owned `stash`; ff_xattn_wgrad_grouped then computes them for up to FF_WGRAD_GROUP_MAX
- * same-shaped blocks per call in four grouped launches.  grads[5] (to_kv) is never written; the LayerNorm / gate gradients
- * (grads[0..3], [7], [8]) are written by the data pass.  `params` / `grads` of the grouped call: n_blocks * FF_XATTN_PARAMS
- * pointers, block after block; dy_out / saved / stash: one pointer per block (the buffers of that block's data pass).
+ * same-shaped blocks per call in four grouped launches.  grads[5] (to_kv) is never written.  The LayerNorm / gate gradients
+ * (grads[0..3], [7], [8]) are COMPLETE only after the grouped call as well: the data pass runs the one-pass LayerNorm backward and
+ * leaves its per-workgroup partial sums in the stash; the grouped call reduces those of all its blocks with one launch (72 -> 9
+ * launches per step, none of them on the data-gradient chain, at flamingo-mini's size).  For that the data pass requires y, dy_out, dy and the two
+ * LayerNorm weight vectors to be 16-byte aligned (FF_ERR_SHAPE otherwise; use ff_xattn_block_bwd_kv for odd views).
+ * `params` / `grads` of the grouped call: n_blocks * FF_XATTN_PARAMS pointers, block after block, the SAME gradient pointers the
+ * data pass received; dy_out / saved / stash: one pointer per block (the buffers of that block's data pass).
  * ------------------------------------------------------------------------------------------------------ */
 #define FF_WGRAD_GROUP_MAX 4
 size_t ff_xattn_wgrad_stash_bytes(const ff_xattn_desc* d);

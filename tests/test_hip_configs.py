@@ -30,7 +30,7 @@ def _check_block(dtype, dim, dv, b, L, N, ml, act="gelu", tag="cfg"):
     outr, _, cache = O.gated_xattn_block_fwd(as64(yd), as64(vfd), ml, p64, act=act)
     dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd), cache, p64, act=act)
     t = TOL[dtype]
-    assert rel(out - yd, outr - as64(yd)) < t["out"] * 2
+    assert rel(out - yd, outr - as64(yd)) < t["out"]
     assert rel(yd.grad, dyr) < t["grad"] and rel(vfd.grad, dvfr) < t["grad"]
     for k in ("attn.to_q.weight", "attn.to_kv.weight", "attn.to_out.weight", "ffw.1.weight", "ffw.3.weight", "attn.norm.weight", "ffw.0.bias"):
         assert rel(dict(m.named_parameters())[k].grad, gr[k]) < t["grad"], k
@@ -64,11 +64,10 @@ def test_config_D_video_resampler(dtype):
     yr, cache = O.resampler_fwd(as64(xd), p64)
     dxr, gr = O.resampler_bwd(as64(dyd), cache, p64)
     t = TOL[dtype]
-    f = 3 if dtype == torch.bfloat16 else 1          # six stacked bf16 layers: the reference's own bf16 error grows the same way
-    assert rel(y, yr) < t["out"] * f
-    assert rel(xd.grad, dxr) < t["grad"] * f
+    assert rel(y, yr) < t["out"]                      # (measured in bf16: 6.7e-3 on the output, 9.7e-3 on d x - six stacked layers)
+    assert rel(xd.grad, dxr) < t["grad"]
     for k in ("time_pos_emb", "latents", "layers.0.0.to_k.weight", "layers.5.1.3.weight", "layers.2.0.norm_media.weight", "norm.bias"):
-        assert rel(dict(m.named_parameters())[k].grad, gr[k]) < t["grad"] * f, k
+        assert rel(dict(m.named_parameters())[k].grad, gr[k]) < t["grad"], k
     with pytest.raises(RuntimeError):                 # 5 frames > num_time_embeds (broadcast error in the reference, :166)
         m(dev(det((1, 5, 10, dim), "D-x5"), dtype))
 
@@ -123,17 +122,17 @@ def test_config_B_full_size_properties():
             out.backward(g, retain_graph=True)
             grads.append([xd.grad.clone(), yd.grad.clone(), rs.layers[3][0].to_k.weight.grad.clone(), rs.time_pos_emb.grad.clone(),
                           blk.ffw[1].weight.grad.clone(), blk.alpha_attn.grad.clone()])
-        lin_tol = 1e-5 if dtype == torch.float32 else 2e-2
+        lin_tol = 1e-5 if dtype == torch.float32 else 1.2e-2      # measured 3.4e-6 / 7e-3
         for a, c, comb in zip(*grads):                                            # backward is linear in the incoming gradient
             assert rel(comb, 0.5 * a.float() - 2.0 * c.float()) < lin_tol
         with torch.no_grad():                                                     # samples do not interact
             vf1 = rs(xd[5:6])
             out1, _ = blk(yd[5:6], vf1.reshape(1, 1, 64, dv), ml[5:6])
         ind_tol = 1e-5 if dtype == torch.float32 else 1e-2        # not bitwise: batch 1 picks another tile / split-K plan
-        assert rel(vf1, vf[5:6]) < ind_tol and rel(out1 - yd[5:6], out[5:6] - yd[5:6]) < ind_tol * 2
+        assert rel(vf1, vf[5:6]) < ind_tol and rel(out1 - yd[5:6], out[5:6] - yd[5:6]) < ind_tol      # measured 6.1e-3 / 4.9e-3 in bf16
         outs[dtype] = (vf.detach().float(), (out - yd).detach().float(), grads[0][4].float())
     f32, b16 = outs[torch.float32], outs[torch.bfloat16]
-    assert rel(b16[0], f32[0]) < 3e-2 and rel(b16[1], f32[1]) < 3e-2 and rel(b16[2], f32[2]) < 6e-2
+    assert rel(b16[0], f32[0]) < 1.2e-2 and rel(b16[1], f32[1]) < 1.2e-2 and rel(b16[2], f32[2]) < 1.2e-2      # measured 7.8e-3, 6.9e-3, 6.8e-3
 
 
 def test_repeated_calls_are_bitwise_deterministic():

@@ -128,7 +128,7 @@ def test_xattn_block_vs_oracle_gpt2_large_shape(dtype, act):
     outr, _, cache = O.gated_xattn_block_fwd(as64(yd), as64(vfd), ml, p64, act=act)
     dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd), cache, p64, act=act)
     t = TOL[dtype]
-    assert rel(out - yd, outr - as64(yd)) < t["out"] * 2      # error on the block's delta, not hidden by the residual
+    assert rel(out - yd, outr - as64(yd)) < t["out"]          # error on the block's delta, not hidden by the residual
     assert rel(yd.grad, dyr) < t["grad"]
     assert rel(vfd.grad, dvfr) < t["grad"]
     for k, prm in m.named_parameters():

@@ -139,14 +139,14 @@ def test_full_model_fp32_on_hip_matches_reference(hoist_kv, family):
 @pytest.mark.gpu
 def test_full_gpt2_model_bf16_on_hip():
     """The benchmark dtype through the GPT-2 wrapper (the LM family of BASELINE configs A and B).  Everything - stock CLIP / GPT-2
-    included - runs in bf16 here, so the tolerance is the bf16 one: 3e-2 relative L2 on logits (the reference's own bf16-vs-fp32
-    drift is 0.3-0.7e-2 per module), 8e-2 on gradients, 3x that on the scalar gates."""
+    included - runs in bf16 here, so the tolerance is a bf16 one: 1.5e-2 relative L2 on logits (measured 8.9e-3; the reference's own
+    bf16-vs-fp32 drift is 0.3-0.7e-2 per module), 2.5e-2 on gradients (measured worst 1.5e-2), 25 % on the scalar gates."""
     model, z = build(torch.bfloat16, "cuda", "gpt2")
     px = torch.from_numpy(z["px"]).to(device="cuda", dtype=torch.bfloat16)
     ids, ml = torch.from_numpy(z["ids"]).cuda(), torch.from_numpy(z["ml"]).cuda()
     model.train()
     out = model(input_ids=ids, attention_mask=torch.ones_like(ids), media_locations=ml, pixel_values=px, labels=ids)
-    assert rel(out.logits, z["logits"]) < 3e-2
+    assert rel(out.logits, z["logits"]) < 1.5e-2          # measured 8.9e-3 (tiny GPT-2 + CLIP stacks in bf16 on stock PyTorch, plus the fusion path)
     assert abs(float(out.loss) - float(z["loss"])) < 3e-2
     out.loss.backward()
     named = dict(model.named_parameters())
@@ -157,7 +157,7 @@ def test_full_gpt2_model_bf16_on_hip():
             assert abs(float(named[k].grad) - float(ref)) < 0.25 * max(abs(float(ref)), 0.05), (k, float(named[k].grad), float(ref))
         else:
             worst[k] = rel(named[k].grad, ref)
-    bad = {k: v for k, v in worst.items() if not v < 8e-2}
+    bad = {k: v for k, v in worst.items() if not v < 2.5e-2}      # measured worst 1.5e-2
     assert not bad, bad
 
 

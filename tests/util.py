@@ -6,18 +6,25 @@ import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# Tolerances (relative L2 error against the fp64 oracle / reference vectors):
-#   fp32 path: MFMA fp32 FMA chains + __expf  -> 2e-5 (the 1e-3 logits target of BASELINE.json is far looser)
-#   bf16 path: inputs/activations rounded to bf16 at every kernel boundary; the reference's own bf16-vs-fp32 deviation is
-#              6.6e-3 (resampler) / 2.9e-3 (xattn block) -> 2e-2 on outputs, 4e-2 on gradients
-TOL = {torch.float32: dict(out=2e-5, grad=5e-5), torch.bfloat16: dict(out=2e-2, grad=4e-2)}
+# Tolerances (relative L2 error against the fp64 oracle / reference vectors), set from MEASURED errors (tools/tol_report.py over a
+# `FF_TOL_REPORT=... pytest -m gpu` run on an MI355X, round 2) with a 1.3-2x margin - the kernels are bitwise deterministic, so the
+# margin only has to absorb a different tile / split-K plan:
+#   fp32 path (MFMA fp32 FMA chains + __expf): measured <= 2.7e-6 everywhere (BASELINE.json's logits target is 1e-3)  -> 5e-6 / 1e-5
+#   bf16 path (inputs / activations rounded to bf16 at every kernel boundary): primitives <= 2.7e-3, modules at real geometry
+#              <= 6.7e-3 on outputs (six stacked resampler layers, config D) and <= 9.7e-3 on gradients                -> 8e-3 / 1.2e-2
+#              The reference's own bf16-vs-fp32 deviation is 6.6e-3 (resampler) / 2.9e-3 (xattn block).
+TOL = {torch.float32: dict(out=5e-6, grad=1e-5), torch.bfloat16: dict(out=8e-3, grad=1.2e-2)}
 
 
 def rel(a, b) -> float:
     a = np.asarray(a.detach().double().cpu().numpy() if torch.is_tensor(a) else a, np.float64)
     b = np.asarray(b.detach().double().cpu().numpy() if torch.is_tensor(b) else b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    r = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    if os.environ.get("FF_TOL_REPORT"):      # tools/tol_report.py: the measured errors the tolerances above are set from
+        with open(os.environ["FF_TOL_REPORT"], "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{r:.3e}\n")
+    return r
 
 
 def dev(a, dtype=torch.float32):

@@ -57,6 +57,15 @@ template <> struct Vec<float> {
         f32x4 v = {o[0], o[1], o[2], o[3]};
         *(f32x4*)p = v;
     }
+    // streaming variants (data touched once per step: keep it out of the way of what the next kernels want cached)
+    static FF_DEV void load_nt(const float* p, float (&o)[4]) {
+        f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+    static FF_DEV void store_nt(float* p, const float (&o)[4]) {
+        f32x4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(v, (f32x4*)p);
+    }
 };
 template <> struct Vec<bf16> {
     static constexpr int N = 8;
@@ -71,6 +80,17 @@ template <> struct Vec<bf16> {
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = (bf16)o[i];
         *(bf16x8*)p = v;
+    }
+    static FF_DEV void load_nt(const bf16* p, float (&o)[8]) {
+        bf16x8 v = __builtin_nontemporal_load((const bf16x8*)p);
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = (float)v[i];
+    }
+    static FF_DEV void store_nt(bf16* p, const float (&o)[8]) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (bf16)o[i];
+        __builtin_nontemporal_store(v, (bf16x8*)p);
     }
 };
 

@@ -4,6 +4,7 @@
 //     p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // Reference training recipe: `--optim adamw_torch`, lr 1e-4 (training/train.sh:10-13).  HBM-bound: 7 streams per element.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include "ff_common.h"
 #include "ff_internal.h"
@@ -30,7 +31,9 @@ struct AdamTable {
 // T: storage type of the parameters' compute copy and of the gradients; ST: storage type of the two moments; MASTER: the update
 // is applied to an fp32 master copy (t.w) and the compute copy is its rounding - what `--fp16` / bf16 autocast training keeps
 // (training/train.sh:24), so that steps far below bf16 resolution of a weight (lr 1e-4) are not lost.
-template <typename T, typename ST, bool MASTER, int VEC>
+// MODE 1 (default for the bf16-state kernel; FF_ADAMW_MODE=0 for A/B): gradients and moments, touched once per step, are streamed with
+// nontemporal accesses so that they do not evict what the next kernels read (37.52 -> 37.40 ms/step at config B in a same-box A/B)
+template <typename T, typename ST, bool MASTER, int VEC, int MODE = 0>
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
     int ti = 0;
 #pragma unroll 1
@@ -52,18 +55,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
     const float step_size = lr / bc1, keep = 1.f - lr * t.decay;
     bool vec = VEC > 1 && n % VEC == 0 && ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0;
     if (MASTER) vec = vec && (uintptr_t)w % 16 == 0;
-    auto ldv = [&](auto* q, long long i, float (&o)[VEC]) {      // VEC consecutive elements of any storage type as floats
+    auto ldv = [&](auto* q, long long i, float (&o)[VEC], auto stream) {      // VEC consecutive elements of any storage type as floats
         typedef std::remove_cv_t<std::remove_pointer_t<decltype(q)>> Q;
         constexpr int QN = Vec<Q>::N;
 #pragma unroll
         for (int c = 0; c < VEC / QN; c++) {
             float part[QN];
-            Vec<Q>::load(q + i + c * QN, part);
+            if constexpr (decltype(stream)::value && MODE >= 1) Vec<Q>::load_nt(q + i + c * QN, part);
+            else Vec<Q>::load(q + i + c * QN, part);
 #pragma unroll
             for (int e = 0; e < QN; e++) o[c * QN + e] = part[e];
         }
     };
-    auto stv = [&](auto* q, long long i, const float (&o)[VEC]) {
+    auto stv = [&](auto* q, long long i, const float (&o)[VEC], auto stream) {
         typedef std::remove_pointer_t<decltype(q)> Q;
         constexpr int QN = Vec<Q>::N;
 #pragma unroll
@@ -71,14 +75,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
             float part[QN];
 #pragma unroll
             for (int e = 0; e < QN; e++) part[e] = o[c * QN + e];
-            Vec<Q>::store(q + i + c * QN, part);
+            if constexpr (decltype(stream)::value && MODE >= 1) Vec<Q>::store_nt(q + i + c * QN, part);
+            else Vec<Q>::store(q + i + c * QN, part);
         }
     };
     for (long long i = base + (long long)threadIdx.x * VEC; i < min(n, base + kAdamChunk); i += 256 * VEC) {
         float pf[VEC], gf[VEC], mf[VEC], vf[VEC];
         if (vec) {
-            if (MASTER) ldv(w, i, pf); else ldv(p, i, pf);
-            ldv(g, i, gf); ldv(m, i, mf); ldv(v, i, vf);
+            constexpr std::true_type S{};
+            constexpr std::false_type K{};
+            if (MASTER) ldv(w, i, pf, S); else ldv(p, i, pf, K);
+            ldv(g, i, gf, S); ldv(m, i, mf, S); ldv(v, i, vf, S);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; e++) {
@@ -96,8 +103,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
             pf[e] -= step_size * mf[e] / (sqrtf(vf[e]) / bc2_sqrt + t.eps);
         }
         if (vec) {
-            stv(p, i, pf); stv(m, i, mf); stv(v, i, vf);
-            if (MASTER) stv(w, i, pf);
+            constexpr std::true_type S{};
+            constexpr std::false_type K{};
+            stv(p, i, pf, K); stv(m, i, mf, S); stv(v, i, vf, S);      // the updated parameters are what the next forward reads: kept cacheable
+            if (MASTER) stv(w, i, pf, S);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; e++)
@@ -146,7 +155,11 @@ static int adamw_launch(const ff_adamw_desc* d, int state_dtype, void* const* pa
             FF_CHECK(state_dtype == FF_DTYPE_F32, FF_ERR_UNSUPPORTED, "ff_adamw_step: fp32 master copies go with fp32 moments");
             adamw_kernel<bf16, float, true, 8><<<grid, block, 0, stream>>>(t);
         } else if (state_dtype == FF_DTYPE_F32) adamw_kernel<bf16, float, false, 8><<<grid, block, 0, stream>>>(t);
-        else adamw_kernel<bf16, bf16, false, 8><<<grid, block, 0, stream>>>(t);
+        else {
+            static const int mode = [] { const char* e = getenv("FF_ADAMW_MODE"); return e ? atoi(e) : 1; }();
+            if (mode >= 1) adamw_kernel<bf16, bf16, false, 8, 1><<<grid, block, 0, stream>>>(t);
+            else adamw_kernel<bf16, bf16, false, 8><<<grid, block, 0, stream>>>(t);
+        }
         FF_TRY(check_launch("adamw"));
     }
     return FF_OK;

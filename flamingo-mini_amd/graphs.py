@@ -39,7 +39,12 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         model.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # With collectives in the step the process group's watchdog THREAD is alive and polls the events of the warm-up steps' collectives
+        # (hipEventQuery) whenever it wakes up; under the default "global" capture mode such a call from another thread during the capture
+        # aborts the process (seen once in ~10 runs of the 1-rank RCCL test).  "thread_local" restricts the check to this thread's own calls.
+        import torch.distributed as dist
+        mode = "thread_local" if reducer is not None or (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = self._eager().detach()
         torch.cuda.synchronize()
 

@@ -146,11 +146,14 @@ FF_DEV void epilogue8(const GemmParams& P, const GemmProblem& pr, int m, int n, 
 
 // Epilogue of one bf16 output tile parked in LDS as fp32 (see gemm_bf16_dma_kernel): thread -> 8 consecutive columns of a row,
 // rows strided over the 256 threads in a rolled loop, so the code exists once and every global access is a 16-byte piece of a row.
-template <int BM, int BN>
+// Row swizzle of the parked fp32 tile: 16-byte chunk `ch` of row r sits at chunk ch ^ (r & kMask); the mask must keep the chunk inside
+// the row (BN / 4 chunks): 15 for the power-of-two widths, 7 for BN = 160 (40 chunks = 5 groups of 8).
+template <int BN> struct CtSwz { static constexpr int kMask = (BN / 4) % 16 == 0 ? 15 : 7; };
+template <int BM, int BN, int NTHR = 256>
 FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const float* ct, int m_base, int n_base) {
-    constexpr int TPR = BN / 8, RPP = 256 / TPR;
+    constexpr int TPR = BN / 8, RPP = NTHR / TPR;
     const int t = threadIdx.x, tr = t / TPR, col = (t % TPR) * 8, n = n_base + col;
-    if (n >= P.N) return;
+    if (t >= TPR * RPP || n >= P.N) return;
     const int nv = min(8, P.N - n);
     const bool vec = P.c_vec8 && nv == 8;
     const float gate = pr.gate ? tanhf(to_f32(*(const bf16*)pr.gate)) : 1.f;
@@ -161,7 +164,7 @@ FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const
 #pragma unroll UNROLL
         for (int r = tr; r < nrows; r += RPP) {
             const int m = m_base + r;
-            const int ch = col >> 2, sw = r & 15;
+            const int ch = col >> 2, sw = r & CtSwz<BN>::kMask;
             const f32x4 lo = *(const f32x4*)(ct + r * BN + ((ch ^ sw) << 2)), hi = *(const f32x4*)(ct + r * BN + (((ch + 1) ^ sw) << 2));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             epilogue8<bf16, F>(P, pr, m, n, nv, vec, gate, v);
@@ -362,13 +365,144 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, cons
 #pragma unroll
         for (int j = 0; j < NT; j++) {
             const int ch = ((wn * WN + j * 16) >> 2) + g;
-            *(f32x4*)(ct + ml * BN + ((ch ^ c) << 2)) = acc[i][j];
+            *(f32x4*)(ct + ml * BN + ((ch ^ (c & CtSwz<BN>::kMask)) << 2)) = acc[i][j];
         }
     }
     __syncthreads();
     FF_TL(4);
     tile_epilogue_bf16<BM, BN>(Q, pr, ct, m_base, n_base);
     FF_TL(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Producer / consumer variant for shapes whose tile grid can be made to fit the chip exactly: 8 waves, waves 0-3 only run MFMA
+// (2 x 2 over the BM x BN tile), waves 4-7 only issue the LDS-DMA of the operand ring.  In the kernel above every wave does both,
+// and a DMA instruction parks its in-order wave for ~100+ cycles, which a second co-resident workgroup has to hide; that is why a
+// workgroup alone on a CU reaches only half of the CU's operand rate there.  Here a single workgroup per CU reaches it, so a launch
+// can use ONE tile per CU: 1024 x 5120 -> 8 x 32 tiles of 128 x 160 = 256 workgroups (the 128 x 128 grid has 320 tiles: 64 CUs get
+// two), and 1024 x 1280 x 5120 -> 64 tiles x split-K 4.  K-major operands only (BN = 160 has no M-major staging).
+// Measured (tools/pc_bench.py, cold operands): 32.3 -> 28.1 us and 31.4 -> 28.4 us incl. the split-K reduce; in-model 37.60 -> 37.41
+// ms/step.  A k-step still takes ~1.05 us = 14 B/clk of operand bytes (the 4-wave kernel alone on a CU: ~10; two of them: ~21 together):
+// eight DMA waves instead of four, or a 4-deep ring, change nothing - the limit is the CU's outstanding-request depth times the cold
+// operands' latency, not DMA issue.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
+                                                           int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* smem = (bf16*)smem_raw;
+    constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
+    constexpr int PER_TILE = BM / 32 + BN / 32;   // DMA instructions per producer wave per k-step
+    static_assert(WN % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+    static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
+
+    RowMap a_map{h_ald, 0, 0}, b_map{h_bld, 0, 0};
+    if (h_seg) { a_map = P.a_map; b_map = P.b_map; }
+    const void* opA = hA;
+    const void* opB = hB;
+    const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
+    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd & 255, h_xcd >> 8, tiles_m, tiles_n);
+    if (tc.z > 0) { opA = P.p[tc.z].A; opB = P.p[tc.z].B; }
+    const int m_base = tc.tm * BM, n_base = tc.tn * BN;
+    const int k_begin = tc.split * h_kps;
+    const int k_end = min(hK, k_begin + h_kps);
+    const int t = threadIdx.x, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool producer = w >= 4;
+    const int pw = w & 3;                          // index among the four producers / the four consumers
+    const int wm = pw >> 1, wn = pw & 1;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)opB, 0, 0x7fffffff, 0x00020000);
+    const int nk = (k_end - k_begin + kBK - 1) / kBK;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned va[BM / 32], vb[BN / 32];
+    auto issue = [&](int tile) {
+        bf16* st = smem + (tile % NS) * STAGE;
+        const int k0 = k_begin + tile * kBK;
+        if (k0 + kBK <= k_end) {               // wave-uniform
+            dma_tile_fast<BM, 0>(ra, st, va, (unsigned)k0 * 2u, pw);
+            dma_tile_fast<BN, 0>(rb, st + A_ELEMS, vb, (unsigned)k0 * 2u, pw);
+        } else {
+            dma_tile<BM, 0>(ra, st, a_map, m_base, hM, k0, k_end, pw, l);
+            dma_tile<BN, 0>(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, pw, l);
+        }
+    };
+    if (producer) {
+        dma_prepare<BM, 0>(a_map, m_base, hM, pw, l, va);
+        dma_prepare<BN, 0>(b_map, n_base, hN, pw, l, vb);
+#pragma unroll
+        for (int s = 0; s < NS - 1; s++)
+            if (s < nk) issue(s);
+    }
+    FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
+    if (tc.z > 0) pr = P.p[tc.z];
+    if (producer) {
+        for (int kt = 0; kt < nk; kt++) {
+            const int younger = min(nk - 1 - kt, NS - 2);
+            if (NS >= 4 && younger == 2) wait_vmcnt<2 * PER_TILE>();
+            else if (NS >= 3 && younger >= 1) wait_vmcnt<PER_TILE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();           // tile kt is in LDS for everybody; the consumers have left stage (kt - 1) % NS
+            if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        }
+    } else {
+        for (int kt = 0; kt < nk; kt++) {
+            __builtin_amdgcn_s_barrier();
+            const bf16* sA = smem + (kt % NS) * STAGE;
+            const bf16* sB = sA + A_ELEMS;
+#pragma unroll
+            for (int ks = 0; ks < kBK / 32; ks++) {
+                bf16x8 fa[MT], fb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, 0>(sA, wm * WM + i * 16, ks);
+#pragma unroll
+                for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, 0>(sB, wn * WN + j * 16, ks);
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
+            }
+        }
+    }
+    const int c = l & 15, g = l >> 4;
+    if (Q.split_k > 1) {   // fp32 partial slab; gemm_splitk_epilogue_kernel reduces the slabs and applies the epilogue
+        if (producer) return;
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const int m = m_base + wm * WM + i * 16 + c;
+            if (m >= Q.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int n = n_base + wn * WN + j * 16 + g * 4;
+                if (n >= Q.N) continue;
+                *(f32x4*)(Q.partial + ((long long)(tc.z * Q.split_k + tc.split) * Q.M + m) * Q.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    static_assert(BM * BN * 4 <= NS * STAGE * 2, "fp32 tile must fit the operand ring");
+    __syncthreads();                                // the consumers' last reads of the ring are done
+    float* ct = (float*)smem_raw;
+    if (!producer) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const int ml = wm * WM + i * 16 + c;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int ch = ((wn * WN + j * 16) >> 2) + g;
+                *(f32x4*)(ct + ml * BN + ((ch ^ (c & CtSwz<BN>::kMask)) << 2)) = acc[i][j];
+            }
+        }
+    }
+    __syncthreads();
+    tile_epilogue_bf16<BM, BN, 512>(Q, pr, ct, m_base, n_base);      // all eight waves share the row loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -586,16 +720,26 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;
     TilePlan p;
     const int ft = forced_tile();
-    if (ft == 128 || ft == 64 || ft == 6412) {
+    const bool pc_ok = a_layout == 0 && b_layout == 0;       // the producer / consumer kernel stages K-major operands only
+    if (ft == 128 || ft == 64 || ft == 6412 || (ft == 128160 && pc_ok)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
-        const long long t = ft == 128 ? t128 : ft == 64 ? t64 : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
+        const long long t = ft == 128 ? t128 : ft == 64 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
+                                                                             : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
         p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
         return p;
     }
     // 200..450 tiles of 128x128 leave most CUs with a single, latency-bound workgroup; 64x128 tiles (1.5x the operand traffic
     // but 2-3 workgroups per CU) measured 10-25 % faster there when A is row-major (sweep in tools/gemm_bench.py)
-    if (t128 >= 200 && t128 < 450 && a_layout == 0 && (long long)cdiv(M, 64) * cdiv(N, 128) * nz >= 400) p = TilePlan{6412, 1};
+    // one 128 x 160 tile per CU (producer / consumer kernel) when that grid, times a small split-K, lands on 224..256 workgroups
+    static const int pc_on = env_int("FF_GEMM_PC", 1);
+    const long long t160 = (long long)cdiv(M, 128) * cdiv(N, 160) * nz;
+    int pc_split = 0;
+    if (pc_on && pc_ok && N % 160 == 0 && K % 64 == 0 && t160 <= 256)
+        for (int sp = 1; sp <= 8 && !pc_split; sp++)
+            if (t160 * sp >= 224 && t160 * sp <= 256 && K / sp >= 1024 && K % (64 * sp) == 0) pc_split = sp;
+    if (pc_split) p = TilePlan{128160, pc_split};
+    else if (t128 >= 200 && t128 < 450 && a_layout == 0 && (long long)cdiv(M, 64) * cdiv(N, 128) * nz >= 400) p = TilePlan{6412, 1};
     else if (t128 >= 200) p = TilePlan{128, 1};
     else if (K >= 2048) {
         int s = (int)std::min<long long>(8, std::max<long long>(2, cdiv(384, t128)));
@@ -640,18 +784,40 @@ template <int BM, int BN, int NS> static int dispatch_bf16_dma(const GemmParams&
 template <int BM, int BN> static int run_bf16_dma_tile(const GemmParams& P, int ns, hipStream_t st) {
     return ns == 2 ? dispatch_bf16_dma<BM, BN, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<BM, BN, 4>(P, st) : dispatch_bf16_dma<BM, BN, 3>(P, st);
 }
+template <int BM, int BN, int NS> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
+    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pc_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm pc lds=%zu): %s", lds, hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
+    const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
+    gemm_bf16_pc_kernel<BM, BN, NS><<<dim3(grid), dim3(512), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
+                                                                                  P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
+                                                                                  (int)P.b_map.ld, seg, P);
+    return check_launch("gemm_bf16_pc");
+}
 static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     static const int ns_env = env_int("FF_GEMM_STAGES", 0);
     // default 2 stages: 64 KiB (128x128) / 16 KiB (64x64) per workgroup, so several workgroups per CU overlap each other's
     // DMA-issue and barrier stalls - measured faster than deeper rings at lower occupancy (tools/gemm_bench.py --sweep)
     const int ns = g_force_stages > 0 ? g_force_stages : ns_env > 0 ? ns_env : 2;
+    if (P.tile == 128160) {      // 3 stages (108 KiB) by default: one workgroup per CU, so the ring has to cover the DMA latency by itself
+        const int pns = g_force_stages > 0 ? g_force_stages : ns_env > 0 ? ns_env : 3;
+        return pns == 4 ? launch_bf16_pc<128, 160, 4>(P, st) : launch_bf16_pc<128, 160, 3>(P, st);      // (2 stages would not hold the parked fp32 tile)
+    }
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
     if (P.tile == 6412) return run_bf16_dma_tile<64, 128>(P, ns, st);
     return run_bf16_dma_tile<64, 64>(P, ns, st);
 }
 
 int gemm_pick_split(int dtype, int M, int N, int K, int nz) {
-    if (dtype == FF_DTYPE_BF16) return plan_bf16(M, N, K, nz, 0).split;
+    if (dtype == FF_DTYPE_BF16)     // workspace sizing does not know the operand layouts: the larger of the two plans they can select
+        return std::max(plan_bf16(M, N, K, nz, 0, 0, 0).split, plan_bf16(M, N, K, nz, 0, 0, 1).split);
     const long long tiles = (long long)cdiv(M, kFBM) * cdiv(N, kFBM) * nz;
     if (tiles >= 128 || K < 1024) return 1;
     int s = (int)(256 / tiles);
@@ -685,8 +851,8 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.partial = (float*)workspace;
     }
     {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
-        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 ? 128 : 64) : kFBM;
-        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 ? 64 : 128) : kFBM;
+        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 ? 128 : 64) : kFBM;
+        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
         const int tiles_m = cdiv(P.M, tm_edge), tiles_n = cdiv(P.N, tn_edge);
         double best = 1e300;
         P.xcd_ms = 1; P.xcd_ns = 1;

@@ -38,12 +38,47 @@ def test_gemm_every_instantiated_tile(al, bl):
     ref = (a if al == 0 else a.T) @ (b.T if bl == 0 else b)
     lib = ffi.lib()
     try:
-        for tile in (128, 6412, 64):
+        for tile in (128, 6412, 64) + ((128160,) if (al, bl) == (0, 0) else ()):      # 128160: the 8-wave producer / consumer kernel (K-major operands)
             for stages in (2, 3, 4):
                 lib.ff_gemm_set_tuning(tile, stages)
                 for split in (1, 2):
                     C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split)
                     assert rel(C, ref) < 1e-2, (tile, stages, split)
+    finally:
+        lib.ff_gemm_set_tuning(0, 0)
+
+
+def test_gemm_balanced_producer_consumer_tile():
+    """The one-tile-per-CU kernel (128 x 160 tiles, 4 MFMA waves + 4 DMA waves) at the two shapes the planner picks it for - the gated
+    block's FFW up-projection 1024 x 5120 x 1280 (256 tiles) and down-projection 1024 x 1280 x 5120 (64 tiles x split-K 4) - with their
+    real epilogues, and forced onto a ragged problem (partial tiles in M and N, K tail) with every epilogue."""
+    from flamingo_mini_amd import ffi
+    dt = torch.bfloat16
+    gate = dev(np.array([0.7]), dt)
+    g = np.tanh(as64(gate)[0])
+    A, B = dev(rnd((1024, 1280), 21, 0.5), dt), dev(rnd((5120, 1280), 22, 0.05), dt)
+    C, aux = F().gemm(A, B, act="gelu", want_aux_out=True)
+    acc = as64(A) @ as64(B).T
+    assert rel(aux, acc) < TOL[dt]["out"] and rel(C, O.act_fwd(acc, "gelu")) < TOL[dt]["out"]
+    A, B, R = dev(rnd((1024, 5120), 23, 0.5), dt), dev(rnd((1280, 5120), 24, 0.02), dt), dev(rnd((1024, 1280), 25), dt)
+    C = F().gemm(A, B, residual=R, gate=gate)
+    assert rel(C, as64(R) + g * (as64(A) @ as64(B).T)) < TOL[dt]["out"]
+    lib = ffi.lib()
+    try:
+        lib.ff_gemm_set_tuning(128160, 0)
+        M, N, K = 200, 336, 1096
+        A, B = dev(rnd((M, K), 26, 0.5), dt), dev(rnd((N, K), 27, 0.05), dt)
+        R, H = dev(rnd((M, N), 28), dt), dev(rnd((M, N), 29), dt)
+        acc, r, h = as64(A) @ as64(B).T, as64(R), as64(H)
+        for split_k in (1, 3):
+            for act in ("gelu", "sqrelu", "relu"):
+                C, aux = F().gemm(A, B, act=act, want_aux_out=True, split_k=split_k)
+                assert rel(aux, acc) < TOL[dt]["out"] and rel(C, O.act_fwd(acc, act)) < TOL[dt]["out"]
+                C = F().gemm(A, B, act_bwd=act, aux_in=H, gate=gate, split_k=split_k)
+                assert rel(C, acc * g * O.act_bwd(np.ones_like(h), h, act)) < TOL[dt]["out"]
+            C = F().gemm(A, B, residual=R, gate=gate, split_k=split_k)
+            assert rel(C, r + g * acc) < TOL[dt]["out"]
+            assert rel(F().gemm(A, B, scale=0.25, split_k=split_k), 0.25 * acc) < TOL[dt]["out"]
     finally:
         lib.ff_gemm_set_tuning(0, 0)
 

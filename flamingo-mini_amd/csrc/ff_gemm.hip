@@ -980,9 +980,9 @@ extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_
     using namespace ff;
     FF_CHECK(d && bm && bn && split_k, FF_ERR_SHAPE, "ff_gemm_plan: null argument");
     if (d->dtype == FF_DTYPE_BF16) {
-        const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout);
-        *bm = p.tile == 128 ? 128 : 64;
-        *bn = p.tile == 64 ? 64 : 128;
+        const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout);
+        *bm = p.tile == 128 || p.tile == 128160 ? 128 : 64;
+        *bn = p.tile == 64 ? 64 : p.tile == 128160 ? 160 : 128;
         *split_k = p.split;
     } else {
         *bm = *bn = kFBM;

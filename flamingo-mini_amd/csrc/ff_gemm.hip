@@ -386,8 +386,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, cons
 // eight DMA waves instead of four, or a 4-deep ring, change nothing - the limit is the CU's outstanding-request depth times the cold
 // operands' latency, not DMA issue.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int NS>
-__global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
+// WPC = workgroups per CU the register budget is sized for (2: <= 128 registers per lane, two 8-wave workgroups share a CU)
+template <int BM, int BN, int AL, int BL, int NS, int WPC>
+__global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
                                                            int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const void* hA, const
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
     constexpr int PER_TILE = BM / 32 + BN / 32;   // DMA instructions per producer wave per k-step
     static_assert(WN % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+    static_assert((AL == 0 || BM == 128 || BM == 64) && (BL == 0 || BN == 128 || BN == 64), "M-major staging exists for 64 / 128-wide tiles only");
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
 
     RowMap a_map{h_ald, 0, 0}, b_map{h_bld, 0, 0};
@@ -423,20 +425,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const void* hA, const
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     unsigned va[BM / 32], vb[BN / 32];
+    const bool a_plain = AL == 0 || a_map.rows_per_seg <= 0, b_plain = BL == 0 || b_map.rows_per_seg <= 0;
+    const unsigned a_step = AL == 0 ? 2u : (unsigned)a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)b_map.ld * 2u;   // bytes per unit of k
     auto issue = [&](int tile) {
         bf16* st = smem + (tile % NS) * STAGE;
         const int k0 = k_begin + tile * kBK;
-        if (k0 + kBK <= k_end) {               // wave-uniform
-            dma_tile_fast<BM, 0>(ra, st, va, (unsigned)k0 * 2u, pw);
-            dma_tile_fast<BN, 0>(rb, st + A_ELEMS, vb, (unsigned)k0 * 2u, pw);
-        } else {
-            dma_tile<BM, 0>(ra, st, a_map, m_base, hM, k0, k_end, pw, l);
-            dma_tile<BN, 0>(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, pw, l);
-        }
+        const bool full = k0 + kBK <= k_end;       // wave-uniform
+        if (full && a_plain) dma_tile_fast<BM, AL>(ra, st, va, (unsigned)k0 * a_step, pw);
+        else dma_tile<BM, AL>(ra, st, a_map, m_base, hM, k0, k_end, pw, l);
+        if (full && b_plain) dma_tile_fast<BN, BL>(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, pw);
+        else dma_tile<BN, BL>(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, pw, l);
     };
     if (producer) {
-        dma_prepare<BM, 0>(a_map, m_base, hM, pw, l, va);
-        dma_prepare<BN, 0>(b_map, n_base, hN, pw, l, vb);
+        dma_prepare<BM, AL>(a_map, m_base, hM, pw, l, va);
+        dma_prepare<BN, BL>(b_map, n_base, hN, pw, l, vb);
 #pragma unroll
         for (int s = 0; s < NS - 1; s++)
             if (s < nk) issue(s);
@@ -461,9 +463,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const void* hA, const
             for (int ks = 0; ks < kBK / 32; ks++) {
                 bf16x8 fa[MT], fb[NT];
 #pragma unroll
-                for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, 0>(sA, wm * WM + i * 16, ks);
+                for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
 #pragma unroll
-                for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, 0>(sB, wn * WN + j * 16, ks);
+                for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, BL>(sB, wn * WN + j * 16, ks);
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -721,10 +723,10 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     TilePlan p;
     const int ft = forced_tile();
     const bool pc_ok = a_layout == 0 && b_layout == 0;       // the producer / consumer kernel stages K-major operands only
-    if (ft == 128 || ft == 64 || ft == 6412 || (ft == 128160 && pc_ok)) {
+    if (ft == 128 || ft == 64 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
-        const long long t = ft == 128 ? t128 : ft == 64 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
+        const long long t = ft == 128 || ft == 128002 ? t128 : ft == 64 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
                                                                              : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
         p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
         return p;
@@ -752,6 +754,9 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
         p = TilePlan{64, s};
     }
     if (want_split > 0) p.split = want_split;
+    static const int pc128 = env_int("FF_GEMM_PC128", 2);      // the producer / consumer kernel for every 128 x 128 launch (0: the 4-wave kernel)
+    if (pc128 && p.tile == 128) p.tile = 128002;
+    if (pc128 >= 2 && p.tile == 6412) p.tile = 128002;         // ... and instead of the 64 x 128 tiles (1: keep those)
     return p;
 }
 static bool big_tile(const GemmParams& P) { return P.tile == 128; }
@@ -784,22 +789,29 @@ template <int BM, int BN, int NS> static int dispatch_bf16_dma(const GemmParams&
 template <int BM, int BN> static int run_bf16_dma_tile(const GemmParams& P, int ns, hipStream_t st) {
     return ns == 2 ? dispatch_bf16_dma<BM, BN, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<BM, BN, 4>(P, st) : dispatch_bf16_dma<BM, BN, 3>(P, st);
 }
-template <int BM, int BN, int NS> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
+template <int BM, int BN, int AL, int BL, int NS, int WPC> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pc_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm pc lds=%zu): %s", lds, hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
-    gemm_bf16_pc_kernel<BM, BN, NS><<<dim3(grid), dim3(512), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
-                                                                                  P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
-                                                                                  (int)P.b_map.ld, seg, P);
+    gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC><<<dim3(grid), dim3(512), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
+                                                                                 P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
+                                                                                 (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_pc");
+}
+// 128 x 128 tiles, two 8-wave workgroups per CU (experiment: FF_GEMM_TILE=128002 / FF_GEMM_PC128=1)
+template <int NS> static int dispatch_bf16_pc128(const GemmParams& P, hipStream_t st) {
+    if (P.a_layout == 0 && P.b_layout == 0) return launch_bf16_pc<128, 128, 0, 0, NS, 2>(P, st);
+    if (P.a_layout == 0 && P.b_layout == 1) return launch_bf16_pc<128, 128, 0, 1, NS, 2>(P, st);
+    if (P.a_layout == 1 && P.b_layout == 0) return launch_bf16_pc<128, 128, 1, 0, NS, 2>(P, st);
+    return launch_bf16_pc<128, 128, 1, 1, NS, 2>(P, st);
 }
 static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     static const int ns_env = env_int("FF_GEMM_STAGES", 0);
@@ -808,8 +820,9 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     const int ns = g_force_stages > 0 ? g_force_stages : ns_env > 0 ? ns_env : 2;
     if (P.tile == 128160) {      // 3 stages (108 KiB) by default: one workgroup per CU, so the ring has to cover the DMA latency by itself
         const int pns = g_force_stages > 0 ? g_force_stages : ns_env > 0 ? ns_env : 3;
-        return pns == 4 ? launch_bf16_pc<128, 160, 4>(P, st) : launch_bf16_pc<128, 160, 3>(P, st);      // (2 stages would not hold the parked fp32 tile)
+        return pns == 4 ? launch_bf16_pc<128, 160, 0, 0, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 0, 3, 1>(P, st);      // (2 stages would not hold the parked fp32 tile)
     }
+    if (P.tile == 128002) return dispatch_bf16_pc128<2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
     if (P.tile == 6412) return run_bf16_dma_tile<64, 128>(P, ns, st);
     return run_bf16_dma_tile<64, 64>(P, ns, st);
@@ -851,7 +864,7 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.partial = (float*)workspace;
     }
     {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
-        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 ? 128 : 64) : kFBM;
+        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : 64) : kFBM;
         const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
         const int tiles_m = cdiv(P.M, tm_edge), tiles_n = cdiv(P.N, tn_edge);
         double best = 1e300;
@@ -981,7 +994,7 @@ extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_
     FF_CHECK(d && bm && bn && split_k, FF_ERR_SHAPE, "ff_gemm_plan: null argument");
     if (d->dtype == FF_DTYPE_BF16) {
         const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout);
-        *bm = p.tile == 128 || p.tile == 128160 ? 128 : 64;
+        *bm = p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : 64;
         *bn = p.tile == 64 ? 64 : p.tile == 128160 ? 160 : 128;
         *split_k = p.split;
     } else {

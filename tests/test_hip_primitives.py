@@ -38,7 +38,8 @@ def test_gemm_every_instantiated_tile(al, bl):
     ref = (a if al == 0 else a.T) @ (b.T if bl == 0 else b)
     lib = ffi.lib()
     try:
-        for tile in (128, 6412, 64) + ((128160,) if (al, bl) == (0, 0) else ()):      # 128160: the 8-wave producer / consumer kernel (K-major operands)
+        # 128002 / 128160: the 8-wave producer / consumer kernel (128 x 128 for every layout, 128 x 160 for K-major operands)
+        for tile in (128, 6412, 64, 128002) + ((128160,) if (al, bl) == (0, 0) else ()):
             for stages in (2, 3, 4):
                 lib.ff_gemm_set_tuning(tile, stages)
                 for split in (1, 2):

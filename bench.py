@@ -457,8 +457,10 @@ def main():
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             tm, tn = (64, 128) if key[1] == 6412 else (key[1], key[1])
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
-            if key[1] == 128160:
-                name = "ff::gemm_bf16_pc_kernel<128, 160, 3>"
+            if key[1] == 128160:      # the 8-wave producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU>
+                name = "ff::gemm_bf16_pc_kernel<128, 160, 0, 0, 3, 1>"
+            elif key[1] == 128002:
+                name = f"ff::gemm_bf16_pc_kernel<128, 128, {key[2]}, {key[3]}, 2, 2>"
             tot_ms = sum(v["ms"] for v in groups.values())
             tot_fl = sum(v["flops"] for v in groups.values())
             traffic = None      # HBM bytes per launch of this kernel from the latest committed PMC passes (profiles/rNN_pmc_traffic.json;

@@ -25,6 +25,14 @@ import torch.distributed as dist
 from . import functional as F
 
 
+def _split_kv_buckets(model: torch.nn.Module, layers_per_bucket: int = 4) -> None:
+    """With collectives in play the hoisted K / V projection runs as one call per `layers_per_bucket` layers (FlamingoBaseModel.
+    kv_project_group): each call is its own autograd node with its own gradient bucket, ready as soon as its layers' backward is done."""
+    for m in model.modules():
+        if hasattr(m, "kv_project_group") and m.kv_project_group == 0:
+            m.kv_project_group = layers_per_bucket
+
+
 def _bucket_is_ours(owners, ids) -> bool:
     """The gradient-ready callbacks are process-wide: a second model in the process (an evaluation copy, a test's reference model)
     announces its buckets too.  A bucket belongs to a reducer iff all of its parameters are that reducer's model's."""
@@ -53,6 +61,8 @@ class GradientAllReducer:
         self._fused_ids = fused
         self.loose = [p for p in model.parameters() if p.requires_grad and id(p) not in fused]
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_param) for p in self.loose]
+        if self.active:
+            _split_kv_buckets(model)
         F.add_grad_ready_callback(self._on_bucket)
 
     def close(self):
@@ -171,6 +181,8 @@ class ShardedAdamW:
         self._loose_opt = FusedAdamW(self.loose, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, master_dtype=master_dtype) if update_fn is None else None
         self._loose_update_fn = update_fn
         self._loose_state = {}
+        if self.collectives:
+            _split_kv_buckets(model)
         F.add_grad_ready_callback(self._on_bucket)
 
     def close(self):

@@ -63,6 +63,11 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
         # keys / values of all cross-attention layers in grouped launches ahead of the LM (functional.kv_project): 41.5 -> 40.2 ms per
         # step at the benchmark configuration; FF_HOIST_KV=0 (or .hoist_kv = False) restores the per-layer projection
         self.hoist_kv = os.environ.get("FF_HOIST_KV", "1") == "1"
+        # 0: ONE projection call (one autograd node, one gradient bucket) for all layers; n > 0: one call per n consecutive layers, so that
+        # under data parallelism the to_kv gradients of the upper layers are final - and their all-reduce starts - while backward is still
+        # working on the lower ones (the data-parallel reducers set 4 = one grouped launch per call; a single bucket of all 36 to_kv
+        # weights, 75 MB at flamingo-mini's size, would only become ready at the very end of backward)
+        self.kv_project_group = 0
 
     def _init_weights(self, module):  # backbones initialise themselves; fusion modules use torch defaults like the reference
         pass
@@ -146,7 +151,9 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
         if xattn_past is None and self.hoist_kv:
             # every layer's to_kv sees the same visual features: project for all layers in grouped launches (functional.kv_project)
             weights = [h.xattn_block.attn.to_kv.weight for h in hooks]
-            hoisted = F.kv_project(visual_features.to(weights[0].dtype), weights)
+            vf_cast = visual_features.to(weights[0].dtype)
+            step = self.kv_project_group if self.kv_project_group > 0 else len(weights)
+            hoisted = [kv for g in range(0, len(weights), step) for kv in F.kv_project(vf_cast, weights[g:g + step])]
         for i, hook in enumerate(hooks):
             hook.condition(visual_features, media_locations, None if xattn_past is None else xattn_past[i], text_time=text_time,
                            hoisted_kv=None if hoisted is None else hoisted[i])

@@ -46,6 +46,8 @@ def _worker(rank, world, port, out_dir, hoist_kv):
     from flamingo_mini_amd.data_parallel import GradientAllReducer
     model, z = _build_tiny(hoist_kv)
     reducer = GradientAllReducer(model)
+    assert model.flamingo.kv_project_group == 4           # collectives in play: the hoisted K / V projection is cut into per-4-layer buckets
+    model.flamingo.kv_project_group = 1                   # (here: one bucket per layer, so that the tiny model has several of them)
     buckets = []
     orig = reducer._on_bucket
     reducer._on_bucket = lambda flat, owners=(): (buckets.append(flat.numel()), orig(flat, owners))[1]
@@ -89,7 +91,8 @@ def test_two_rank_gloo_matches_single_process(tmp_path, hoist_kv):
     ((_loss(model, z, [0]) + _loss(model, z, [1])) / 2).backward()
     n_hooks = len(model.flamingo.get_modified_layers())
     # one flat bucket per xattn block + the resampler (+ all to_kv weights when hoisted); the token embedding goes through its own hook
-    assert int(r0["nbuckets"]) == n_hooks + 1 + int(hoist_kv)
+    # (hoisted: one to_kv bucket per projection call - the workers ran one call per layer, this process one call for all layers)
+    assert int(r0["nbuckets"]) == n_hooks + 1 + (n_hooks if hoist_kv else 0)
     for k, p in model.named_parameters():
         if not p.requires_grad:
             continue

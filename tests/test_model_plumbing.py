@@ -129,10 +129,12 @@ def test_cpu_tensors_raise_in_the_product_path():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["opt", "gpt2"])
-@pytest.mark.parametrize("hoist_kv", [False, True], ids=["per-layer-kv", "hoisted-kv"])
+@pytest.mark.parametrize("hoist_kv", [False, True, 1], ids=["per-layer-kv", "hoisted-kv", "hoisted-kv-one-call-per-layer"])
 def test_full_model_fp32_on_hip_matches_reference(hoist_kv, family):
     model, z = build(torch.float32, "cuda", family)
-    model.flamingo.hoist_kv = hoist_kv
+    model.flamingo.hoist_kv = bool(hoist_kv)
+    if hoist_kv == 1 and hoist_kv is not True:      # the data-parallel layout: several projection calls (= gradient buckets) instead of one
+        model.flamingo.kv_project_group = 1
     run_checks(model, z, "cuda", torch.float32, 1e-4, 5e-4)
 
 

@@ -25,7 +25,6 @@ this box's host cores (and config A end to end).
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -34,7 +33,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

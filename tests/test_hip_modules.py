@@ -10,7 +10,7 @@ import torch
 
 from detgen import det, resampler_params, xattn_params
 from oracle import flamingo_oracle as O
-from util import GOLDEN, TOL, as64, dev, rel, rnd
+from util import GOLDEN, TOL, as64, dev, rel
 
 pytestmark = pytest.mark.gpu
 

@@ -1,7 +1,7 @@
 """Condense a rocprofv3 `--kernel-trace --stats --output-format csv` run of bench.py into a per-step, per-category table.
     python tools/summarize_rocprof.py gpurun_out/prof_x/x_kernel_stats.csv --steps-total 5 > profiles/rNN_summary.md
 """
-import argparse, csv, re, sys
+import argparse, csv, re
 
 
 def category(name):

@@ -10,7 +10,7 @@ import numpy as np, torch
 from flamingo_mini_amd import ffi, functional as F
 ffi.LIB_PATH = os.path.join(ROOT, "tools", "_dbg", "libflamingo_fusion_timeline.so")
 from flamingo_mini_amd import GatedCrossAttentionBlock
-from detgen import det, xattn_params
+from detgen import xattn_params
 
 lib = ffi.lib()
 rd = C.CDLL(ffi.LIB_PATH).ff_debug_xa_timeline_read

@@ -25,6 +25,52 @@ def test_library_exports_exactly_the_header():
     assert lib.ff_version() == ffi.ABI_VERSION and lib.ff_arch() == b"gfx950"
 
 
+def _header_prototypes():
+    """name -> (return kind, [parameter kinds]) parsed from the header; kinds: 'ptr', 'int', 'size', 'i64', 'float', 'str'."""
+    text = open(os.path.join(ROOT, "include", "flamingo_fusion.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+
+    def kind(decl: str) -> str:
+        decl = decl.strip()
+        if "*" in decl or decl.startswith("ff_stream_t"):
+            return "str" if decl.replace("const", "").strip().startswith("char") else "ptr"
+        base = re.sub(r"\b[a-z_][a-z0-9_]*$", "", decl).strip() or decl      # drop the parameter name
+        base = base.replace("const", "").strip()
+        return {"int": "int", "size_t": "size", "long long": "i64", "float": "float", "unsigned": "int", "void": "void"}[base]
+
+    protos = {}
+    for ret, name, params in re.findall(r"^\s*([a-z_][a-z0-9_ ]*?\**)\s*\b(ff_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.M | re.S):
+        params = " ".join(params.split())
+        plist = [] if params in ("", "void") else [kind(q) for q in params.split(",")]
+        protos[name] = (kind(ret + " x") if "*" in ret else kind(ret + " x"), plist)
+    return protos
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every binding in ffi._SIGNATURES has the arity and the argument classes (pointer / int / size_t / long long / float) of its C
+    prototype: a mismatch here would not fail loudly at run time, it would shift arguments."""
+    from flamingo_mini_amd import ffi
+    protos = _header_prototypes()
+    assert set(protos) == set(ffi._SIGNATURES), set(protos) ^ set(ffi._SIGNATURES)
+
+    def ckind(t):
+        if t is None:
+            return "void"
+        if t is C.c_char_p:
+            return "str"
+        if t in (C.c_void_p,) or hasattr(t, "contents") or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int: "int", C.c_size_t: "size", C.c_longlong: "i64", C.c_float: "float", C.c_uint: "int"}[t]
+
+    for name, (res, args) in ffi._SIGNATURES.items():
+        want_ret, want_args = protos[name]
+        got_args = [ckind(a) for a in args]
+        assert got_args == want_args, (name, got_args, want_args)
+        if res is not None:
+            assert ckind(res) == want_ret, (name, ckind(res), want_ret)
+
+
 def test_workspace_queries_and_error_codes_without_a_device():
     from flamingo_mini_amd import ffi
     lib = ffi.lib()

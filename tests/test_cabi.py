@@ -71,6 +71,53 @@ def test_ctypes_signatures_match_the_header_prototypes():
             assert ckind(res) == want_ret, (name, ckind(res), want_ret)
 
 
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """Field names, order, offsets and sizes of every descriptor struct: the header is compiled (as C, with gcc) into a program that prints
+    offsetof / sizeof of each field, and the ctypes mirror in ffi.py must agree byte for byte."""
+    import shutil
+    import subprocess
+    from flamingo_mini_amd import ffi
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    text = open(os.path.join(ROOT, "include", "flamingo_fusion.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct\s+ff_[a-z_]+\s*\{(.*?)\}\s*(ff_[a-z_]+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if decl:
+                names = decl.replace("*", " ").split(",")
+                fields += [names[0].split()[-1]] + [n.strip() for n in names[1:]]
+        structs[name] = fields
+    mirror = {"ff_rowmap": ffi.RowMap, "ff_gemm_desc": ffi.GemmDesc, "ff_gemm_profile_record": ffi.GemmProfileRecord, "ff_ln_desc": ffi.LnDesc,
+              "ff_reduce_desc": ffi.ReduceDesc, "ff_strides": ffi.Strides, "ff_attn_desc": ffi.AttnDesc, "ff_resampler_desc": ffi.ResamplerDesc,
+              "ff_adamw_desc": ffi.AdamWDesc, "ff_kvproj_desc": ffi.KvProjDesc, "ff_xattn_desc": ffi.XattnDesc}
+    assert set(structs) == set(mirror), set(structs) ^ set(mirror)
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "flamingo_fusion.h"', "int main(void) {"]
+    for sname, fields in structs.items():
+        lines.append(f'  printf("{sname} . %zu\\n", sizeof({sname}));')
+        for f in fields:
+            lines.append(f'  printf("{sname} {f} %zu %zu\\n", offsetof({sname}, {f}), sizeof((({sname}*)0)->{f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        parts = line.split()
+        cls = mirror[parts[0]]
+        if parts[1] == ".":
+            assert C.sizeof(cls) == int(parts[2]), (parts[0], C.sizeof(cls), parts[2])
+            assert [f[0] for f in cls._fields_] == structs[parts[0]], (parts[0], [f[0] for f in cls._fields_], structs[parts[0]])
+        else:
+            fld = getattr(cls, parts[1])
+            assert (fld.offset, fld.size) == (int(parts[2]), int(parts[3])), (parts[0], parts[1], fld.offset, fld.size, parts[2:])
+
+
 def test_workspace_queries_and_error_codes_without_a_device():
     from flamingo_mini_amd import ffi
     lib = ffi.lib()

@@ -383,14 +383,23 @@ def main():
     graph_note = ""
     if use_graph:       # forward + backward (+ gradient all-reduces) + optimizer captured once, one graph launch per step (flamingo_mini_amd/graphs.py)
         from flamingo_mini_amd import GraphedTrainStep
+        err = None
         try:
             graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=reducer if world > 1 else None)
-            step = graphed
         except Exception as e:      # e.g. a collective that cannot be captured on this software stack: run the same step eagerly
             if world == 1 and args.graph == "on":
                 raise
-            graph_note = f"; graph capture failed ({type(e).__name__}: {str(e)[:120]}), eager launches instead"
+            err = e
             torch.cuda.synchronize()
+        captured = err is None
+        if world > 1:               # every rank must take the same path: a rank replaying captured collectives while another launches them
+            flag = torch.tensor([1 if captured else 0], device=device, dtype=torch.int32)      # eagerly would deadlock
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            captured = bool(flag.item())
+        if captured:
+            step = graphed
+        else:
+            graph_note = "; graph capture failed on a rank" + (f" ({type(err).__name__}: {str(err)[:120]})" if err is not None else "") + ", eager launches instead"
             use_graph = False
             if opt is not None and args.optimizer == "fused":
                 from flamingo_mini_amd import FusedAdamW

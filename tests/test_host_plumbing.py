@@ -110,6 +110,16 @@ def _worker(rank, world, port, out_dir, mode):
         _loss(model, z, [rank], torch.float32).backward()
         reducer.finish()
         out = {k: v for k, v in _grads(model).items()}
+        # two micro-batches (the same sequence twice at half weight): the first under no_sync(), the second finds .grad in place, so the
+        # blocks do not defer, autograd accumulates, and the reducer all-reduces the accumulated gradients after backward
+        model.zero_grad(set_to_none=True)
+        with reducer.no_sync():
+            (_loss(model, z, [rank], torch.float32) / 2).backward()
+        host.calls.clear()
+        (_loss(model, z, [rank], torch.float32) / 2).backward()
+        assert "ff_xattn_block_bwd_kv_data" not in host.calls
+        reducer.finish()
+        out.update({"acc." + k: v for k, v in _grads(model).items()})
         reducer.close()
     else:
         from test_data_parallel import HP, _torch_adamw
@@ -146,3 +156,5 @@ def test_two_gloo_ranks_on_the_product_gradient_flow(tmp_path, mode, clean_patch
     for k in want:
         assert np.array_equal(r0[k], r1[k]), k                        # the ranks hold the same values after the exchange
         assert _close(r0[k], want[k], 5e-4 if mode == "sharded" else 2e-4), k
+        if mode == "reduce":
+            assert np.array_equal(r0["acc." + k], r1["acc." + k]) and _close(r0["acc." + k], want[k], 2e-4), k

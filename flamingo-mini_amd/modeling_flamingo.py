@@ -126,7 +126,7 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
     # ---- forward (reference :183-306) ----
     def forward(self, input_ids=None, attention_mask=None, media_locations=None, pixel_values=None, visual_features=None,
                 head_mask=None, inputs_embeds=None, use_cache: bool = False, past_key_values=None, return_dict: bool = True,
-                labels=None, loss_reduction: str = "mean", **kwargs) -> CausalLMOutputWithPast:
+                labels=None, loss_reduction: str = "mean", text_time=None, **kwargs) -> CausalLMOutputWithPast:
         assert return_dict, "can only use return_dict=True at the moment!"
         assert (input_ids is None) != (inputs_embeds is None), "you must pass either input_ids or inputs_embeds!"
         ref = input_ids if input_ids is not None else inputs_embeds
@@ -142,10 +142,12 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
             else:  # cached K/V make the features irrelevant; only the shape is used
                 visual_features = torch.zeros((batch_size, 1, self.config.resampler_num_latents, self.config.dim_visual),
                                               dtype=self.resampler.latents.dtype, device=device)
-        if media_locations is None:
-            media_locations = torch.zeros((batch_size, seq_length), dtype=torch.int, device=device)
-
-        text_time = F.text_time(media_locations)       # once per step, shared by every block (the reference recomputes it per layer)
+        if text_time is None:
+            if media_locations is None:
+                media_locations = torch.zeros((batch_size, seq_length), dtype=torch.int, device=device)
+            text_time = F.text_time(media_locations)   # once per step, shared by every block (the reference recomputes it per layer)
+        # (text_time given: a decode step of the static-cache path - generated tokens are never media tags, so the (b, 1) value of the
+        # prompt's last token is valid for every later position and no per-step cumsum over a growing tensor is needed)
         hooks = self.get_modified_layers()
         hoisted = None
         if xattn_past is None and self.hoist_kv:
@@ -213,6 +215,95 @@ class FlamingoOPT(FlamingoBaseModel):
 
     def get_modified_layers(self):
         return [layer for layer in self.lm.decoder.layers if isinstance(layer, ModifiedLMBlock)]
+
+
+class _DecodeSession:
+    """Fixed-shape greedy decoding for one (batch, max_length) shape: the LM keeps a transformers StaticCache of max_length positions, the
+    attention mask and the token buffer are preallocated, positions travel as a device tensor (`cache_position`), the cross-attention K / V
+    of the prompt step are copied into persistent buffers, and the text_time of a generated token is the prompt's last value (generated
+    tokens are never media tags).  A decode step then issues exactly the same work on the same addresses every time, so on the GPU it is
+    captured once into a HIP graph and replayed (the eager step is host-bound: 72 layers, ~800 launches of a few microseconds each).
+    If the capture raises (e.g. a host synchronisation inside the stock LM) the steps run eagerly.  Token-for-token equal to the
+    growing-cache loop of FlamingoModel.generate (tests/test_model_plumbing.py)."""
+
+    def __init__(self, model, b, max_length, device, ids_dtype, am_dtype, eos, pad, graph):
+        from transformers.cache_utils import StaticCache
+        self.model, self.b, self.max_length, self.eos, self.graph_wanted = model, b, max_length, eos, graph
+        self.fill = pad if pad is not None else 0
+        self.cache = StaticCache(config=model.flamingo.lm.config, max_cache_len=max_length)
+        self.ids_buf = torch.empty((b, max_length), dtype=ids_dtype, device=device)
+        self.am_buf = torch.empty((b, max_length), dtype=am_dtype, device=device)
+        self.finished = torch.zeros(b, dtype=torch.bool, device=device)
+        self.n_new = torch.zeros((), dtype=torch.long, device=device)          # tokens appended while not every sequence had finished
+        self.pos = torch.zeros((1,), dtype=torch.long, device=device)          # position of `tok` (the token the next step consumes)
+        self.tok = torch.zeros((b, 1), dtype=ids_dtype, device=device)
+        self.tt_step = torch.zeros((b, 1), dtype=torch.int32, device=device)
+        self.xattn_past = None                                                 # persistent (k, v) per layer, filled by every prompt step
+        self.replay = None
+        self.capture_failed = False
+
+    def _append(self, logits):             # choose, apply the eos bookkeeping of generate(), append at `pos`
+        nxt = logits.float().argmax(-1)
+        alive = ~self.finished.all()
+        if self.eos is not None:
+            nxt = torch.where(self.finished, torch.full_like(nxt, self.fill), nxt)
+            self.finished.logical_or_(nxt == self.eos)
+        self.tok.copy_(nxt[:, None])
+        self.ids_buf.index_copy_(1, self.pos, self.tok)
+        self.n_new.add_(alive.to(self.n_new.dtype))
+
+    def _step(self):
+        self.am_buf.index_fill_(1, self.pos, 1)
+        o = self.model.flamingo(input_ids=self.tok, attention_mask=self.am_buf, use_cache=True, past_key_values=(self.xattn_past, self.cache),
+                                cache_position=self.pos, text_time=self.tt_step)
+        self.pos.add_(1)
+        self._append(o.logits[:, -1])
+
+    @torch.no_grad()
+    def run(self, ids, ml, am, pixel_values, visual_features):
+        L0 = ids.shape[1]
+        dev = ids.device
+        self.cache.reset()
+        out = self.model.flamingo(input_ids=ids, attention_mask=am, media_locations=ml, use_cache=True, past_key_values=(None, self.cache),
+                                  pixel_values=pixel_values, visual_features=visual_features, cache_position=torch.arange(L0, device=dev))
+        fresh = out.past_key_values[0]
+        if self.xattn_past is None:
+            self.xattn_past = tuple((torch.empty_like(k, memory_format=torch.contiguous_format), torch.empty_like(v, memory_format=torch.contiguous_format))
+                                    for k, v in fresh)
+        for (kb, vb), (k, v) in zip(self.xattn_past, fresh):
+            kb.copy_(k); vb.copy_(v)
+        self.tt_step.copy_(F.text_time(ml)[:, -1:])
+        self.ids_buf.fill_(self.fill)
+        self.ids_buf[:, :L0] = ids
+        self.am_buf.zero_()
+        self.am_buf[:, :L0] = am
+        self.finished.zero_()
+        self.n_new.zero_()
+        self.pos.fill_(L0)
+        self._append(out.logits[:, -1])
+        remaining = self.max_length - L0 - 1
+        if self.graph_wanted and self.replay is None and not self.capture_failed and remaining > 1:
+            self._step()                                                      # eager once: lazy initialisation, allocator pools
+            remaining -= 1
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    self._step()
+                self.graph, self.replay = g, g.replay
+            except Exception:                                                 # the steps run eagerly from here on (and in later calls)
+                torch.cuda.synchronize()
+                self.capture_failed = True
+        run_step = self.replay or self._step
+        i = 0
+        while i < remaining:
+            run_step()
+            i += 1
+            if self.eos is not None and i % 16 == 0 and bool(self.finished.all()):     # (a host sync: only every 16 tokens)
+                break
+        if self.eos is not None:
+            return self.ids_buf[:, :L0 + int(self.n_new)].clone()
+        return self.ids_buf.clone()
 
 
 class FlamingoModel(PreTrainedModel):
@@ -330,7 +421,7 @@ class FlamingoModel(PreTrainedModel):
                  max_length: int = 150, num_beams: int = 1, do_sample: bool = False, temperature: float = 1.0, top_k: int = 0,
                  top_p: float = 1.0, eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None, bos_token_id: Optional[int] = None,
                  early_stopping: bool = True, length_penalty: float = 1.0, use_cache: bool = True, generator: Optional[torch.Generator] = None,
-                 input_ids=None, **unsupported):
+                 input_ids=None, static_decode: Optional[bool] = None, **unsupported):
         """Text generation with the cached cross-attention path: the first step runs CLIP + resampler and fills the xattn K/V and LM caches,
         every later step feeds one token (reference: HF `generate` through prepare_inputs_for_generation / _reorder_cache, :464-548).
         transformers >= 4.50 no longer gives PreTrainedModel a `generate`, so the decoding strategies the reference's callers use are
@@ -349,6 +440,10 @@ class FlamingoModel(PreTrainedModel):
             if do_sample:
                 raise ValueError("beam search with sampling is not implemented")
             return self._beam_search(ids, ml, am, pixel_values, visual_features, max_length, num_beams, eos_token_id, pad, early_stopping, length_penalty)
+        if static_decode is None:       # greedy decoding of a GPT-2-backed model on the GPU: fixed-shape decode steps, replayed from a HIP graph
+            static_decode = ids.is_cuda and os.environ.get("FF_STATIC_DECODE", "1") == "1"
+        if static_decode and not do_sample and isinstance(self.flamingo, FlamingoGPT2) and ids.shape[1] + 1 < max_length:
+            return self._static_greedy(ids, ml, am, pixel_values, visual_features, max_length, eos_token_id, pad)
         finished = torch.zeros(ids.shape[0], dtype=torch.bool, device=ids.device)
         past, step_ids = None, ids
         while ids.shape[1] < max_length:
@@ -368,6 +463,27 @@ class FlamingoModel(PreTrainedModel):
             if eos_token_id is not None and bool(finished.all()):
                 break
         return ids
+
+    def _static_greedy(self, ids, ml, am, pixel_values, visual_features, max_length, eos, pad, graph: Optional[bool] = None):
+        """Greedy decoding with FIXED shapes (see _DecodeSession).  Sessions - preallocated caches and buffers plus, on the GPU, the captured
+        HIP graph of one decode step - are kept per (batch, max_length, keys per sequence, eos / pad) and reused by later calls, so only the
+        first caption batch of a shape pays for the capture.  reset_decode_sessions() drops them (needed only if parameters are re-allocated)."""
+        b = ids.shape[0]
+        if graph is None:
+            graph = ids.is_cuda and not self.training and os.environ.get("FF_DECODE_GRAPH", "1") == "1"
+        sessions = self.__dict__.setdefault("_decode_sessions", {})
+        n_media = int(ml.sum(-1).max()) if visual_features is None and pixel_values is None else \
+            (visual_features.shape[1] if visual_features is not None else (pixel_values.shape[1] if pixel_values.ndim >= 5 else pixel_values.shape[0]))
+        key = (b, max_length, n_media, str(ids.device), eos, pad, bool(graph))
+        sess = sessions.get(key)
+        if sess is None:
+            if len(sessions) >= 4:                                            # a handful of shapes at most: each holds a KV cache and a graph
+                sessions.pop(next(iter(sessions)))
+            sess = sessions[key] = _DecodeSession(self, b, max_length, ids.device, ids.dtype, am.dtype, eos, pad, graph)
+        return sess.run(ids, ml, am, pixel_values, visual_features)
+
+    def reset_decode_sessions(self) -> None:
+        self.__dict__.pop("_decode_sessions", None)
 
     def _beam_search(self, ids, ml, am, pixel_values, visual_features, max_length, nb, eos, pad, early_stopping, length_penalty):
         """Standard beam search over the cached decode path.  The prompt runs once per sequence; its caches are then replicated per beam

@@ -171,7 +171,10 @@ def test_greedy_generate_cached_equals_uncached(family):
     px = torch.from_numpy(z["px"]).float().cuda()
     ids, ml = torch.from_numpy(z["ids"]).cuda()[:, :4], torch.from_numpy(z["ml"]).cuda()[:, :4]
     am = torch.ones_like(ids)
-    gen = model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9)
+    gen = model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9)      # gpt2: fixed-shape steps replayed from a HIP graph
+    if family == "gpt2":
+        assert torch.equal(model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9), gen)      # the session (and its graph) reused
+        assert torch.equal(model.generate(ids, media_locations=ml, attention_mask=am, pixel_values=px, max_length=9, static_decode=False), gen)
     cur, cml, cam = ids, ml, am
     for _ in range(5):     # uncached reference loop
         with torch.no_grad():
@@ -198,6 +201,16 @@ def test_generation_strategies_cpu_with_oracle_checker(family):
         greedy = model.generate(ids, **kw)
         assert greedy.shape == (2, 9) and torch.equal(greedy, model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9))
         assert torch.equal(model.generate(ids, do_sample=True, top_k=1, **kw), greedy)          # top-1 sampling is greedy
+        if family == "gpt2":        # the fixed-shape decode path (StaticCache, device-side positions; HIP-graph replay on the GPU) gives the same tokens
+            assert torch.equal(model.generate(ids, static_decode=True, **kw), greedy)
+            ids2 = (ids + 7) % 90                                             # another prompt through the SAME session: everything is reset
+            assert len(model._decode_sessions) == 1
+            assert torch.equal(model.generate(ids2, static_decode=True, **kw), model.generate(ids2, static_decode=False, **kw))
+            assert len(model._decode_sessions) == 1
+            for eos in {int(greedy[0, 5]), int(greedy[1, 7]), int(greedy[0, 8])}:     # early stop: same tokens, same trimmed length
+                want = model.generate(ids, eos_token_id=eos, pad_token_id=0, static_decode=False, **kw)
+                got = model.generate(ids, eos_token_id=eos, pad_token_id=0, static_decode=True, **kw)
+                assert got.shape == want.shape and torch.equal(got, want), (eos, got, want)
         g = torch.Generator().manual_seed(3)
         s1 = model.generate(ids, do_sample=True, temperature=0.7, top_p=0.9, generator=g, **kw)
         g = torch.Generator().manual_seed(3)

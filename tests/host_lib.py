@@ -118,7 +118,13 @@ class HostLib:
                 (d.dim, ffi_)]
 
     def ff_xattn_saved_bytes(self, d):
-        return 64
+        # the library's layout starts with K / V as (b, n_kv, 2, heads, dim_head) when the block projects them itself: functional._kv_views
+        # hands views of that region to the caller (output_kv=True), so the stand-in keeps the same contract
+        own_kv = d.cached_k.sr == 0
+        return 64 + (d.batch * d.n_media * d.n_visual * 2 * d.heads * d.dim_head * 4 if own_kv else 0)
+
+    def ff_xattn_kv_offset(self, d):
+        return 0
 
     def ff_xattn_scratch_bytes(self, d):
         return 64
@@ -129,23 +135,63 @@ class HostLib:
     def ff_xattn_wgrad_workspace_bytes(self, d):
         return 64
 
+    @staticmethod
+    def _strided(ptr, d, st):
+        """(b, heads, n_kv, dim_head) float32 view of externally held K or V: element strides (batch, row, head) from the descriptor."""
+        n_kv = d.n_media * d.n_visual
+        span = (d.batch - 1) * st.sb + (n_kv - 1) * st.sr + (d.heads - 1) * st.sh + d.dim_head
+        base = _view(ptr, (span,))
+        return np.lib.stride_tricks.as_strided(base, shape=(d.batch, d.heads, n_kv, d.dim_head),
+                                               strides=(st.sb * 4, st.sh * 4, st.sr * 4, 4), writeable=False)
+
     def ff_xattn_block_fwd(self, d, y, vf, tt, params, ck, cv, out, saved, saved_n, scratch, scratch_n, stream):
+        """Three layouts, as in the library: vf given (the block projects K / V itself and keeps them at the start of `saved`), K / V
+        projected outside during training (ck = the layer's (b, n_kv, 2 inner) tensor: full sequence), cached decode (ck / cv with arbitrary
+        (b, h, n, d) strides, the LAST n_tokens rows of text_time)."""
         self._f32(d)
-        assert vf is None and ck, "the host stand-in serves the training layout only: K / V projected outside the block"
-        self.calls.append("ff_xattn_block_fwd")
         inner = d.heads * d.dim_head
         n_kv = d.n_media * d.n_visual
         shapes = self._xa_shapes(d)
         p = {k: (None if q is None else _view(q, s).astype(np.float64)) for k, q, s in zip(XA_KEYS, _ptrs(params, len(shapes)), shapes)}
-        p["attn.to_kv.weight"] = np.eye(2 * inner)                    # the oracle projects K / V itself: identity on the projected tensor
-        kv = _view(ck, (d.batch, d.n_media, d.n_visual, 2 * inner)).astype(np.float64)
         ttv = _view(tt, (d.batch, d.tt_stride), np.int32).astype(np.int64)
-        ml = np.diff(ttv, axis=1, prepend=0)[:, d.tt_offset:d.tt_offset + d.n_tokens]
-        assert d.tt_offset == 0 and d.tt_stride == d.n_tokens, "training layout: the block sees the whole sequence"
+        ml_full = np.diff(ttv, axis=1, prepend=0)
         yv = _view(y, (d.batch, d.n_tokens, d.dim)).astype(np.float64)
-        o, _, cache = O.gated_xattn_block_fwd(yv, kv, ml, p, heads=d.heads, dim_head=d.dim_head, act=_ACT[d.act], n_visual=d.n_visual)
+        kw = dict(heads=d.heads, dim_head=d.dim_head, act=_ACT[d.act], n_visual=d.n_visual)
+        if vf is not None:                                              # per-layer projection (hoist_kv = False)
+            self.calls.append("ff_xattn_block_fwd[own kv]")
+            assert d.tt_offset == 0 and d.tt_stride == d.n_tokens
+            vfv = _view(vf, (d.batch, d.n_media, d.n_visual, d.dim_visual)).astype(np.float64)
+            o, (k, v), cache = O.gated_xattn_block_fwd(yv, vfv, ml_full, p, **kw)
+            kvbuf = _view(saved, (d.batch, n_kv, 2, d.heads, d.dim_head))
+            kvbuf[:, :, 0] = k.transpose(0, 2, 1, 3)
+            kvbuf[:, :, 1] = v.transpose(0, 2, 1, 3)
+            self.cache[int(saved)] = (cache, p, n_kv)
+        elif d.tt_offset == 0 and d.tt_stride == d.n_tokens and int(cv) - int(ck) == inner * 4 and d.cached_k.sr == 2 * inner:
+            self.calls.append("ff_xattn_block_fwd")                    # training layout: K / V of this layer projected outside the block
+            p["attn.to_kv.weight"] = np.eye(2 * inner)                  # the oracle projects K / V itself: identity on the projected tensor
+            kv = _view(ck, (d.batch, d.n_media, d.n_visual, 2 * inner)).astype(np.float64)
+            o, _, cache = O.gated_xattn_block_fwd(yv, kv, ml_full, p, **kw)
+            self.cache[int(saved)] = (cache, p, n_kv)
+        else:                                                           # cached decode: inference only
+            self.calls.append("ff_xattn_block_fwd[cached]")
+            k = self._strided(ck, d, d.cached_k).astype(np.float64)
+            v = self._strided(cv, d, d.cached_v).astype(np.float64)
+            assert d.tt_offset + d.n_tokens == d.tt_stride, "cached decode reads the last n_tokens entries of text_time"
+            o, _, _ = O.gated_xattn_block_fwd(yv, None, ml_full, p, previous_kv=(k, v), **kw)
         _view(out, o.shape)[...] = o
-        self.cache[int(saved)] = (cache, p, n_kv)
+        return 0
+
+    def ff_xattn_block_bwd(self, d, y, vf, tt, params, dy_out, saved, saved_n, grads, dy, dvf, scratch, scratch_n, stream):
+        self.calls.append("ff_xattn_block_bwd")
+        cache, p, n_kv = self.cache.pop(int(saved))
+        g_out = _view(dy_out, (d.batch, d.n_tokens, d.dim)).astype(np.float64)
+        dyv, dvfv, g = O.gated_xattn_block_bwd(g_out, cache, p, heads=d.heads, dim_head=d.dim_head, act=_ACT[d.act])
+        _view(dy, dyv.shape)[...] = dyv
+        if dvf:
+            _view(dvf, dvfv.shape)[...] = dvfv
+        shapes = self._xa_shapes(d)
+        for k, q, s in zip(XA_KEYS, _ptrs(grads, len(shapes)), shapes):
+            _view(q, s)[...] = np.asarray(g[k]).reshape(s)
         return 0
 
     def _xa_backward(self, d, dy_out, saved):

@@ -95,6 +95,40 @@ def test_product_autograd_on_the_host_library_matches_the_oracle_model(clean_pat
         assert _close(v, 2.0 * want[k], 2e-4), k
 
 
+def test_per_layer_projection_and_cached_decoding_on_the_host_library(clean_patches):
+    """hoist_kv = False (the block projects K / V itself and returns views of the library's saved buffer) and the cached decode call with
+    strided K / V and the tail of text_time - through the real functional.py; generation both with the growing cache and with the
+    fixed-shape decode session."""
+    ref, z, _ = _model("oracle")
+    ref.flamingo.hoist_kv = False
+    ref.zero_grad(set_to_none=True)
+    _loss(ref, z, [0, 1], torch.float64).backward()
+    want = _grads(ref)
+    ref.eval()
+    px64 = torch.from_numpy(z["px"]).double()
+    ids, ml = torch.from_numpy(z["ids"])[:, :4], torch.from_numpy(z["ml"])[:, :4]
+    kw = dict(media_locations=ml, attention_mask=torch.ones_like(ids), max_length=9)
+    want_tokens = ref.generate(ids, pixel_values=px64, **kw)
+
+    model, z, host = _model("host")
+    model.flamingo.hoist_kv = False
+    model.zero_grad(set_to_none=True)
+    _loss(model, z, [0, 1], torch.float32).backward()
+    assert "ff_xattn_block_bwd" in host.calls and not any(c.startswith("ff_kv_project") for c in host.calls)
+    for k, v in _grads(model).items():
+        assert _close(v, want[k], 2e-4), k
+    model.eval()
+    px32 = torch.from_numpy(z["px"]).float()
+    host.calls.clear()
+    got = model.generate(ids, pixel_values=px32, static_decode=False, **kw)
+    assert torch.equal(got, want_tokens)
+    n_hooks = len(model.flamingo.get_modified_layers())
+    assert host.calls.count("ff_xattn_block_fwd[cached]") == n_hooks * 4          # 5 new tokens: the prompt step + 4 cached steps
+    assert torch.equal(model.generate(ids, pixel_values=px32, static_decode=True, **kw), want_tokens)
+    model.flamingo.hoist_kv = True                                                 # K / V views of the hoisted projection feed the same cached path
+    assert torch.equal(model.generate(ids, pixel_values=px32, static_decode=False, **kw), want_tokens)
+
+
 def _worker(rank, world, port, out_dir, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -44,9 +44,24 @@ def _bucket_is_ours(owners, ids) -> bool:
     return False
 
 
+class _StreamWork:
+    """`work.wait()` of a collective that was issued synchronously on the side stream: the current stream waits for the recorded event."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+
+
 class GradientAllReducer:
-    def __init__(self, model: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False):
-        """force_collectives: issue the collectives even in a 1-rank group (exercises the RCCL path on a single GPU)."""
+    def __init__(self, model: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False,
+                 reduce_dtype: Optional[torch.dtype] = None):
+        """force_collectives: issue the collectives even in a 1-rank group (exercises the RCCL path on a single GPU).
+        reduce_dtype=torch.float32: bf16 buckets are widened to fp32 for the exchange (the sum over the ranks is accumulated in fp32 and
+        rounded to bf16 once, at twice the bytes on the links); None = exchange in the gradients' own dtype (ReduceOp.AVG on bf16)."""
+        self.reduce_dtype = reduce_dtype
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
@@ -102,7 +117,26 @@ class GradientAllReducer:
         self._reduce_async(flat, list(owners))
 
     def _reduce_async(self, flat: torch.Tensor, owners):
-        if self.cuda:
+        widen = self.reduce_dtype is not None and flat.dtype != self.reduce_dtype
+        if widen and self.cuda:
+            ready = torch.cuda.Event()
+            ready.record()
+            if not torch.cuda.is_current_stream_capturing():
+                flat.record_stream(self.stream)
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                wide = flat.to(self.reduce_dtype)
+                dist.all_reduce(wide, op=dist.ReduceOp.AVG, group=self.group)        # enqueued on the side stream, which then waits for it
+                flat.copy_(wide)
+                done = torch.cuda.Event()
+                done.record()
+            self.pending.append((flat, _StreamWork(done), False, owners))
+        elif widen:
+            wide = flat.to(self.reduce_dtype)
+            dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=self.group)
+            flat.copy_(wide.div_(self.world))
+            self.pending.append((flat, _StreamWork(None), False, owners))
+        elif self.cuda:
             ready = torch.cuda.Event()
             ready.record()                                   # after the kernels producing `flat` on the compute stream
             if not torch.cuda.is_current_stream_capturing():
@@ -139,7 +173,7 @@ class GradientAllReducer:
         self._early.clear()
 
 
-class ShardedAdamW:
+class ShardedAdamW(torch.optim.Optimizer):
     """Data-parallel AdamW with the optimizer state sharded over the ranks (reduce-scatter -> sharded update ->
     all-gather), pipelined per gradient bucket on the side stream while backward continues.
 
@@ -149,15 +183,23 @@ class ShardedAdamW:
     bucket's gradients are final:   reduce_scatter(AVG) -> ff_adamw_step on the rank's slice -> all_gather of the updated
     parameters - all on the reducer's stream, so communication AND the update overlap with the backward of the layers below
     (nothing that is still to run in this step reads those weights).  Un-fused parameters (the token embedding) are all-reduced
-    and updated replicated, as in GradientAllReducer + FusedAdamW.  Call `finish_step()` after backward() - it replaces
+    and updated replicated, as in GradientAllReducer + FusedAdamW.  Call `step()` (= `finish_step()`) after backward() - it replaces
     `reducer.finish(); optimizer.step()`.
+
+    It is a torch.optim.Optimizer: `param_groups[0]["lr"]` is the learning rate the next backward's updates use, so torch / HF LR
+    schedulers attach as usual (the reference trains with constant_with_warmup); `state_dict()` / `load_state_dict()` save and restore
+    THIS RANK's shards (every rank saves its own file; world size and rank must match on load).  Gradient accumulation: every
+    micro-batch but the last under `no_sync()`; the last backward then finds accumulated `.grad`s and the bucket's pipeline runs in
+    `step()` on the accumulated values.  A second backward without no_sync() after a bucket was already updated in this step raises.
+    `capturable=True` keeps the step count and the learning rate in device scalars (graphs.GraphedTrainStep replays the step).
 
     xGMI arithmetic (8 GPUs, 7 links x ~153 GB/s each): reduce-scatter + all-gather move 2 * (S / 8) per link pair instead of a
     ring's 2 * (7/8) * S over one link, and the update touches 1/8 of the state per rank.
     """
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 master_dtype=None, process_group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False, update_fn=None):
+                 master_dtype=None, process_group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False, update_fn=None,
+                 capturable: bool = False):
         from .optim import FusedAdamW
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -165,49 +207,98 @@ class ShardedAdamW:
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self.cuda = self.backend == "nccl"
         self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
-        self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.master_dtype = master_dtype
+        self.capturable = capturable
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.step_count = 0
-        self.buckets = {}            # position of the bucket in the backward pass -> state
+        self.buckets = {}            # ids of the bucket's parameters -> state (independent of the order the buckets arrive in)
         self._work: List = []
+        self._late: List = []        # buckets whose gradients are being accumulated: their pipeline runs in step()
+        self._updated = set()        # buckets already updated in the running step
+        self._sync = True
+        self._loaded = None          # a state_dict loaded before the buckets exist: applied as they are created
+        self._dev_scalars = {}       # capturable: device -> (step counter, learning rate)
         self._update_fn = update_fn or self._hip_update
+        self._model = model
+        self._names = {id(p): n for n, p in model.named_parameters()}
         fused = {id(p) for m in model.modules() if hasattr(m, "fused_params") for p in m.fused_params()}
         self._fused_ids = fused
-        self._arrival = 0                                           # buckets are identified by their position in the backward pass
+        self._arrival = 0                                           # buckets seen so far in the running backward pass
         self.loose = [p for p in model.parameters() if p.requires_grad and id(p) not in fused]
-        self._loose_work: List = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_loose) for p in self.loose]
-        self._loose_opt = FusedAdamW(self.loose, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, master_dtype=master_dtype) if update_fn is None else None
+        trainable = [p for p in model.parameters() if p.requires_grad]
+        super().__init__(trainable, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._loose_opt = FusedAdamW(self.loose, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, master_dtype=master_dtype,
+                                     capturable=capturable) if update_fn is None else None
         self._loose_update_fn = update_fn
         self._loose_state = {}
         if self.collectives:
             _split_kv_buckets(model)
         F.add_grad_ready_callback(self._on_bucket)
 
+    @property
+    def hp(self):
+        return self.param_groups[0]
+
     def close(self):
         F.remove_grad_ready_callback(self._on_bucket)
         for h in self._hooks:
             h.remove()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Micro-batches whose gradients are only accumulated locally (every one but the last of an optimizer step)."""
+        self._sync = False
+        try:
+            yield
+        finally:
+            self._sync = True
+
+    def set_lr(self, lr: float) -> None:
+        for g in self.param_groups:
+            g["lr"] = lr
+        self.sync_device_hyperparams()
+
+    def sync_device_hyperparams(self) -> None:
+        """capturable mode: copy the host learning rate into the device scalars the captured kernels read (before a graph replay)."""
+        for dev, (_, lr_dev, seen) in self._dev_scalars.items():
+            if seen[0] != self.hp["lr"]:
+                lr_dev.fill_(float(self.hp["lr"]))
+                seen[0] = self.hp["lr"]
+        if self._loose_opt is not None:
+            for g in self._loose_opt.param_groups:
+                g["lr"] = self.hp["lr"]
+            self._loose_opt.sync_device_hyperparams()
+
+    def _scalars(self, device):
+        sc = self._dev_scalars.get(device)
+        if sc is None:
+            sc = self._dev_scalars[device] = (torch.full((), float(self.step_count), dtype=torch.float32, device=device),
+                                              torch.full((), float(self.hp["lr"]), dtype=torch.float32, device=device), [self.hp["lr"]])
+        return sc
 
     # ---- the kernel call (tests substitute a torch implementation through update_fn on CPU ranks) ----
     def _hip_update(self, p, g, m, v, master, step):
         from . import ffi
         import ctypes as C
         lib = ffi.lib()
+        step_dev = lr_dev = None
+        if self.capturable:
+            sc = self._scalars(p.device)
+            step, step_dev, lr_dev = 0, sc[0].data_ptr(), sc[1].data_ptr()
         desc = ffi.AdamWDesc(ffi.dtype_code(p.dtype), 1, step, self.hp["lr"], self.hp["betas"][0], self.hp["betas"][1], self.hp["eps"],
-                             self.hp["weight_decay"], 1.0, None)
+                             self.hp["weight_decay"], 1.0, step_dev)
         one = lambda t: ffi.ptr_array([t])
         ffi.check(lib.ff_adamw_step_mixed(desc, ffi.dtype_code(m.dtype), one(p), one(g), one(m), one(v), None if master is None else one(master),
-                                          None, (C.c_longlong * 1)(p.numel()), ffi.stream_handle(p.device)), "ff_adamw_step_mixed")
+                                          lr_dev, (C.c_longlong * 1)(p.numel()), ffi.stream_handle(p.device)), "ff_adamw_step_mixed")
+
+    def _bucket_name(self, owners) -> str:
+        return self._names.get(id(owners[0][0]), f"bucket{len(self.buckets)}")
 
     def _bucket_state(self, flat, owners):
-        key = self._arrival                      # the order of the buckets within a backward pass is the same every step (static graph)
+        key = tuple(id(p) for p, _, _ in owners)
         self._arrival += 1
-        sig = (flat.numel(), tuple((off, cnt) for _, off, cnt in owners))
         st = self.buckets.get(key)
-        if st is not None and st["sig"] != sig:
-            raise RuntimeError("ShardedAdamW: the gradient buckets of this backward pass do not arrive in the order of the first one")
         if st is None:
             n = flat.numel()
             assert n % self.world == 0, "flat gradient buffers are padded to a multiple of 1024 elements (functional._flat_offsets)"
@@ -217,34 +308,55 @@ class ShardedAdamW:
                 for p, off, cnt in owners:       # parameters move into the flat buffer; the modules keep seeing them under their own names
                     pflat[off:off + cnt].copy_(p.detach().reshape(-1))
                     p.data = pflat[off:off + cnt].view(p.shape)
+            for m in self._model.modules():      # a captured decode graph still reads the old parameter storage
+                if hasattr(m, "reset_decode_sessions"):
+                    m.reset_decode_sessions()
             lo = self.rank * shard
             sdt = torch.float32 if (self.master_dtype is not None and flat.dtype == torch.bfloat16) else flat.dtype
-            st = dict(sig=sig, params=[p for p, _, _ in owners], pflat=pflat, shard=shard, lo=lo, m=torch.zeros(shard, dtype=sdt, device=flat.device), v=torch.zeros(shard, dtype=sdt, device=flat.device),
+            st = dict(name=self._bucket_name(owners), owners=[(p, off, cnt) for p, off, cnt in owners], params=[p for p, _, _ in owners], pflat=pflat,
+                      shard=shard, lo=lo, m=torch.zeros(shard, dtype=sdt, device=flat.device), v=torch.zeros(shard, dtype=sdt, device=flat.device),
                       master=pflat[lo:lo + shard].to(torch.float32) if sdt != flat.dtype else None, gshard=torch.empty(shard, dtype=flat.dtype, device=flat.device))
+            if self._loaded is not None and st["name"] in self._loaded:
+                self._restore_bucket(st, self._loaded.pop(st["name"]))
             self.buckets[key] = st
         return st
+
+    def _pipeline(self, st, flat):
+        """reduce-scatter -> update of this rank's slice -> all-gather, on the current stream."""
+        lo, shard = st["lo"], st["shard"]
+        if self.collectives:
+            if self.cuda:
+                dist.reduce_scatter_tensor(st["gshard"], flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:       # gloo has no reduce-scatter: all-reduce and keep this rank's slice
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                st["gshard"].copy_(flat[lo:lo + shard]).div_(self.world)
+            g = st["gshard"]
+        else:
+            g = flat[lo:lo + shard]
+        self._update_fn(st["pflat"][lo:lo + shard], g, st["m"], st["v"], st["master"], self.step_count + 1)
+        if self.collectives:
+            dist.all_gather_into_tensor(st["pflat"], st["pflat"][lo:lo + shard].clone() if not self.cuda else st["pflat"][lo:lo + shard], group=self.group)
 
     def _on_bucket(self, flat: torch.Tensor, owners=()):
         if not owners or not _bucket_is_ours(owners, self._fused_ids):
             return
+        first = self._arrival == 0
         st = self._bucket_state(flat, owners)
-        step = self.step_count + 1
-        lo, shard = st["lo"], st["shard"]
-
-        def pipeline():
-            if self.collectives:
-                if self.cuda:
-                    dist.reduce_scatter_tensor(st["gshard"], flat, op=dist.ReduceOp.AVG, group=self.group)
-                else:       # gloo has no reduce-scatter: all-reduce and keep this rank's slice
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                    st["gshard"].copy_(flat[lo:lo + shard]).div_(self.world)
-                g = st["gshard"]
-            else:
-                g = flat[lo:lo + shard]
-            self._update_fn(st["pflat"][lo:lo + shard], g, st["m"], st["v"], st["master"], step)
-            if self.collectives:
-                dist.all_gather_into_tensor(st["pflat"], st["pflat"][lo:lo + shard].clone() if not self.cuda else st["pflat"][lo:lo + shard], group=self.group)
-
+        key = tuple(id(p) for p in st["params"])
+        es = flat.element_size()
+        accumulating = any(p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + off * es for p, off, _ in owners)
+        if key in self._updated:
+            raise RuntimeError("ShardedAdamW: a fused module ran backward twice in one step after its parameters were already updated; "
+                               "wrap all but the last micro-batch in ShardedAdamW.no_sync()")
+        if not self._sync:
+            return                               # autograd accumulates into .grad; nothing is exchanged or updated
+        if accumulating:                         # the gradient of this step is .grad AFTER autograd has added `flat` to it: see step()
+            if st not in self._late:
+                self._late.append(st)
+            return
+        if self.capturable and first and flat.is_cuda:
+            self._scalars(flat.device)[0].add_(1.0)       # the step counter the captured updates read, advanced on the device
+        self._updated.add(key)
         if self.cuda:
             ready = torch.cuda.Event()
             ready.record()
@@ -252,15 +364,15 @@ class ShardedAdamW:
                 flat.record_stream(self.stream)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
-                pipeline()
+                self._pipeline(st, flat)
                 done = torch.cuda.Event()
                 done.record()
             self._work.append(done)
         else:
-            pipeline()
+            self._pipeline(st, flat)
 
     def _on_loose(self, p: torch.Tensor):
-        if self.collectives:
+        if self.collectives and self._sync:
             if self.cuda:
                 dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, group=self.group)
             else:
@@ -268,13 +380,27 @@ class ShardedAdamW:
                 p.grad.div_(self.world)
 
     def finish_step(self):
-        """After backward(): wait for the per-bucket pipelines, update the un-fused parameters, advance the step count."""
+        """After backward(): wait for the per-bucket pipelines, run the pipelines of buckets whose gradients were accumulated over several
+        micro-batches, update the un-fused parameters, advance the step count."""
         for ev in self._work:
             torch.cuda.current_stream().wait_event(ev)
         self._work.clear()
+        for st in self._late:                    # accumulated gradients: gather .grad into the bucket layout, then the same pipeline
+            flat = torch.zeros_like(st["pflat"])
+            for p, off, cnt in st["owners"]:
+                if p.grad is not None:
+                    flat[off:off + cnt].copy_(p.grad.reshape(-1))
+            if self.capturable and not self._updated and flat.is_cuda:
+                self._scalars(flat.device)[0].add_(1.0)
+            self._updated.add(tuple(id(p) for p in st["params"]))
+            self._pipeline(st, flat)
+        self._late.clear()
+        self._updated.clear()
         self._arrival = 0
         self.step_count += 1
         if self._loose_opt is not None:
+            for g in self._loose_opt.param_groups:
+                g["lr"] = self.hp["lr"]
             self._loose_opt.step()
         else:
             for p in self.loose:
@@ -283,6 +409,15 @@ class ShardedAdamW:
                 s = self._loose_state.setdefault(id(p), dict(m=torch.zeros_like(p), v=torch.zeros_like(p)))
                 self._loose_update_fn(p.data.view(-1), p.grad.view(-1), s["m"].view(-1), s["v"].view(-1), None, self.step_count)
 
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.finish_step()
+        return loss
+
     def zero_grad(self, set_to_none: bool = True):
         """Gradients are re-created by every backward (flat buffers), so they are simply dropped."""
         for st in self.buckets.values():
@@ -290,3 +425,50 @@ class ShardedAdamW:
                 p.grad = None
         for p in self.loose:
             p.grad = None
+
+    # ---- checkpointing: this rank's shards --------------------------------------------------------------------------------
+    def state_dict(self):
+        """This rank's optimizer state: per bucket (named after its first parameter) the moment shards and, in mixed precision, the
+        fp32 master shard; plus the replicated state of the un-fused parameters.  Every rank saves its own."""
+        if self.capturable:
+            for sc in self._dev_scalars.values():
+                self.step_count = max(self.step_count, int(float(sc[0])))
+        buckets = {st["name"]: dict(lo=st["lo"], shard=st["shard"], exp_avg=st["m"], exp_avg_sq=st["v"], master=st["master"])
+                   for st in self.buckets.values()}
+        loose = self._loose_opt.state_dict() if self._loose_opt is not None else \
+            {self._names.get(i, str(i)): dict(exp_avg=s["m"], exp_avg_sq=s["v"]) for i, s in self._loose_state.items()}
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        return dict(step=self.step_count, world=self.world, rank=self.rank, buckets=buckets, loose=loose, param_groups=groups)
+
+    def _restore_bucket(self, st, src):
+        if src["lo"] != st["lo"] or src["shard"] != st["shard"]:
+            raise RuntimeError(f"ShardedAdamW.load_state_dict: bucket {st['name']} was saved with another sharding")
+        st["m"].copy_(src["exp_avg"])
+        st["v"].copy_(src["exp_avg_sq"])
+        if st["master"] is not None:
+            if src.get("master") is not None:
+                st["master"].copy_(src["master"])
+            else:
+                st["master"].copy_(st["pflat"][st["lo"]:st["lo"] + st["shard"]])
+
+    def load_state_dict(self, state):
+        if state["world"] != self.world or state["rank"] != self.rank:
+            raise RuntimeError(f"ShardedAdamW.load_state_dict: saved by rank {state['rank']} of {state['world']}, this is rank {self.rank} of {self.world}")
+        self.step_count = int(state["step"])
+        for g, src in zip(self.param_groups, state.get("param_groups", [])):
+            g.update({k: v for k, v in src.items() if k != "params"})
+        pending = dict(state["buckets"])
+        for st in self.buckets.values():
+            if st["name"] in pending:
+                self._restore_bucket(st, pending.pop(st["name"]))
+        self._loaded = pending                   # buckets are created by the first backward: their state is applied then
+        if self._loose_opt is not None:
+            self._loose_opt.load_state_dict(state["loose"])
+        else:
+            by_name = {n: i for i, n in self._names.items()}
+            for n, s in state["loose"].items():
+                if n in by_name:
+                    self._loose_state[by_name[n]] = dict(m=s["exp_avg"].clone(), v=s["exp_avg_sq"].clone())
+        for sc in self._dev_scalars.values():
+            sc[0].fill_(float(self.step_count))
+        self.sync_device_hyperparams()

@@ -51,42 +51,84 @@ class _WgradQueue:
     The queue keeps raw addresses, never the gradient tensors themselves: AccumulateGrad adopts an incoming gradient without a copy
     only while nobody else references it (otherwise it clones - at that moment, i.e. before the flush has filled it).  The final
     callback verifies that adoption really happened for every deferred gradient and repairs the ones autograd copied after all.
-    FF_DEFER_WGRAD=0 disables the deferral."""
+    The queue's state belongs to ONE backward pass (the autograd engine's graph task, torch._C._current_graph_task_id()): the engine
+    does not run queue_callback callbacks of a pass that raised (OOM, a bad label, an exception in a hook), so whatever such a pass
+    left behind - raw gradient addresses of flat buffers that are gone by now - must never be run or grouped with fresh entries.
+    State is therefore kept per graph task, and the leftovers of dead passes are dropped by the next forward that runs outside any
+    backward (forget_dead_passes).  A block whose parameters take part TWICE in one pass (module reuse, activation-checkpoint
+    recompute) must not defer the second time: the engine sums the two contributions the moment the second one is returned, so the
+    first is completed on the spot and the second runs the plain, non-deferred backward (seen_in_this_pass).
+    `enabled = False` (or FF_DEFER_WGRAD=0 in the environment at import) disables the deferral."""
+
+    class _Pass:
+        def __init__(self):
+            self.pending: list = []
+            self.done: list = []
+            self.deferred_ids: set = set()   # parameters with a deferred gradient in this pass
+            self.summed_ids: set = set()     # ... that received a second contribution: autograd holds their SUM, nothing to repair
 
     def __init__(self):
         import os
         self.enabled = os.environ.get("FF_DEFER_WGRAD", "1") == "1"
-        self.pending: list = []
-        self.done: list = []
-        self._callback_armed = False
+        self._passes: dict = {}              # graph-task id -> _Pass
+
+    @property
+    def pending(self) -> list:
+        return [e for st in self._passes.values() for e in st.pending]
+
+    def forget_dead_passes(self) -> None:
+        """Called from a forward: outside any backward pass, whatever the queue still holds belongs to passes that raised."""
+        if self._passes and torch._C._current_graph_task_id() < 0:
+            self._passes.clear()
+
+    def seen_in_this_pass(self, params) -> bool:
+        """True if one of `params` already has a deferred gradient in the running pass (the caller must then not defer again)."""
+        st = self._passes.get(torch._C._current_graph_task_id())
+        if st is None:
+            return False
+        hit = [id(p) for p in params if id(p) in st.deferred_ids]
+        if hit:
+            st.summed_ids.update(hit)
+            self._flush_pending(st)          # the first contribution must be complete before autograd adds the second one to it
+        return bool(hit)
 
     def push(self, entry) -> None:
-        self.pending.append(entry)
-        if not self._callback_armed:
-            self._callback_armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
-        same = [e for e in self.pending if e["key"] == entry["key"]]
+        task = torch._C._current_graph_task_id()
+        st = self._passes.get(task)
+        if st is None:
+            st = self._passes[task] = self._Pass()
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: self.flush(task))
+        st.pending.append(entry)
+        st.deferred_ids.update(id(p) for p in entry["wparams"])
+        same = [e for e in st.pending if e["key"] == entry["key"]]
         if len(same) >= ffi.WGRAD_GROUP_MAX:
-            self._run(same)
+            self._run(st, same)
 
-    def flush(self) -> None:
-        self._callback_armed = False
-        while self.pending:
-            key = self.pending[0]["key"]
-            self._run([e for e in self.pending if e["key"] == key][: ffi.WGRAD_GROUP_MAX])
-        done, self.done = self.done, []
-        for e in done:      # every AccumulateGrad of this backward pass has run by now
-            for p, (off, n) in zip(e["wparams"], e["wslices"]):
-                filled = e["flat"][off:off + n].view(p.shape)
-                if p.grad is None:
-                    continue                                 # retain_graph / autograd.grad without accumulation: nothing to repair
-                if p.grad.data_ptr() != filled.data_ptr():   # autograd cloned the (then unfilled) tensor instead of adopting it
-                    p.grad.copy_(filled)
+    def _flush_pending(self, st) -> None:
+        while st.pending:
+            key = st.pending[0]["key"]
+            self._run(st, [e for e in st.pending if e["key"] == key][: ffi.WGRAD_GROUP_MAX])
 
-    def _run(self, group) -> None:
+    def flush(self, task) -> None:
+        st = self._passes.get(task)
+        if st is None:
+            return
+        try:
+            self._flush_pending(st)
+            for e in st.done:        # every AccumulateGrad of this backward pass has run by now
+                for p, (off, n) in zip(e["wparams"], e["wslices"]):
+                    if p.grad is None or id(p) in st.summed_ids:
+                        continue                                 # retain_graph / autograd.grad without accumulation; or a sum of two uses
+                    filled = e["flat"][off:off + n].view(p.shape)
+                    if p.grad.data_ptr() != filled.data_ptr():   # autograd cloned the (then unfilled) tensor instead of adopting it
+                        p.grad.copy_(filled)
+        finally:
+            self._passes.pop(task, None)
+
+    def _run(self, st, group) -> None:
         lib = ffi.lib()
         ids = {id(e) for e in group}
-        self.pending = [e for e in self.pending if id(e) not in ids]
+        st.pending = [e for e in st.pending if id(e) not in ids]
         e0 = group[0]
         desc, dev = e0["desc"], e0["device"]
         ws = _empty_bytes(lib.ff_xattn_wgrad_workspace_bytes(desc), dev)
@@ -102,7 +144,7 @@ class _WgradQueue:
                   "ff_xattn_wgrad_grouped")
         for e in group:
             _announce(e["flat"], e["own"])
-        self.done.extend(group)
+        st.done.extend(group)
 
 
 _wgrad_queue = _WgradQueue()
@@ -320,6 +362,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, kv, tt, cfg, n_visual, *params):
         lib = ffi.lib()
+        _wgrad_queue.forget_dead_passes()
         y, kv = y.contiguous(), kv.contiguous()
         params = tuple(p.contiguous() for p in params)
         desc, inner = _XattnBlockKvFn._desc(y, kv, n_visual, params[_KV_PARAM].shape[1], cfg, tt)
@@ -347,7 +390,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
         dy, dkv = torch.empty_like(y), torch.empty_like(kv)
         scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
         aligned = all(t.data_ptr() % 16 == 0 for t in (y, dout, params[2], params[7]))     # the deferred entry point requires it
-        if _wgrad_queue.enabled and aligned and all(p.grad is None for p in own):
+        if _wgrad_queue.enabled and aligned and all(p.grad is None for p in own) and not _wgrad_queue.seen_in_this_pass(own):
             # data gradients now; d ffw.3 / d ffw.1 / d to_out / d to_q (and the final reductions of the LayerNorm / gate gradients)
             # later, grouped with the neighbouring layers' (see _WgradQueue)
             stash = _empty_bytes(lib.ff_xattn_wgrad_stash_bytes(desc), dev)

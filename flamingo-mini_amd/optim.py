@@ -138,7 +138,37 @@ class FusedAdamW(torch.optim.Optimizer):
                     self.state[p]["step"] = torch.tensor(float(bucket["step"]), dtype=torch.float32)
 
     def load_state_dict(self, state_dict):
-        super().load_state_dict(state_dict)
+        """torch's Optimizer.load_state_dict casts every floating-point state tensor to the PARAMETER's dtype, which would turn the fp32
+        moments / master copies of a bf16 parameter into bf16 (and the next step would then either raise or silently continue with bf16
+        moments).  The tensors of the incoming state_dict are therefore put back in their own precision afterwards: `master` always in
+        fp32, the moments in `state_dtype` (the precision this optimizer was built for) or, without one, the checkpoint's."""
+        import copy
+        incoming = state_dict["state"]
+        saved_groups = state_dict["param_groups"]
+        super().load_state_dict(copy.copy(state_dict))
+        # map the checkpoint's integer ids to this optimizer's parameters (same order: torch's own rule)
+        ids = [i for g in saved_groups for i in g["params"]]
+        params = [p for g in self.param_groups for p in g["params"]]
+        for i, p in zip(ids, params):
+            src = incoming.get(i)
+            st = self.state.get(p)
+            if src is None or st is None:
+                continue
+            mixed = p.dtype == torch.bfloat16
+            for key in ("exp_avg", "exp_avg_sq", "master"):
+                if key not in src or not torch.is_tensor(src[key]):
+                    continue
+                want = torch.float32 if key == "master" else (self.state_dtype if (mixed and self.state_dtype is not None) else
+                                                              (src[key].dtype if mixed else p.dtype))
+                if st[key].dtype != want or st[key].dtype != src[key].dtype:
+                    st[key] = src[key].detach().to(device=p.device, dtype=want).clone(memory_format=torch.preserve_format)
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+            if mixed and self.master_dtype is None and "master" in st:
+                del st["master"]                       # this optimizer keeps no master copies: the parameter itself is the weight
+        for group in self.param_groups:                # device-side counters of the capturable mode restart from the loaded step counts
+            for k in ("_step_dev", "_lr_dev", "_lr_on_dev"):
+                group.pop(k, None)
         self.__dict__.pop("_bucket_cache", None)       # moments were replaced: rebuild the pointer tables
 
     def state_dict(self):

@@ -150,3 +150,50 @@ def test_learning_rate_schedule_survives_graph_replay():
     torch.cuda.synchronize()
     for a, b in zip(p_e, p_g):
         assert rel(b, a) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["master", "state"])
+def test_fused_adamw_mixed_precision_state_dict_round_trip(mode):
+    """save -> load -> step in mixed precision (ADVICE r02): torch's Optimizer.load_state_dict casts state tensors to the parameter's dtype;
+    the fp32 moments / master copies of bf16 parameters must come back as fp32 and the resumed run must equal the uninterrupted one."""
+    from flamingo_mini_amd import FusedAdamW
+    kw = dict(master_dtype=torch.float32) if mode == "master" else dict(state_dtype=torch.float32)
+    shapes = [(257,), (64, 40), (1,)]
+
+    def make():
+        return [torch.nn.Parameter(dev(rnd(s, 10 + i), torch.bfloat16)) for i, s in enumerate(shapes)]
+
+    grads = [[dev(rnd(s, 100 * st + i, 0.3), torch.bfloat16) for i, s in enumerate(shapes)] for st in range(4)]
+    straight, first = make(), make()
+    o_straight, o_first = FusedAdamW(straight, lr=1e-2, weight_decay=0.1, **kw), FusedAdamW(first, lr=1e-2, weight_decay=0.1, **kw)
+    for st in range(4):
+        for p, g in zip(straight, grads[st]):
+            p.grad = g.clone()
+        o_straight.step()
+    for st in range(2):
+        for p, g in zip(first, grads[st]):
+            p.grad = g.clone()
+        o_first.step()
+    import copy
+    import io
+    buf = io.BytesIO()
+    torch.save(dict(opt=o_first.state_dict(), params=[p.detach().clone() for p in first]), buf)
+    buf.seek(0)
+    ck = torch.load(buf)
+    resumed = [torch.nn.Parameter(t.clone()) for t in ck["params"]]
+    o_res = FusedAdamW(resumed, lr=1e-2, weight_decay=0.1, **kw)
+    o_res.load_state_dict(copy.deepcopy(ck["opt"]))
+    for p in resumed:
+        st = o_res.state[p]
+        assert st["exp_avg"].dtype == torch.float32 and st["exp_avg_sq"].dtype == torch.float32
+        assert ("master" in st) == (mode == "master") and (mode != "master" or st["master"].dtype == torch.float32)
+    for st in range(2, 4):
+        for p, g in zip(resumed, grads[st]):
+            p.grad = g.clone()
+        o_res.step()
+    for a, b in zip(straight, resumed):
+        assert torch.equal(a, b)
+    for a, b in zip(straight, resumed):
+        for k in ("exp_avg", "exp_avg_sq") + (("master",) if mode == "master" else ()):
+            assert torch.equal(o_straight.state[a][k], o_res.state[b][k]), k
+    assert float(o_res.state_dict()["state"][0]["step"]) == 4.0

@@ -192,3 +192,238 @@ def test_two_gloo_ranks_on_the_product_gradient_flow(tmp_path, mode, clean_patch
         assert _close(r0[k], want[k], 5e-4 if mode == "sharded" else 2e-4), k
         if mode == "reduce":
             assert np.array_equal(r0["acc." + k], r1["acc." + k]) and _close(r0["acc." + k], want[k], 2e-4), k
+
+
+# ---- the deferred weight-gradient queue under failure and module reuse ---------------------------------------
+def _host_blocks(n, tag):
+    import host_lib
+    import oracle_backend
+    from detgen import xattn_params
+    from flamingo_mini_amd import GatedCrossAttentionBlock
+    oracle_backend.uninstall()
+    host = host_lib.install()
+    dim, dv, heads, dh, nv, ffm = 32, 24, 2, 8, 4, 2
+    blocks = []
+    for i in range(n):
+        m = GatedCrossAttentionBlock(dim=dim, dim_visual=dv, dim_head=dh, heads=heads, ff_mult=ffm, n_visual=nv)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in xattn_params(dim, dv, heads, dh, ffm, tag=f"{tag}{i}").items()})
+        blocks.append(m)
+    return host, blocks, (dim, dv, heads, dh, nv, ffm)
+
+
+def _oracle_chain(blocks, order, y, vf, ml, g):
+    """float64 oracle of h = block_order[-1](... block_order[0](y)): parameter gradients summed per block, d y, d vf."""
+    from oracle import flamingo_oracle as O
+    heads, dh = blocks[0].cfg[0], blocks[0].cfg[1]
+    ps = [{k: v.detach().double().numpy() for k, v in m.state_dict().items()} for m in blocks]
+    h, caches = y.astype(np.float64), []
+    for i in order:
+        h, _, c = O.gated_xattn_block_fwd(h, vf.astype(np.float64), ml, ps[i], heads=heads, dim_head=dh, n_visual=blocks[0].n_visual)
+        caches.append(c)
+    grads = [dict() for _ in blocks]
+    d, dvf = g.astype(np.float64), 0.0
+    for i, c in reversed(list(zip(order, caches))):
+        d, dv_i, gi = O.gated_xattn_block_bwd(d, c, ps[i], heads=heads, dim_head=dh)
+        dvf = dvf + dv_i
+        for k, v in gi.items():
+            grads[i][k] = grads[i].get(k, 0.0) + np.asarray(v)
+    return grads, d, dvf
+
+
+def _run_chain(blocks, order, y, vf, ml, g, hook_at=None):
+    from flamingo_mini_amd import functional as F
+    yt = torch.from_numpy(y).requires_grad_(True)
+    vft = torch.from_numpy(vf).requires_grad_(True)
+    mlt = torch.from_numpy(ml)
+    kvs = F.kv_project(vft, [m.attn.to_kv.weight for m in blocks])
+    h = yt
+    for n, i in enumerate(order):
+        h, _ = blocks[i](h, vft, mlt, hoisted_kv=kvs[i])
+        if hook_at == n:
+            def boom(grad):
+                raise RuntimeError("simulated failure inside backward")
+            h.register_hook(boom)
+    (h * torch.from_numpy(g)).sum().backward()
+    return yt.grad, vft.grad
+
+
+def test_a_backward_pass_that_raises_leaves_no_stale_weight_gradient_work(clean_patches):
+    """backward() raising after some blocks deferred their weight gradients: the engine never runs that pass's queue callback, so its
+    entries (raw addresses of buffers that are freed afterwards) must neither run later nor be grouped with the next pass's entries,
+    and the next pass must flush its own trailing group (a 'catch the error, skip the batch' loop)."""
+    from detgen import det
+    from flamingo_mini_amd import functional as F
+    host, blocks, (dim, dv, heads, dh, nv, ffm) = _host_blocks(5, "qf")
+    b, L = 2, 6
+    y, vf, g = det((b, L, dim), "qf-y"), det((b, 1, nv, dv), "qf-vf"), det((b, L, dim), "qf-g")
+    ml = np.zeros((b, L), np.int64); ml[:, 0] = 1
+    order = list(range(5))
+    with pytest.raises(RuntimeError, match="simulated failure"):
+        _run_chain(blocks, order, y, vf, ml, g, hook_at=1)          # blocks 4, 3, 2 defer (3 < group size: all still pending), then the hook raises
+    assert len(F._wgrad_queue.pending) == 3
+    for m in blocks:
+        m.zero_grad(set_to_none=True)
+    host.calls.clear()
+    dy, dvf = _run_chain(blocks, order, y, vf, ml, g)
+    assert not F._wgrad_queue.pending and not F._wgrad_queue._passes
+    grouped = [int(c.split("[")[1][:-1]) for c in host.calls if c.startswith("ff_xattn_wgrad_grouped")]
+    assert sorted(grouped) == [1, 4]                                 # this pass's five blocks only: one full group and its own trailing one
+    want, dy_w, dvf_w = _oracle_chain(blocks, order, y, vf, ml, g)
+    assert _close(dy.double().numpy(), dy_w, 2e-4) and _close(dvf.double().numpy(), dvf_w, 2e-4)
+    for m, w in zip(blocks, want):
+        for k, p in m.named_parameters():
+            got = p.grad.double().numpy()
+            assert np.isfinite(got).all() and _close(got.reshape(-1), np.asarray(w[k]).reshape(-1), 2e-4), k
+
+
+def test_a_block_used_twice_in_one_pass_sums_both_contributions(clean_patches):
+    """Module reuse (or an activation-checkpoint recompute): the same parameters receive two gradient contributions in one backward pass.
+    The second use must not defer - autograd adds the two tensors the moment the second is returned - and the first must be complete by
+    then."""
+    from detgen import det
+    from flamingo_mini_amd import functional as F
+    host, blocks, (dim, dv, heads, dh, nv, ffm) = _host_blocks(3, "qr")
+    b, L = 2, 6
+    y, vf, g = det((b, L, dim), "qr-y"), det((b, 1, nv, dv), "qr-vf"), det((b, L, dim), "qr-g")
+    ml = np.zeros((b, L), np.int64); ml[:, 0] = 1
+    order = [0, 1, 2, 1, 0]
+    dy, dvf = _run_chain(blocks, order, y, vf, ml, g)
+    assert not F._wgrad_queue.pending and not F._wgrad_queue._passes
+    assert host.calls.count("ff_xattn_block_bwd_kv_data") == 3 and host.calls.count("ff_xattn_block_bwd_kv") == 2
+    want, dy_w, dvf_w = _oracle_chain(blocks, order, y, vf, ml, g)
+    assert _close(dy.double().numpy(), dy_w, 2e-4) and _close(dvf.double().numpy(), dvf_w, 2e-4)
+    for m, w in zip(blocks, want):
+        for k, p in m.named_parameters():
+            got = p.grad.double().numpy()
+            assert np.isfinite(got).all() and _close(got.reshape(-1), np.asarray(w[k]).reshape(-1), 2e-4), k
+
+
+# ---- four gloo ranks: bucket arrival order, accumulation under no_sync(), widened reduction, sharded state round trip ------------
+def _rank_inputs(rank, dims, micro=0):
+    from detgen import det
+    dim, dv, heads, dh, nv, ffm = dims
+    b, L = 2, 6
+    y, vf, g = det((b, L, dim), f"r{rank}m{micro}-y"), det((b, 1, nv, dv), f"r{rank}m{micro}-vf"), det((b, L, dim), f"r{rank}m{micro}-g")
+    ml = np.zeros((b, L), np.int64); ml[:, 0] = 1
+    return y, vf, ml, g
+
+
+def _chain_loss(blocks, order, y, vf, ml, g, dtype=torch.float32):
+    from flamingo_mini_amd import functional as F
+    yt, vft, mlt = torch.from_numpy(y).to(dtype), torch.from_numpy(vf).to(dtype), torch.from_numpy(ml)
+    kvs = F.kv_project(vft, [m.attn.to_kv.weight for m in blocks])
+    h = yt
+    for i in order:
+        h, _ = blocks[i](h, vft, mlt, hoisted_kv=kvs[i])
+    return (h * torch.from_numpy(g).to(dtype)).sum()
+
+
+ORDER_A, ORDER_B = [0, 1, 2], [2, 0, 1]
+
+
+def _four_rank_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from flamingo_mini_amd.data_parallel import GradientAllReducer, ShardedAdamW
+    from test_data_parallel import HP, _torch_adamw
+    host, blocks, dims = _host_blocks(3, "w4")
+    model = torch.nn.ModuleList(blocks)
+    # (1) all-reduce with the exchange widened to float64 (reduce_dtype): mean gradients, identical on every rank
+    reducer = GradientAllReducer(model, reduce_dtype=torch.float64)
+    _chain_loss(blocks, ORDER_A, *_rank_inputs(rank, dims)).backward()
+    reducer.finish()
+    out = {"g." + k: p.grad.double().numpy().copy() for k, p in model.named_parameters()}
+    reducer.close()
+    model.zero_grad(set_to_none=True)
+    # (2) sharded AdamW: step 1 visits the blocks in one order, step 2 in another (the buckets arrive in another order) and is made of two
+    # micro-batches, the first under no_sync()
+    opt = ShardedAdamW(model, update_fn=_torch_adamw, **HP)
+    _chain_loss(blocks, ORDER_A, *_rank_inputs(rank, dims)).backward()
+    opt.step()
+    saved = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items() if k != "buckets"}
+    saved["buckets"] = {n: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()} for n, b in opt.state_dict()["buckets"].items()}
+    params_after_1 = {k: p.detach().clone() for k, p in model.named_parameters()}
+
+    def step2(o, mods):
+        o.zero_grad()
+        with o.no_sync():
+            (_chain_loss(mods, ORDER_B, *_rank_inputs(rank, dims, 1)) / 2).backward()
+        (_chain_loss(mods, ORDER_B, *_rank_inputs(rank, dims, 2)) / 2).backward()
+        o.step()
+
+    step2(opt, blocks)
+    out.update({"p." + k: p.detach().double().numpy().copy() for k, p in model.named_parameters()})
+    refused = 0
+    opt.zero_grad()
+    _chain_loss(blocks, ORDER_A, *_rank_inputs(rank, dims)).backward()
+    try:                                                   # a second backward in the same step without no_sync(): refused, not silently applied
+        _chain_loss(blocks, ORDER_A, *_rank_inputs(rank, dims)).backward()
+    except RuntimeError as e:
+        refused = int("no_sync" in str(e))
+    opt.close()
+    # (3) resume: fresh modules holding the parameters after step 1 + this rank's saved shards -> the same step 2
+    _, blocks2, _ = _host_blocks(3, "w4")
+    model2 = torch.nn.ModuleList(blocks2)
+    model2.load_state_dict(params_after_1)
+    opt2 = ShardedAdamW(model2, update_fn=_torch_adamw, **HP)
+    opt2.load_state_dict(saved)
+    step2(opt2, blocks2)
+    out.update({"r." + k: p.detach().double().numpy().copy() for k, p in model2.named_parameters()})
+    opt2.close()
+    np.savez(os.path.join(out_dir, f"w4_{rank}.npz"), refused=refused, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_gloo_ranks_reduce_dtype_bucket_order_accumulation_and_resume(tmp_path, clean_patches):
+    world = 4
+    port = _free_port()
+    mp.start_processes(_four_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    res = [np.load(tmp_path / f"w4_{r}.npz") for r in range(world)]
+    # single-process float64 reference on the oracle-backed entry points
+    import host_lib
+    import oracle_backend
+    from detgen import xattn_params
+    from flamingo_mini_amd import GatedCrossAttentionBlock
+    from test_data_parallel import HP
+    host_lib.uninstall()
+    oracle_backend.install()
+    dims = (32, 24, 2, 8, 4, 2)
+    dim, dv, heads, dh, nv, ffm = dims
+    blocks = []
+    for i in range(3):
+        m = GatedCrossAttentionBlock(dim=dim, dim_visual=dv, dim_head=dh, heads=heads, ff_mult=ffm, n_visual=nv).double()
+        m.load_state_dict({k: torch.from_numpy(v).double() for k, v in xattn_params(dim, dv, heads, dh, ffm, tag=f"w4{i}").items()})
+        blocks.append(m)
+    model = torch.nn.ModuleList(blocks)
+
+    def ref_loss(order, micro):
+        from flamingo_mini_amd import functional as F
+        tot = 0.0
+        for r in range(world):
+            y, vf, ml, g = _rank_inputs(r, dims, micro)
+            h = torch.from_numpy(y).double()
+            vft, mlt = torch.from_numpy(vf).double(), torch.from_numpy(ml)
+            for i in order:
+                h, _ = blocks[i](h, vft, mlt)
+            tot = tot + (h * torch.from_numpy(g).double()).sum()
+        return tot / world
+
+    ref_loss(ORDER_A, 0).backward()
+    for k, p in model.named_parameters():
+        for r in range(world):
+            assert np.array_equal(res[r]["g." + k], res[0]["g." + k]), k
+        assert _close(res[0]["g." + k].reshape(-1), p.grad.numpy().reshape(-1), 2e-4), k
+    opt = torch.optim.AdamW(model.parameters(), **HP)
+    opt.step()
+    model.zero_grad(set_to_none=True)
+    ((ref_loss(ORDER_B, 1) + ref_loss(ORDER_B, 2)) / 2).backward()
+    opt.step()
+    for k, p in model.named_parameters():
+        want = p.detach().numpy().reshape(-1)
+        for r in range(world):
+            assert np.array_equal(res[r]["p." + k], res[0]["p." + k]), k          # every rank holds the same parameters after the all-gather
+            assert np.array_equal(res[r]["r." + k], res[r]["p." + k]), k          # resumed from the saved shards: bit-identical step 2
+        assert _close(res[0]["p." + k].reshape(-1), want, 5e-4), k
+    assert all(int(r["refused"]) == 1 for r in res)

@@ -217,6 +217,12 @@ class FlamingoOPT(FlamingoBaseModel):
         return [layer for layer in self.lm.decoder.layers if isinstance(layer, ModifiedLMBlock)]
 
 
+# Decode sessions hold HIP graphs and raw parameter addresses: they live in a weak side table, not in the model's __dict__, so
+# copy.deepcopy(model) / pickling (EMA or evaluation copies) neither see nor try to copy them.
+import weakref
+_DECODE_SESSIONS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
 class _DecodeSession:
     """Fixed-shape greedy decoding for one (batch, max_length) shape: the LM keeps a transformers StaticCache of max_length positions, the
     attention mask and the token buffer are preallocated, positions travel as a device tensor (`cache_position`), the cross-attention K / V
@@ -241,6 +247,15 @@ class _DecodeSession:
         self.xattn_past = None                                                 # persistent (k, v) per layer, filled by every prompt step
         self.replay = None
         self.capture_failed = False
+        self.param_ptrs = self._param_ptrs()                                   # what a captured graph reads: checked before every reuse
+
+    def _param_ptrs(self):
+        return tuple(p.data_ptr() for p in self.model.parameters())
+
+    def stale(self) -> bool:
+        """Parameters were re-allocated since this session was built (model.to() / .half(), ShardedAdamW moving them into flat buffers):
+        a captured graph would replay reads of freed memory."""
+        return self.param_ptrs != self._param_ptrs()
 
     def _append(self, logits):             # choose, apply the eos bookkeeping of generate(), append at `pos`
         nxt = logits.float().argmax(-1)
@@ -467,23 +482,30 @@ class FlamingoModel(PreTrainedModel):
     def _static_greedy(self, ids, ml, am, pixel_values, visual_features, max_length, eos, pad, graph: Optional[bool] = None):
         """Greedy decoding with FIXED shapes (see _DecodeSession).  Sessions - preallocated caches and buffers plus, on the GPU, the captured
         HIP graph of one decode step - are kept per (batch, max_length, keys per sequence, eos / pad) and reused by later calls, so only the
-        first caption batch of a shape pays for the capture.  reset_decode_sessions() drops them (needed only if parameters are re-allocated)."""
+        first caption batch of a shape pays for the capture.  a session whose model's parameters were re-allocated since (model.to(), ShardedAdamW) is rebuilt; reset_decode_sessions() drops them all."""
         b = ids.shape[0]
         if graph is None:
             graph = ids.is_cuda and not self.training and os.environ.get("FF_DECODE_GRAPH", "1") == "1"
-        sessions = self.__dict__.setdefault("_decode_sessions", {})
+        sessions = _DECODE_SESSIONS.setdefault(self, {})
         n_media = int(ml.sum(-1).max()) if visual_features is None and pixel_values is None else \
             (visual_features.shape[1] if visual_features is not None else (pixel_values.shape[1] if pixel_values.ndim >= 5 else pixel_values.shape[0]))
         key = (b, max_length, n_media, str(ids.device), eos, pad, bool(graph))
         sess = sessions.get(key)
+        if sess is not None and sess.stale():
+            sessions.pop(key)
+            sess = None
         if sess is None:
             if len(sessions) >= 4:                                            # a handful of shapes at most: each holds a KV cache and a graph
                 sessions.pop(next(iter(sessions)))
             sess = sessions[key] = _DecodeSession(self, b, max_length, ids.device, ids.dtype, am.dtype, eos, pad, graph)
         return sess.run(ids, ml, am, pixel_values, visual_features)
 
+    @property
+    def _decode_sessions(self) -> dict:
+        return _DECODE_SESSIONS.get(self, {})
+
     def reset_decode_sessions(self) -> None:
-        self.__dict__.pop("_decode_sessions", None)
+        _DECODE_SESSIONS.pop(self, None)
 
     def _beam_search(self, ids, ml, am, pixel_values, visual_features, max_length, nb, eos, pad, early_stopping, length_penalty):
         """Standard beam search over the cached decode path.  The prompt runs once per sequence; its caches are then replicated per beam

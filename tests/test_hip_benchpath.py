@@ -1,0 +1,148 @@
+"""The code path bench.py times, against the oracle, at the benchmark's geometry.
+
+Config B runs bf16 with 64-wide heads - the fused LayerNorm -> Q projection -> attention kernel (xa_qattn_fwd_kernel), its backward mirror
+(xa_dattn_bwd_kernel) - with the K / V projection of all layers hoisted (ff_kv_project_*), the data-gradient-only block backward
+(ff_xattn_block_bwd_kv_data), the weight gradients of four blocks per grouped launch (ff_xattn_wgrad_grouped: one full group and a ragged
+one here) and the final LayerNorm / gate reductions deferred with them.  The module-level oracle tests call `block(y, vf, ml)`, i.e. the
+per-layer, non-deferred entry points; this file drives six gpt2-large-geometry blocks through `functional.kv_project` + `hoisted_kv=`
+exactly like FlamingoBaseModel.forward does, in bf16 and fp32, at the benchmark's batch (32 x 32 tokens, one image) and at a ragged one
+(batch 5, 96 tokens = the multi-tile kernels, three images, rows with text_time 0 and beyond the last image).
+
+Two comparisons per case, both against oracle.gated_xattn_block_fwd / _bwd (float64):
+  per block  - the oracle is fed what the block actually received on the device (its input rows and the incoming gradient, both as stored
+               in the run's dtype), so every block's outputs and every one of its parameter gradients are held to the plain tolerances;
+  chained    - the oracle runs the six blocks on its own float64 intermediates: the end-to-end output, d y, d visual_features.
+The resampler stack of config B (depth 6, 257 CLIP tokens, batch 32) gets the same treatment against oracle.resampler_fwd / _bwd.
+"""
+import numpy as np
+import pytest
+import torch
+
+from detgen import det, resampler_params, xattn_params
+from oracle import flamingo_oracle as O
+from test_hip_modules import build_block, build_resampler
+from util import TOL, as64, dev, rel
+
+pytestmark = pytest.mark.gpu
+
+DIM, DV, HEADS, DH, NV, FFM = 1280, 1024, 8, 64, 64, 4
+LAYERS = 6
+
+
+def _scalar_close(got, want, tol):
+    return abs(float(got) - float(want)) < tol * max(1.0, abs(float(want))) * 5
+
+
+def run_hoisted_chain(blocks, y, vf, ml, g):
+    """What FlamingoBaseModel.forward does with hoist_kv: one grouped projection of every layer's K / V, then the blocks in sequence.
+    Returns the hidden states h_0 .. h_n (with .grad retained)."""
+    from flamingo_mini_amd import functional as F
+    kvs = F.kv_project(vf, [m.attn.to_kv.weight for m in blocks])
+    hs = [y]
+    for m, kv in zip(blocks, kvs):
+        h, _ = m(hs[-1], vf, ml, hoisted_kv=kv)
+        h.retain_grad()
+        hs.append(h)
+    hs[-1].backward(g)
+    assert not F._wgrad_queue.pending
+    return hs
+
+
+def check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act="gelu", chain_factor=3.0):
+    t = TOL[dtype]
+    p64 = [{k: as64(v) for k, v in m.state_dict().items()} for m in blocks]
+    vf64 = as64(vf)
+    worst = {}
+
+    def note(name, err, bound):      # collected, asserted together at the end (one GPU run shows every margin)
+        worst[name] = max(worst.get(name, 0.0), err / bound)
+
+    # ---- per block, on the device's own inputs ----
+    dvf_sum = np.zeros_like(vf64)
+    for i, m in enumerate(blocks):
+        x_in, x_out = as64(hs[i]), as64(hs[i + 1])
+        out_r, _, cache = O.gated_xattn_block_fwd(x_in, vf64, ml_np, p64[i], act=act)
+        note(f"block{i}.out", rel(x_out - x_in, out_r - x_in), t["out"])
+        dy_r, dvf_r, g_r = O.gated_xattn_block_bwd(as64(hs[i + 1].grad), cache, p64[i], act=act)
+        note(f"block{i}.dy", rel(hs[i].grad, dy_r), t["grad"])
+        dvf_sum += dvf_r
+        for k, prm in m.named_parameters():
+            assert prm.grad is not None and bool(torch.isfinite(prm.grad.float()).all()), (i, k)
+            if g_r[k].size == 1:
+                assert _scalar_close(prm.grad, g_r[k], t["grad"]), (i, k, float(prm.grad), float(g_r[k]))
+            else:
+                note(f"block{i}.{k}", rel(prm.grad, g_r[k]), t["grad"])
+    note("dvf(sum of per-block oracles)", rel(vf.grad, dvf_sum), t["grad"] * 1.5)
+    # ---- chained: the oracle on its own float64 intermediates ----
+    h = as64(y)
+    caches = []
+    for i in range(len(blocks)):
+        h, _, c = O.gated_xattn_block_fwd(h, vf64, ml_np, p64[i], act=act)
+        caches.append(c)
+    note("chain.out", rel(as64(hs[-1]) - as64(y), h - as64(y)), t["out"] * chain_factor)
+    d, dvf = as64(g), np.zeros_like(vf64)
+    for i in reversed(range(len(blocks))):
+        d, dvf_i, _ = O.gated_xattn_block_bwd(d, caches[i], p64[i], act=act)
+        dvf += dvf_i
+    note("chain.dy", rel(y.grad, d), t["grad"] * chain_factor)
+    note("chain.dvf", rel(vf.grad, dvf), t["grad"] * chain_factor)
+    return worst
+
+
+def _case(dtype, b, L, N, ml_np, tag, act="gelu"):
+    blocks = [build_block(xattn_params(DIM, DV, HEADS, DH, FFM, alpha_attn=0.5 - 0.1 * i, alpha_ffw=-0.4 + 0.15 * i, tag=f"{tag}{i}"),
+                          DIM, DV, HEADS, DH, NV, FFM, act, dtype) for i in range(LAYERS)]
+    y = dev(det((b, L, DIM), tag + "y"), dtype).requires_grad_(True)
+    vf = dev(det((b, N, NV, DV), tag + "vf"), dtype).requires_grad_(True)
+    g = dev(det((b, L, DIM), tag + "g"), dtype)
+    ml = torch.as_tensor(ml_np).cuda()
+    hs = run_hoisted_chain(blocks, y, vf, ml, g)
+    worst = check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act=act)
+    print(f"[benchpath {tag} {dtype}] worst error / bound:", {k: round(v, 3) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
+    bad = {k: round(v, 3) for k, v in worst.items() if not v < 1.0}
+    assert not bad, f"error / bound >= 1: {bad}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_config_B_hoisted_deferred_blocks_full_batch(dtype):
+    """32 sequences x 32 tokens, one image (media tag at token 0): the benchmark's shapes, the single-tile fused kernels."""
+    ml = np.zeros((32, 32), np.int64); ml[:, 0] = 1
+    _case(dtype, 32, 32, 1, ml, "BP")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_hoisted_deferred_blocks_ragged_batch_long_text(dtype):
+    """batch 5, 96 tokens (three query tiles: the multi-tile forward and the separate d K / d V launch), three images, rows before the first
+    tag (text_time 0 -> zero rows) and after a fourth tag (text_time > n_media -> uniform rows), squared-ReLU feed-forward."""
+    b, L, N = 5, 96, 3
+    ml = np.zeros((b, L), np.int64)
+    ml[0, [0, 30, 61]] = 1
+    ml[1, [10, 50]] = 1
+    ml[2, [0, 1, 2, 3]] = 1
+    ml[3, [95]] = 1
+    ml[4, [5, 6, 40]] = 1
+    _case(dtype, b, L, N, ml, "BR", act="sqrelu")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_config_B_resampler_full_batch(dtype):
+    """The resampler of config B at its full batch: (32, 1, 257, 1024) CLIP-L features, depth 6, grouped weight gradients over 4 + 2 layers."""
+    dim, depth, b = 1024, 6, 32
+    p = resampler_params(dim, depth, HEADS, DH, 64, 4, 4, tag="BPrs")
+    m = build_resampler(p, dim, depth, HEADS, DH, 64, 4, 4, "gelu", dtype)
+    xd = dev(det((b, 1, 257, dim), "BPrs-x"), dtype).requires_grad_(True)
+    dyd = dev(det((b, 64, dim), "BPrs-dy"), dtype)
+    y = m(xd)
+    y.backward(dyd)
+    p64 = {k: as64(v) for k, v in m.state_dict().items()}
+    yr, cache = O.resampler_fwd(as64(xd), p64)
+    dxr, gr = O.resampler_bwd(as64(dyd), cache, p64)
+    t = TOL[dtype]
+    assert rel(y, yr) < t["out"]
+    assert rel(xd.grad, dxr) < t["grad"]
+    worst = {}
+    for k, prm in m.named_parameters():
+        worst[k] = rel(prm.grad, gr[k])
+    bad = {k: v for k, v in worst.items() if not v < t["grad"]}
+    print(f"[benchpath resampler {dtype}] worst parameter-gradient errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    assert not bad, bad

@@ -207,6 +207,15 @@ def test_generation_strategies_cpu_with_oracle_checker(family):
             assert len(model._decode_sessions) == 1
             assert torch.equal(model.generate(ids2, static_decode=True, **kw), model.generate(ids2, static_decode=False, **kw))
             assert len(model._decode_sessions) == 1
+            import copy
+            twin = copy.deepcopy(model)                                       # sessions (graphs, raw addresses) are not part of the model's state
+            assert len(twin._decode_sessions) == 0 and torch.equal(twin.generate(ids, static_decode=True, **kw), greedy)
+            sess = next(iter(model._decode_sessions.values()))
+            first = next(model.parameters())
+            first.data = first.data.clone()                                   # a re-allocated parameter: the old session must not be replayed
+            assert sess.stale()
+            assert torch.equal(model.generate(ids, static_decode=True, **kw), greedy)
+            assert next(iter(model._decode_sessions.values())) is not sess and len(model._decode_sessions) == 1
             for eos in {int(greedy[0, 5]), int(greedy[1, 7]), int(greedy[0, 8])}:     # early stop: same tokens, same trimmed length
                 want = model.generate(ids, eos_token_id=eos, pad_token_id=0, static_decode=False, **kw)
                 got = model.generate(ids, eos_token_id=eos, pad_token_id=0, static_decode=True, **kw)

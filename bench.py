@@ -71,7 +71,13 @@ def parse():
     ap.add_argument("--frames", type=int, default=None, help="frames per image (0 = still images, 5-D pixel tensor; > 0 = 6-D video tensor)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
-    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"], help="fused = ff_adamw_step (this library), torch = torch.optim.AdamW(fused=True)")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "fused-master", "sharded", "sharded-master", "torch"],
+                    help="fused = ff_adamw_step on bf16 parameters with bf16 moments; fused-master = the same kernel with fp32 master weights and fp32 "
+                         "moments (the reference's --fp16 recipe, training/train.sh:24); sharded(-master) = data_parallel.ShardedAdamW (reduce-scatter -> "
+                         "update of this rank's 1/N slice -> all-gather per gradient bucket, replaces the gradient all-reduce); torch = torch.optim.AdamW(fused=True)")
+    ap.add_argument("--companions", default="auto", choices=["auto", "on", "off"],
+                    help="N=1 only: after the main measurement, re-run the same workload in child processes (a) with the untouched Hugging Face backbones "
+                         "and no tuning file, (b) with the fp32-master / fp32-moment optimizer, and add both to the JSON line (auto = on for the default config B run)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph (auto = on; at N > 1 the RCCL all-reduces are captured with it, and the "
                          "step falls back to eager launches if that capture fails)")
@@ -85,12 +91,15 @@ def parse():
     ap.add_argument("--hoist-kv", default="env", choices=["env", "on", "off"],
                     help="project K / V of all cross-attention layers up front in grouped launches (env = FF_HOIST_KV, default on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--child", action="store_true", help="internal: a companion run started by the main process (timed region only)")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
     args = ap.parse_args()
     if args.backbone_tweaks == "off":
         os.environ["FLAMINGO_STOCK_BACKBONES"] = "1"
         args.stock_tuning = "off"
+    if args.child:
+        args.no_cpu_baseline, args.caption_tokens, args.profile_steps, args.companions = True, 0, 0, "off"
     for k, v in CONFIGS[args.config].items():
         if k != "what" and getattr(args, k) is None:
             setattr(args, k, v)
@@ -178,9 +187,51 @@ def caption_leg(args, model, batch, device):
     new = out.shape[1] - 4
     sessions = list(getattr(model, "_decode_sessions", {}).values())
     graphed = bool(sessions) and all(s.replay is not None for s in sessions)
+    # HBM roofline of one decode step: every weight a token step touches is streamed once (the LM incl. the tied lm_head, and per gated
+    # block norm / to_q / to_out / ffw - to_kv is not needed, K / V are cached), plus the caches it reads: the cross-attention K / V of all
+    # layers and the LM's self-attention K / V up to the current position (average over the decoded positions).
+    es = next(model.parameters()).element_size()
+    fl = model.flamingo
+    lm_bytes = sum(p.numel() for n, p in fl.lm.named_parameters() if ".xattn_block." not in n) * es
+    blocks = fl.get_modified_layers()
+    blk_bytes = sum(p.numel() for h in blocks for n, p in h.xattn_block.named_parameters() if "to_kv" not in n) * es
+    cfg = fl.config
+    inner = cfg.xattn_heads * cfg.xattn_dim_head
+    n_kv = cfg.resampler_num_latents * (batch["pixel_values"].shape[1] if batch["pixel_values"].ndim >= 5 else 1)
+    xkv_bytes = len(blocks) * args.batch * n_kv * 2 * inner * es
+    n_lm_layers = getattr(fl.lm.config, "n_layer", getattr(fl.lm.config, "num_hidden_layers", 0))
+    avg_pos = 4 + new / 2.0
+    lmkv_bytes = int(n_lm_layers * args.batch * 2 * avg_pos * cfg.dim * es)
+    step_bytes = lm_bytes + blk_bytes + xkv_bytes + lmkv_bytes
+    step_s = dt / new
     return {"value": round(args.batch * new / dt, 1), "unit": "caption tokens/sec", "batch": args.batch, "new_tokens_per_image": new,
             "ms_per_decode_step": round(dt / new * 1e3, 2), "decode_step_hip_graph": graphed,
+            "roofline": {"bound": "hbm", "achieved": round(step_bytes / step_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(step_bytes / step_s / 8e12, 4),
+                         "bytes_per_decode_step": {"lm_weights": lm_bytes, "xattn_block_weights": blk_bytes, "xattn_kv_cache": xkv_bytes, "lm_kv_cache_avg": lmkv_bytes},
+                         "note": "algorithmic HBM bytes of one token step (weights streamed once + caches read) / measured step time, which includes "
+                                 "the prompt / CLIP / resampler step amortised over the new tokens"},
             "note": "greedy, cached xattn K/V + static LM cache, decode steps replayed from a HIP graph when captured; includes the prompt/CLIP/resampler step"}
+
+
+def run_companion(args, extra, timeout=420):
+    """The same workload in a child process with other switches; returns the fields of its JSON line that matter next to the main one."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--child", "--config", args.config, "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--batch", str(args.batch), "--seq-len", str(args.seq_len), "--graph", args.graph] + extra
+    env = {k: v for k, v in os.environ.items() if k != "FLAMINGO_STOCK_BACKBONES"}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        d = json.loads(line[-1])
+        c = d["config"]
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "loss_first": c["loss_first"], "loss_last": c["loss_last"],
+                "optimizer": c["optimizer"], "backbone_tweaks": c["backbone_tweaks"], "stock_gemm_tuning_file": c["stock_gemm_tuning_file"],
+                "hip_graph": c["hip_graph"], "steps": d["steps"], "warmup": d["warmup"]}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
 
 
 def _usable_cores() -> int:
@@ -343,21 +394,31 @@ def main():
     # fault with gpt2-large, with one gated block, without the optimizer; no fault with the math SDPA backend, with LM dropout 0, at 512
     # tokens, or when only this library's kernels are captured at the same shapes).  `--graph on` still forces the capture.
     use_graph = args.graph == "on" or (args.graph == "auto" and args.config != "E")
-    if args.no_optimizer:
-        opt = None
-    elif args.optimizer == "fused":
-        from flamingo_mini_amd import FusedAdamW
-        opt = FusedAdamW(params, lr=1e-4, capturable=use_graph)
-    else:
-        opt = torch.optim.AdamW(params, lr=1e-4, fused=True, capturable=use_graph)
-    reducer = GradientAllReducer(model)
+    master = dict(master_dtype=torch.float32) if args.optimizer.endswith("-master") and dtype == torch.bfloat16 else {}
+
+    def make_optimizer(capturable):
+        if args.no_optimizer:
+            return None
+        if args.optimizer.startswith("fused"):
+            from flamingo_mini_amd import FusedAdamW
+            return FusedAdamW(params, lr=1e-4, capturable=capturable, **master)
+        if args.optimizer.startswith("sharded"):
+            from flamingo_mini_amd.data_parallel import ShardedAdamW
+            return ShardedAdamW(model, lr=1e-4, capturable=capturable, **master)
+        return torch.optim.AdamW(params, lr=1e-4, fused=True, capturable=capturable)
+
+    opt = make_optimizer(use_graph)
+    sharded = args.optimizer.startswith("sharded") and opt is not None
+    # ShardedAdamW does the exchange itself (reduce-scatter / all-gather per bucket); otherwise the buckets are all-reduced
+    reducer = None if sharded else GradientAllReducer(model)
 
     def eager_step():
         for p in params:                 # == model.zero_grad(set_to_none=True) without walking the ~1000 frozen parameters (4 ms of host time)
             p.grad = None
         out = model(**batch)
         out.loss.backward()
-        reducer.finish()
+        if reducer is not None:
+            reducer.finish()
         if opt is not None:
             opt.step()
         return out.loss
@@ -376,7 +437,8 @@ def main():
             t.append(time.perf_counter())
             out.loss.backward()
             t.append(time.perf_counter())
-            reducer.finish()
+            if reducer is not None:
+                reducer.finish()
             if opt is not None:
                 opt.step()
             t.append(time.perf_counter())
@@ -390,7 +452,7 @@ def main():
         from flamingo_mini_amd import GraphedTrainStep
         err = None
         try:
-            graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=reducer if world > 1 else None)
+            graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=reducer if (world > 1 and reducer is not None) else None)
         except Exception as e:      # e.g. a collective that cannot be captured on this software stack: run the same step eagerly
             if world == 1 and args.graph == "on":
                 raise
@@ -406,9 +468,10 @@ def main():
         else:
             graph_note = "; graph capture failed on a rank" + (f" ({type(err).__name__}: {str(err)[:120]})" if err is not None else "") + ", eager launches instead"
             use_graph = False
-            if opt is not None and args.optimizer == "fused":
-                from flamingo_mini_amd import FusedAdamW
-                opt = FusedAdamW(params, lr=1e-4, capturable=False)
+            if opt is not None and args.optimizer != "torch":
+                if sharded:
+                    opt.close()
+                opt = make_optimizer(False)
             step = eager_step
     else:
         step = eager_step
@@ -422,8 +485,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    loss_first = None
+    for i in range(args.steps):
         loss = step()
+        if i == 0:
+            loss_first = loss.detach().clone()      # (the replayed graph overwrites its static loss tensor every step)
+    loss_last = loss.detach().clone()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -450,6 +517,7 @@ def main():
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t1) / prof_steps * 1e3
     loss_val = float(loss.float().item())
+    loss_first_val, loss_last_val = float(loss_first.float().item()), float(loss_last.float().item())
 
     if rank == 0:
         groups, shapes, attn = gemm_profile_summary(lib, ffi, max_rec) if prof_steps else ({}, {}, {})
@@ -470,20 +538,31 @@ def main():
             tm, tn = (64, 128) if key[1] == 6412 else (key[1], key[1])
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
             if key[1] == 128160:      # the 8-wave producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU>
-                name = "ff::gemm_bf16_pc_kernel<128, 160, 0, 0, 3, 1>"
+                name = f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 3, 1>"
             elif key[1] == 128002:
                 name = f"ff::gemm_bf16_pc_kernel<128, 128, {key[2]}, {key[3]}, 2, 2>"
             tot_ms = sum(v["ms"] for v in groups.values())
             tot_fl = sum(v["flops"] for v in groups.values())
-            traffic = None      # HBM bytes per launch of this kernel from the latest committed PMC passes (profiles/rNN_pmc_traffic.json;
-            try:                # rocprofv3 counters cannot be collected from inside this process)
+            # HBM bytes per launch of this kernel: PMC counters cannot be read from inside this process (rocprofv3 wraps the command), so the
+            # figure comes from the latest committed counter passes of the SAME command (tools/gpu_final.sh -> profiles/rNN_pmc_traffic.json)
+            # and is tagged with its source; a kernel that file does not list gives null plus the reason, never a number of another kernel.
+            traffic, traffic_source = None, "no profiles/r*_pmc_traffic.json in the tree"
+            try:
                 import glob
-                with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
-                    traffic = json.load(f)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+                path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+                with open(path) as f:
+                    kernels = json.load(f)["kernels"]
+                rel_path = os.path.relpath(path, ROOT)
+                if name in kernels:
+                    traffic = kernels[name].get("hbm_bytes_per_launch")
+                    traffic_source = (f"{rel_path}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch "
+                                      "(MI355X_MICROARCH.md HBM section), average over the kernel's launches; not collected by this run")
+                else:
+                    traffic_source = f"{rel_path} has no entry for {name} (kernel renamed since those passes): re-run tools/gpu_final.sh"
+            except Exception as e:
+                traffic_source = f"unreadable traffic file: {e!r}"[:160]
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": traffic, "kernel": name, "launches": g["launches"],
+                        "traffic": traffic, "traffic_source": traffic_source, "kernel": name, "launches": g["launches"],
                         "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
                         "avg_launch_gflop": round(g["flops"] / g["launches"] / 1e9, 3),
                         "all_fusion_gemms": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
@@ -504,7 +583,12 @@ def main():
                                    + ("; step replayed from a captured HIP graph" + (" (RCCL all-reduces captured)" if world > 1 else "") if use_graph else "; eager launches")
                                    + graph_note + "; random-init weights, gates alpha=0.5",
                        "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
-                       "trainable_params": n_trainable, "loss": round(loss_val, 4), "hip_graph": use_graph, "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
+                       "trainable_params": n_trainable,
+                       # the same batch every step, AdamW at lr 1e-4 from random init: the loss of the timed steps is a trajectory, not a constant
+                       # ("the loss printed by the bench"); `loss` = after the instrumented eager steps that follow
+                       "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
+                       "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
+                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,
         }
@@ -518,6 +602,20 @@ def main():
             result["caption"] = caption_leg(args, model, batch, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
+        want_companions = args.companions == "on" or (args.companions == "auto" and args.config == "B" and args.backbone_tweaks == "on"
+                                                      and args.optimizer == "fused" and not args.no_optimizer)
+        if world == 1 and want_companions:
+            # free this process's model and graph pools first: the children build their own copies on the same GPU
+            batch = model = opt = step = graphed = reducer = params = loss = loss_first = loss_last = None      # (closures keep the names alive)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            result["stock_backbones"] = dict(run_companion(args, ["--backbone-tweaks", "off", "--optimizer", args.optimizer]),
+                                             what="same workload and fusion path, UNTOUCHED Hugging Face CLIP / LM modules and hipBLASLt's default heuristic "
+                                                  "(no op substitutions, no tuning file): the north star's 'backbones left on stock PyTorch-ROCm' figure")
+            result["fp32_master_optimizer"] = dict(run_companion(args, ["--optimizer", "fused-master"]),
+                                                   what="same as the headline run but AdamW keeps fp32 master weights and fp32 moments for the bf16 parameters "
+                                                        "(ff_adamw_step_mixed) - the reference's --fp16 recipe, training/train.sh:24")
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -36,6 +36,7 @@ class FlamingoConfig(PretrainedConfig):
         freeze_vision_model: bool = True,
         **kwargs,
     ):
+        kwargs.setdefault("tie_word_embeddings", True)         # lm_head shares the LM's token embedding (GPT-2 / OPT): see _tied_weights_keys
         super().__init__(**kwargs)
         own = dict(locals())
         for name in ("self", "kwargs", "__class__"):

@@ -45,6 +45,14 @@ def _repeat_leading(t: torch.Tensor, m: int) -> torch.Tensor:
     return t.repeat_interleave(m, dim=0)
 
 
+def _add_eoc_row(base_lm) -> None:
+    """One extra embedding row for <EOC> (reference :315, :343: resize_token_embeddings(vocab_size + 1)).  from_pretrained builds the model
+    on the meta device first (transformers >= 5); the mean / covariance initialisation of the new row cannot run there and is pointless
+    (the checkpoint overwrites it), so it is only applied to real tensors."""
+    real = base_lm.get_input_embeddings().weight.device.type != "meta"
+    base_lm.resize_token_embeddings(base_lm.config.vocab_size + 1, mean_resizing=real)
+
+
 class FlamingoBaseModel(ABC, PreTrainedModel):
     """CLIP -> PerceiverResampler -> LM whose layers were wrapped by ModifiedLMBlock (reference :43-306)."""
 
@@ -186,32 +194,40 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
 
 
 class FlamingoGPT2(FlamingoBaseModel):
+    # GPT2LMHeadModel ties lm_head to the token embedding; declared here so that save_pretrained (safetensors: no aliased tensors) writes the
+    # embedding once and from_pretrained re-ties it (transformers >= 5 refuses to save undeclared shared tensors)
+    _tied_weights_keys = {"lm_head.weight": "lm.wte.weight"}
+
     def __init__(self, config: FlamingoConfig):
         assert config.lm.startswith("gpt")
         super().__init__(config)
         base_lm = load_language_model(config)
         assert config.dim == base_lm.config.n_embd, \
             f"specified {config.dim=} in FlamingoConfig, but {config.lm} has hidden size={base_lm.config.n_embd}"
-        base_lm.resize_token_embeddings(base_lm.config.vocab_size + 1)      # one extra row for <EOC>
+        _add_eoc_row(base_lm)
         self.lm = base_lm.transformer
         self.lm_head = base_lm.lm_head
         self._init_layers(self.lm.h)
+        self.post_init()
 
     def get_modified_layers(self):
         return [layer for layer in self.lm.h if isinstance(layer, ModifiedLMBlock)]
 
 
 class FlamingoOPT(FlamingoBaseModel):
+    _tied_weights_keys = {"lm_head.weight": "lm.decoder.embed_tokens.weight"}
+
     def __init__(self, config: FlamingoConfig):
         assert config.lm.startswith("facebook/opt")
         super().__init__(config)
         base_lm = load_language_model(config)
         assert config.dim == base_lm.config.hidden_size, \
             f"specified {config.dim=} in FlamingoConfig, but {config.lm} has hidden size={base_lm.config.hidden_size}"
-        base_lm.resize_token_embeddings(base_lm.config.vocab_size + 1)
+        _add_eoc_row(base_lm)
         self.lm = base_lm.model
         self.lm_head = base_lm.lm_head
         self._init_layers(self.lm.decoder.layers)
+        self.post_init()
 
     def get_modified_layers(self):
         return [layer for layer in self.lm.decoder.layers if isinstance(layer, ModifiedLMBlock)]
@@ -337,6 +353,7 @@ class FlamingoModel(PreTrainedModel):
             self.freeze_lm()
         if config.freeze_vision_model:
             self.freeze_vm()
+        self.post_init()      # (transformers bookkeeping: the tied-weight table save_pretrained / from_pretrained use; _init_weights is a no-op)
 
     def _init_weights(self, module):
         pass

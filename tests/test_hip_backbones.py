@@ -49,27 +49,39 @@ def _batch(dtype):
     return dict(pixel_values=px, input_ids=ids, media_locations=ml, attention_mask=torch.ones_like(ids), labels=ids)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 def test_substituted_backbones_equal_stock_hf_modules(dtype):
-    from flamingo_mini_amd import FusedAdamW, GraphedTrainStep
     stock, tweaked = _build(True, dtype), _build(False, dtype)
     assert "_QuickGELU" in _names(tweaked) and "_PatchConvAsMatmul" in _names(tweaked)
     assert "_QuickGELU" not in _names(stock) and "_PatchConvAsMatmul" not in _names(stock) and "NewGELUActivation" in _names(stock)
     tweaked.load_state_dict(stock.state_dict(), strict=True)          # same parameter names: the substitutions own no parameters
     batch = _batch(dtype)
-    out_s, out_t = stock(**batch), tweaked(**batch)
+    with torch.no_grad():
+        out_s, out_t = stock(**batch), tweaked(**batch)
     # fp32: the tanh-GELU spellings and the unfolded convolution differ by rounding only; bf16: every op rounds its output to bf16, the
     # substitutions round ONCE where the stock expression rounds after each of its 3-8 elementwise kernels
     tol = 1e-5 if dtype == torch.float32 else 1.2e-2
     err = rel(out_t.logits, out_s.logits)
-    print(f"[backbones {dtype}] logits rel-L2 substituted vs stock: {err:.3e}; loss {float(out_t.loss):.6f} vs {float(out_s.loss):.6f}")
+    print(f"[backbones {dtype}] logits rel-L2 substituted vs stock: {err:.3e}; loss {float(out_t.loss):.6f} vs {float(out_s.loss):.6f}", flush=True)
     assert err < tol
     assert abs(float(out_t.loss) - float(out_s.loss)) < (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, abs(float(out_s.loss)))
-    # the same training step, eager on the stock model and replayed from a captured graph on the substituted one: losses step by step
-    params_s = [p for p in stock.parameters_trainable()]
-    params_t = [p for p in tweaked.parameters_trainable()]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_graph_replay_of_substituted_model_follows_eager_stock_model(dtype):
+    """The same training steps: eager launches on the stock model, a captured HIP graph replayed on the substituted one (what bench.py's
+    default line does): the losses must agree step by step."""
+    from flamingo_mini_amd import FusedAdamW, GraphedTrainStep
+    tweaked = _build(False, dtype)
+    batch = _batch(dtype)
+    start = {k: v.detach().clone() for k, v in tweaked.state_dict().items()}
+    opt_t = FusedAdamW(list(tweaked.parameters_trainable()), lr=1e-4, capturable=True)
+    step = GraphedTrainStep(tweaked, opt_t, batch, warmup=1)          # one eager step inside, then replays
+    losses_t = [None] + [float(step()) for _ in range(3)]
+    stock = _build(True, dtype)
+    stock.load_state_dict(start, strict=True)
+    params_s = list(stock.parameters_trainable())
     opt_s = FusedAdamW(params_s, lr=1e-4)
-    opt_t = FusedAdamW(params_t, lr=1e-4, capturable=True)
     losses_s = []
     for _ in range(4):
         for p in params_s:
@@ -78,9 +90,7 @@ def test_substituted_backbones_equal_stock_hf_modules(dtype):
         loss.backward()
         opt_s.step()
         losses_s.append(float(loss))
-    step = GraphedTrainStep(tweaked, opt_t, batch, warmup=1)          # one eager step inside, then replays
-    losses_t = [None] + [float(step()) for _ in range(3)]
-    print(f"[backbones {dtype}] loss per step, stock eager {losses_s} vs substituted graph replay {losses_t}")
+    print(f"[backbones {dtype}] loss per step, stock eager {losses_s} vs substituted graph replay {losses_t}", flush=True)
     ltol = 1e-4 if dtype == torch.float32 else 3e-2
     for a, c in zip(losses_s[1:], losses_t[1:]):
         assert abs(a - c) < ltol * max(1.0, abs(a)), (losses_s, losses_t)

@@ -29,8 +29,10 @@ DIM, DV, HEADS, DH, NV, FFM = 1280, 1024, 8, 64, 64, 4
 LAYERS = 6
 
 
-def _scalar_close(got, want, tol):
-    return abs(float(got) - float(want)) < tol * max(1.0, abs(float(want))) * 5
+# Rounding of a stored activation: a block's output x_out = x_in + delta is kept in the run's dtype, so |x_out - oracle| carries the rounding
+# of x_out itself (relative 2^-9 / sqrt(3) rms for bf16's 8 significand bits, 2^-25 / sqrt(3) for fp32) on top of the error of delta.  With
+# small gates (tanh(alpha) ~ 0.05) |delta| << |x_out| and that term dominates: it is part of the bound, not of the kernels' error.
+ROUND_RMS = {torch.bfloat16: 2.0 ** -9 / 3 ** 0.5, torch.float32: 2.0 ** -25 / 3 ** 0.5}
 
 
 def run_hoisted_chain(blocks, y, vf, ml, g):
@@ -62,14 +64,15 @@ def check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act="gelu", c
     for i, m in enumerate(blocks):
         x_in, x_out = as64(hs[i]), as64(hs[i + 1])
         out_r, _, cache = O.gated_xattn_block_fwd(x_in, vf64, ml_np, p64[i], act=act)
-        note(f"block{i}.out", rel(x_out - x_in, out_r - x_in), t["out"])
+        delta = float(np.linalg.norm(out_r - x_in))
+        note(f"block{i}.out", float(np.linalg.norm(x_out - out_r)) / delta, t["out"] + 1.5 * ROUND_RMS[dtype] * float(np.linalg.norm(out_r)) / delta)
         dy_r, dvf_r, g_r = O.gated_xattn_block_bwd(as64(hs[i + 1].grad), cache, p64[i], act=act)
         note(f"block{i}.dy", rel(hs[i].grad, dy_r), t["grad"])
         dvf_sum += dvf_r
         for k, prm in m.named_parameters():
             assert prm.grad is not None and bool(torch.isfinite(prm.grad.float()).all()), (i, k)
-            if g_r[k].size == 1:
-                assert _scalar_close(prm.grad, g_r[k], t["grad"]), (i, k, float(prm.grad), float(g_r[k]))
+            if g_r[k].size == 1:      # the gates: a sum over all b * L * dim elements, held to 5 x the tolerance like in the module tests
+                note(f"block{i}.{k}", abs(float(prm.grad) - float(g_r[k])), t["grad"] * max(1.0, abs(float(g_r[k]))) * 5)
             else:
                 note(f"block{i}.{k}", rel(prm.grad, g_r[k]), t["grad"])
     note("dvf(sum of per-block oracles)", rel(vf.grad, dvf_sum), t["grad"] * 1.5)
@@ -79,7 +82,8 @@ def check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act="gelu", c
     for i in range(len(blocks)):
         h, _, c = O.gated_xattn_block_fwd(h, vf64, ml_np, p64[i], act=act)
         caches.append(c)
-    note("chain.out", rel(as64(hs[-1]) - as64(y), h - as64(y)), t["out"] * chain_factor)
+    dtot = float(np.linalg.norm(h - as64(y)))
+    note("chain.out", float(np.linalg.norm(as64(hs[-1]) - h)) / dtot, t["out"] * chain_factor + 1.5 * ROUND_RMS[dtype] * float(np.linalg.norm(h)) / dtot)
     d, dvf = as64(g), np.zeros_like(vf64)
     for i in reversed(range(len(blocks))):
         d, dvf_i, _ = O.gated_xattn_block_bwd(d, caches[i], p64[i], act=act)
@@ -98,7 +102,7 @@ def _case(dtype, b, L, N, ml_np, tag, act="gelu"):
     ml = torch.as_tensor(ml_np).cuda()
     hs = run_hoisted_chain(blocks, y, vf, ml, g)
     worst = check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act=act)
-    print(f"[benchpath {tag} {dtype}] worst error / bound:", {k: round(v, 3) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
+    print(f"[benchpath {tag} {dtype}] worst error / bound:", {k: round(v, 3) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]}, flush=True)
     bad = {k: round(v, 3) for k, v in worst.items() if not v < 1.0}
     assert not bad, f"error / bound >= 1: {bad}"
 
@@ -144,5 +148,5 @@ def test_config_B_resampler_full_batch(dtype):
     for k, prm in m.named_parameters():
         worst[k] = rel(prm.grad, gr[k])
     bad = {k: v for k, v in worst.items() if not v < t["grad"]}
-    print(f"[benchpath resampler {dtype}] worst parameter-gradient errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    print(f"[benchpath resampler {dtype}] worst parameter-gradient errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:4], flush=True)
     assert not bad, bad

@@ -17,6 +17,12 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+#ifdef FF_DEBUG
+int dbg_switch(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#endif
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -135,7 +141,7 @@ static size_t rs_scratch_layout(const RsDims& s, void* base, size_t cap, bool bw
             L.dK = a.take(rows_kv * s.inner * s.es);
             L.dV = a.take(rows_kv * s.inner * s.es);
         }
-        static const int defer_ln = [] { const char* e = getenv("FF_DEFER_LN"); return e ? atoi(e) : 1; }();
+        static const int defer_ln = dbg_switch("FF_DEFER_LN", 1);
         const bool lnd = defer_ln != 0 && layernorm_bwd_deferrable(s.dt, s.D);
         for (int i = 0; i < 3 * s.depth + 1; i++)       // [3l] ff norm, [3l+1] norm_latents, [3l+2] norm_media of layer l; [3 depth] final norm
             o.lnp[i] = lnd ? a.take<float>(layernorm_bwd_partial_bytes(i % 3 == 2 ? s.Bn * s.F : (int)rows_q, s.D)) : nullptr;
@@ -380,8 +386,8 @@ struct XaStash {
 };
 // The ~5 us final reductions of the two LayerNorm backwards (d gamma, d beta, both gate gradients) are off the data-gradient chain as
 // well: in the deferred mode their partials stay in the stash and ff_xattn_wgrad_grouped finishes up to 8 of them with one launch.
-static bool xa_ln_deferrable(const XaDims& s) {      // FF_DEFER_LN=0: finish every LayerNorm backward on the spot (A/B timing)
-    static const int on = [] { const char* e = getenv("FF_DEFER_LN"); return e ? atoi(e) : 1; }();
+static bool xa_ln_deferrable(const XaDims& s) {      // development builds: FF_DEFER_LN=0 finishes every LayerNorm backward on the spot (A/B timing)
+    static const int on = dbg_switch("FF_DEFER_LN", 1);
     return on != 0 && layernorm_bwd_deferrable(s.dt, s.d);
 }
 static size_t xa_stash_layout(const XaDims& s, void* base, size_t cap, XaStash& o) {
@@ -444,9 +450,9 @@ static ff_attn_desc xa_attn_desc(const ff_xattn_desc& x, const XaDims& s, bool c
     return a;
 }
 
-// FF_XATTN_FUSED=0 falls back to the separate LayerNorm / projection GEMM / attention launches (debugging, A/B timing)
+// development builds: FF_XATTN_FUSED=0 falls back to the separate LayerNorm / projection GEMM / attention launches (A/B timing)
 static bool xa_fused_enabled() {
-    static const int v = [] { const char* e = getenv("FF_XATTN_FUSED"); return e ? atoi(e) : 1; }();
+    static const int v = dbg_switch("FF_XATTN_FUSED", 1);
     return v != 0;
 }
 static XaFusedArgs xa_fused_args(const ff_xattn_desc& x, const XaDims& s, bool ext_kv) {

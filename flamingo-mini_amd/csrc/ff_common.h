@@ -36,6 +36,15 @@ void set_error(const char* fmt, ...);
     } while (0)
 int check_launch(const char* what);
 
+// A/B switches of DEVELOPMENT builds (build.py --debug: -DFF_DEBUG, libflamingo_fusion_debug.so): read once from the environment.
+// The shipped library has none - dbg_switch() is the constant default there, so no environment variable can change what it computes
+// or how (no global mutable state).
+#ifdef FF_DEBUG
+int dbg_switch(const char* name, int dflt);
+#else
+constexpr int dbg_switch(const char*, int dflt) { return dflt; }
+#endif
+
 // ---- scalar conversions ------------------------------------------------------------------
 FF_DEV float to_f32(float v) { return v; }
 FF_DEV float to_f32(bf16 v) { return (float)v; }

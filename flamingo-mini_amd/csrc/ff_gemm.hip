@@ -202,6 +202,7 @@ FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const
 
 struct TileCoord {
     int z, split, tm, tn;
+    int sub_r0, sub_rows, sub_c0, sub_cols;      // the XCD sub-grid the tile belongs to (used by the L2 pre-touch to share lines)
 };
 // a / b for 0 <= a < 2^20, 0 < b: one v_rcp + fix-up instead of the ~35-instruction integer division sequence
 FF_DEV int fast_div(int a, int b) {
@@ -226,6 +227,7 @@ FF_DEV TileCoord tile_coord(int nz, int split_k, int ms, int ns, int tiles_m, in
     int p = bid;
     const int lm = __builtin_ctz(ms), ln = __builtin_ctz(ns);
     c.tm = 0; c.tn = 0;
+    c.sub_r0 = 0; c.sub_rows = tiles_m; c.sub_c0 = 0; c.sub_cols = tiles_n;
     for (int sgrid = 0; sgrid < ms * ns; sgrid++) {
         const int sm = sgrid >> ln, sn = sgrid & (ns - 1);
         const int r0 = (sm * tiles_m) >> lm, r1 = ((sm + 1) * tiles_m) >> lm;
@@ -235,6 +237,7 @@ FF_DEV TileCoord tile_coord(int nz, int split_k, int ms, int ns, int tiles_m, in
             const int q = fast_div(p, cw);
             c.tm = r0 + q;
             c.tn = c0 + p - q * cw;
+            c.sub_r0 = r0; c.sub_rows = r1 - r0; c.sub_c0 = c0; c.sub_cols = cw;
             break;
         }
         p -= cnt;
@@ -386,17 +389,48 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, cons
 // eight DMA waves instead of four, or a 4-deep ring, change nothing - the limit is the CU's outstanding-request depth times the cold
 // operands' latency, not DMA issue.
 // ------------------------------------------------------------------------------------------------
+// Staging of the B operand tile: one piece, or - BN = 160 with N the contiguous index (M-major) - a 128-column piece and a 32-column piece:
+// a 160-element k-row is 320 bytes, which no whole number of 1-KiB wave-level DMA instructions covers, 256 + 64 bytes do (4 + 1
+// instructions per wave and k-step, the same count as for the K-major tile).  Fragment reads pick the piece by their column.
+template <int BN, int BL> struct BStage {
+    static constexpr bool SPLIT = BL == 1 && BN == 160;
+    static FF_DEV void prepare(const RowMap& map, int n_base, int n_lim, int w, int l, unsigned* v) {
+        if constexpr (SPLIT) {
+            dma_prepare<128, 1>(map, n_base, n_lim, w, l, v);
+            dma_prepare<32, 1>(map, n_base + 128, n_lim, w, l, v + 4);
+        } else dma_prepare<BN, BL>(map, n_base, n_lim, w, l, v);
+    }
+    static FF_DEV void fast(__amdgpu_buffer_rsrc_t r, bf16* st, const unsigned* v, unsigned soff, int w) {
+        if constexpr (SPLIT) {
+            dma_tile_fast<128, 1>(r, st, v, soff, w);
+            dma_tile_fast<32, 1>(r, st + 128 * kBK, v + 4, soff, w);
+        } else dma_tile_fast<BN, BL>(r, st, v, soff, w);
+    }
+    static FF_DEV void slow(__amdgpu_buffer_rsrc_t r, bf16* st, const RowMap& map, int n_base, int n_lim, int k0, int k_end, int w, int l) {
+        if constexpr (SPLIT) {
+            dma_tile<128, 1>(r, st, map, n_base, n_lim, k0, k_end, w, l);
+            dma_tile<32, 1>(r, st + 128 * kBK, map, n_base + 128, n_lim, k0, k_end, w, l);
+        } else dma_tile<BN, BL>(r, st, map, n_base, n_lim, k0, k_end, w, l);
+    }
+    static FF_DEV bf16x8 frag(const bf16* s, int col0, int ks) {      // col0: wave-uniform
+        if constexpr (SPLIT) return col0 < 128 ? frag_read2<128, 1>(s, col0, ks) : frag_read2<32, 1>(s + 128 * kBK, col0 - 128, ks);
+        else return frag_read2<BN, BL>(s, col0, ks);
+    }
+};
+
 // WPC = workgroups per CU the register budget is sized for (2: <= 128 registers per lane, two 8-wave workgroups share a CU)
+// h_pf: L2 pre-touch distance in k-steps | share flag << 8 (0 = off; see touch_offset in ff_gemm_tiles.h)
 template <int BM, int BN, int AL, int BL, int NS, int WPC>
 __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
-                                                           int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
+                                                           int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, int h_pf, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
     constexpr int PER_TILE = BM / 32 + BN / 32;   // DMA instructions per producer wave per k-step
+    typedef BStage<BN, BL> BS;
     static_assert(WN % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
-    static_assert((AL == 0 || BM == 128 || BM == 64) && (BL == 0 || BN == 128 || BN == 64), "M-major staging exists for 64 / 128-wide tiles only");
+    static_assert((AL == 0 || BM == 128 || BM == 64) && (BL == 0 || BN == 128 || BN == 64 || BN == 160), "M-major staging exists for 64 / 128 / 160-wide tiles only");
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
 
     RowMap a_map{h_ald, 0, 0}, b_map{h_bld, 0, 0};
@@ -433,15 +467,35 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
         const bool full = k0 + kBK <= k_end;       // wave-uniform
         if (full && a_plain) dma_tile_fast<BM, AL>(ra, st, va, (unsigned)k0 * a_step, pw);
         else dma_tile<BM, AL>(ra, st, a_map, m_base, hM, k0, k_end, pw, l);
-        if (full && b_plain) dma_tile_fast<BN, BL>(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, pw);
-        else dma_tile<BN, BL>(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, pw, l);
+        if (full && b_plain) BS::fast(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, pw);
+        else BS::slow(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, pw, l);
     };
+    // L2 pre-touch by the MFMA waves: waves 0, 1 own the A tile's lines, waves 2, 3 the B tile's; one lane = one 128-byte line
+    const int pf_dist = h_pf & 255;
+    const int nk_full = (k_end - k_begin) / kBK;                   // only whole k-steps are touched
+    unsigned pf_voff = kOobOffset;
+    unsigned* pf_scratch = (unsigned*)(smem_raw + (size_t)NS * STAGE * sizeof(bf16)) + pw * 64;
+    const bool pf_a = pw < 2;
     if (producer) {
         dma_prepare<BM, AL>(a_map, m_base, hM, pw, l, va);
-        dma_prepare<BN, BL>(b_map, n_base, hN, pw, l, vb);
+        BS::prepare(b_map, n_base, hN, pw, l, vb);
 #pragma unroll
         for (int s = 0; s < NS - 1; s++)
             if (s < nk) issue(s);
+    } else if (pf_dist > 0 && a_plain && b_plain) {
+        // lines this workgroup has in common with its co-resident neighbours of the XCD sub-grid are shared out among them
+        constexpr int kWindow = 32 * WPC;                         // workgroups of one XCD in flight at a time
+        int share_a = 1, mine_a = 0, share_b = 1, mine_b = 0;
+        if (h_pf >> 8) {
+            share_a = min(tc.sub_cols, kWindow);                   // tiles of one row panel run side by side: they all read the same A lines
+            mine_a = (tc.tn - tc.sub_c0) % share_a;
+            share_b = max(1, min(tc.sub_rows, kWindow / max(tc.sub_cols, 1)));
+            mine_b = (tc.tm - tc.sub_r0) % share_b;
+        }
+        const int idx = (pw & 1) * 64 + l;
+        pf_voff = pf_a ? touch_offset<BM, AL>(a_map, m_base, hM, idx, share_a, mine_a) : touch_offset<BN, BL>(b_map, n_base, hN, idx, share_b, mine_b);
+        for (int tp = NS - 1; tp < min(pf_dist, nk_full); tp++)     // tiles the loop below is too late for
+            touch_issue(pf_a ? ra : rb, pf_scratch, pf_voff, (unsigned)(k_begin + tp * kBK) * (pf_a ? a_step : b_step));
     }
     FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
     if (tc.z > 0) pr = P.p[tc.z];
@@ -457,6 +511,8 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
     } else {
         for (int kt = 0; kt < nk; kt++) {
             __builtin_amdgcn_s_barrier();
+            if (pf_dist > 0 && kt + pf_dist < nk_full)
+                touch_issue(pf_a ? ra : rb, pf_scratch, pf_voff, (unsigned)(k_begin + (kt + pf_dist) * kBK) * (pf_a ? a_step : b_step));
             const bf16* sA = smem + (kt % NS) * STAGE;
             const bf16* sB = sA + A_ELEMS;
 #pragma unroll
@@ -465,13 +521,14 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
 #pragma unroll
                 for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
 #pragma unroll
-                for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, BL>(sB, wn * WN + j * 16, ks);
+                for (int j = 0; j < NT; j++) fb[j] = BS::frag(sB, wn * WN + j * 16, ks);
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
                     for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
             }
         }
+        if (pf_dist > 0) wait_vmcnt<0>();           // (the touches are pending LDS writes of this wave: drained before its memory is reused)
     }
     const int c = l & 15, g = l >> 4;
     if (Q.split_k > 1) {   // fp32 partial slab; gemm_splitk_epilogue_kernel reduces the slabs and applies the epilogue
@@ -680,7 +737,9 @@ struct ProfState {
     int cap = 0, n = 0;
     hipEvent_t* ev = nullptr;     // 2 events per record
     ff_gemm_profile_record* rec = nullptr;
-} g_prof;
+};
+// per THREAD, like ff_last_error(): a thread that enables the log records the launches it issues itself; other threads are unaffected
+thread_local ProfState g_prof;
 }
 int profile_begin(int dtype, int tile, int a_layout, int b_layout, int M, int N, int K, int nz, int split_k, hipStream_t st) {
     if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
@@ -699,17 +758,7 @@ static int prof_begin(const GemmParams& P, int dtype, int bm, hipStream_t st) {
 }
 static void prof_end(int i, hipStream_t st) { profile_end(i, st); }
 
-// FF_GEMM_TILE=64|128 forces the bf16 block tile (tuning / microbenchmarks only)
-static int g_force_tile = -1, g_force_stages = -1;
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-static int forced_tile() {
-    if (g_force_tile >= 0) return g_force_tile;
-    static const int v = env_int("FF_GEMM_TILE", 0);
-    return v;
-}
+static int env_int(const char* name, int dflt) { return dbg_switch(name, dflt); }      // development builds only (ff_common.h)
 
 // Block tile and split-K factor for a bf16 problem.  Measured on MI355X (tools/gemm_bench.py --sweep): a k-step's cost
 // is the L2 -> LDS traffic of its operand tiles, so 128x128 (64 FLOP/B) beats 64x64 (32 FLOP/B) whenever it can put
@@ -718,11 +767,13 @@ static int forced_tile() {
 // 43.74 ms/step): no split for the small 64-tile GEMMs +0.5 ms, one-workgroup-per-CU split counts +0.7 ms, no 64x128 rule +0.5 ms -
 // in-model the operands arrive cold from HBM and more workgroups in flight hide that better than isolated timings suggest.
 struct TilePlan { int tile, split; };
-static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_layout = 0, int b_layout = 0) {
+static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_layout = 0, int b_layout = 0, int ft = 0) {
     const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;
     TilePlan p;
-    const int ft = forced_tile();
-    const bool pc_ok = a_layout == 0 && b_layout == 0;       // the producer / consumer kernel stages K-major operands only
+    if (ft == 0) ft = env_int("FF_GEMM_TILE", 0);
+    // the 128 x 160 producer / consumer kernel needs a K-major A operand; B may be K-major or (split staging) N-contiguous
+    static const int pc_bl1 = env_int("FF_GEMM_PC_BL1", 1);
+    const bool pc_ok = a_layout == 0 && (b_layout == 0 || (pc_bl1 && N % 8 == 0));
     if (ft == 128 || ft == 64 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
@@ -735,6 +786,7 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     // but 2-3 workgroups per CU) measured 10-25 % faster there when A is row-major (sweep in tools/gemm_bench.py)
     // one 128 x 160 tile per CU (producer / consumer kernel) when that grid, times a small split-K, lands on 224..256 workgroups
     static const int pc_on = env_int("FF_GEMM_PC", 1);
+    if (ft == 128160 && !pc_ok) ft = 0;
     const long long t160 = (long long)cdiv(M, 128) * cdiv(N, 160) * nz;
     int pc_split = 0;
     if (pc_on && pc_ok && N % 160 == 0 && K % 64 == 0 && t160 <= 256)

@@ -153,10 +153,10 @@ static int adamw_launch(const ff_adamw_desc* d, int state_dtype, void* const* pa
         if (d->dtype == FF_DTYPE_F32) adamw_kernel<float, float, false, 4><<<grid, block, 0, stream>>>(t);
         else if (master) {
             FF_CHECK(state_dtype == FF_DTYPE_F32, FF_ERR_UNSUPPORTED, "ff_adamw_step: fp32 master copies go with fp32 moments");
-            adamw_kernel<bf16, float, true, 8><<<grid, block, 0, stream>>>(t);
-        } else if (state_dtype == FF_DTYPE_F32) adamw_kernel<bf16, float, false, 8><<<grid, block, 0, stream>>>(t);
+            adamw_kernel<bf16, float, true, 8, 1><<<grid, block, 0, stream>>>(t);       // (master copy, gradients, moments: streamed nontemporally)
+        } else if (state_dtype == FF_DTYPE_F32) adamw_kernel<bf16, float, false, 8, 1><<<grid, block, 0, stream>>>(t);
         else {
-            static const int mode = [] { const char* e = getenv("FF_ADAMW_MODE"); return e ? atoi(e) : 1; }();
+            static const int mode = dbg_switch("FF_ADAMW_MODE", 1);
             if (mode >= 1) adamw_kernel<bf16, bf16, false, 8, 1><<<grid, block, 0, stream>>>(t);
             else adamw_kernel<bf16, bf16, false, 8><<<grid, block, 0, stream>>>(t);
         }

@@ -60,7 +60,7 @@ def test_substituted_backbones_equal_stock_hf_modules(dtype):
         out_s, out_t = stock(**batch), tweaked(**batch)
     # fp32: the tanh-GELU spellings and the unfolded convolution differ by rounding only; bf16: every op rounds its output to bf16, the
     # substitutions round ONCE where the stock expression rounds after each of its 3-8 elementwise kernels
-    tol = 1e-5 if dtype == torch.float32 else 1.2e-2
+    tol = 1e-5 if dtype == torch.float32 else 2e-2      # measured 1.4e-6 / 1.14e-2
     err = rel(out_t.logits, out_s.logits)
     print(f"[backbones {dtype}] logits rel-L2 substituted vs stock: {err:.3e}; loss {float(out_t.loss):.6f} vs {float(out_s.loss):.6f}", flush=True)
     assert err < tol

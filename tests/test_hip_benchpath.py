@@ -65,14 +65,20 @@ def check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act="gelu", c
         x_in, x_out = as64(hs[i]), as64(hs[i + 1])
         out_r, _, cache = O.gated_xattn_block_fwd(x_in, vf64, ml_np, p64[i], act=act)
         delta = float(np.linalg.norm(out_r - x_in))
-        note(f"block{i}.out", float(np.linalg.norm(x_out - out_r)) / delta, t["out"] + 1.5 * ROUND_RMS[dtype] * float(np.linalg.norm(out_r)) / delta)
-        dy_r, dvf_r, g_r = O.gated_xattn_block_bwd(as64(hs[i + 1].grad), cache, p64[i], act=act)
+        # (two stored activations of magnitude |x| sit between x_in and x_out: y1 and the output itself)
+        note(f"block{i}.out", float(np.linalg.norm(x_out - out_r)) / delta, t["out"] + 2.5 * ROUND_RMS[dtype] * float(np.linalg.norm(out_r)) / delta)
+        dy2 = as64(hs[i + 1].grad)
+        dy_r, dvf_r, g_r = O.gated_xattn_block_bwd(dy2, cache, p64[i], act=act)
+        # the two gate gradients are dot products over all b * L * dim elements, (1 - tanh^2 alpha) * sum(d branch_sum .* branch): their error is
+        # held to the tolerance times the natural scale of such a sum, || a .* b ||_2 (cache[2] = attn_out, cache[3] = ffw_out of the oracle)
+        gate_scale = {"alpha_ffw": float(np.linalg.norm(dy2 * cache[3])) * float(1.0 - cache[5][0] ** 2),
+                      "alpha_attn": float(np.linalg.norm(dy_r * cache[2])) * float(1.0 - cache[4][0] ** 2)}
         note(f"block{i}.dy", rel(hs[i].grad, dy_r), t["grad"])
         dvf_sum += dvf_r
         for k, prm in m.named_parameters():
             assert prm.grad is not None and bool(torch.isfinite(prm.grad.float()).all()), (i, k)
-            if g_r[k].size == 1:      # the gates: a sum over all b * L * dim elements, held to 5 x the tolerance like in the module tests
-                note(f"block{i}.{k}", abs(float(prm.grad) - float(g_r[k])), t["grad"] * max(1.0, abs(float(g_r[k]))) * 5)
+            if g_r[k].size == 1:
+                note(f"block{i}.{k}", abs(float(prm.grad) - float(g_r[k])), t["grad"] * max(gate_scale[k], 1e-30))
             else:
                 note(f"block{i}.{k}", rel(prm.grad, g_r[k]), t["grad"])
     note("dvf(sum of per-block oracles)", rel(vf.grad, dvf_sum), t["grad"] * 1.5)
@@ -94,7 +100,7 @@ def check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act="gelu", c
 
 
 def _case(dtype, b, L, N, ml_np, tag, act="gelu"):
-    blocks = [build_block(xattn_params(DIM, DV, HEADS, DH, FFM, alpha_attn=0.5 - 0.1 * i, alpha_ffw=-0.4 + 0.15 * i, tag=f"{tag}{i}"),
+    blocks = [build_block(xattn_params(DIM, DV, HEADS, DH, FFM, alpha_attn=0.5 - 0.05 * i, alpha_ffw=-0.4 - 0.06 * i, tag=f"{tag}{i}"),
                           DIM, DV, HEADS, DH, NV, FFM, act, dtype) for i in range(LAYERS)]
     y = dev(det((b, L, DIM), tag + "y"), dtype).requires_grad_(True)
     vf = dev(det((b, N, NV, DV), tag + "vf"), dtype).requires_grad_(True)

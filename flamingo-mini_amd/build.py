@@ -37,9 +37,13 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, debug: bool = False) -> str:
+    """debug=True: the development build libflamingo_fusion_debug.so (-DFF_DEBUG: A/B switches read from the environment), selected with
+    FLAMINGO_FUSION_LIB=debug; the shipped library reads no environment variable."""
     hipcc = _hipcc()
-    obj_dir = os.path.join(CSRC, "_obj")
+    obj_dir = os.path.join(CSRC, "_obj_debug" if debug else "_obj")
+    lib_path = LIB_PATH.replace(".so", "_debug.so") if debug else LIB_PATH
+    flags = FLAGS + (["-DFF_DEBUG"] if debug else [])
     os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
@@ -51,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + flags + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-4000:]}")
@@ -62,14 +66,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         list(ex.map(compile_one, jobs))
     objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB_PATH, objs):
-        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs, capture_output=True, text=True)
+    if force or jobs or _stale(lib_path, objs):
+        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
         if verbose:
-            print("linked", LIB_PATH)
-    return LIB_PATH
+            print("linked", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, debug="--debug" in sys.argv))

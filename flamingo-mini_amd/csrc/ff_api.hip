@@ -715,7 +715,7 @@ static int kv_project_bwd(const ff_kvproj_desc* d, const void* vf, const void* c
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
-extern "C" int ff_version(void) { return 2; }
+extern "C" int ff_version(void) { return 3; }
 extern "C" const char* ff_arch(void) { return "gfx950"; }
 extern "C" const char* ff_last_error(void) { return ff::g_err; }
 

@@ -767,10 +767,12 @@ static int env_int(const char* name, int dflt) { return dbg_switch(name, dflt); 
 // 43.74 ms/step): no split for the small 64-tile GEMMs +0.5 ms, one-workgroup-per-CU split counts +0.7 ms, no 64x128 rule +0.5 ms -
 // in-model the operands arrive cold from HBM and more workgroups in flight hide that better than isolated timings suggest.
 struct TilePlan { int tile, split; };
+constexpr int kPrefetchDist = 0;      // default L2 pre-touch distance (k-steps ahead of the MFMA waves); 0 = off
 static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_layout = 0, int b_layout = 0, int ft = 0) {
     const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;
     TilePlan p;
-    if (ft == 0) ft = env_int("FF_GEMM_TILE", 0);
+    static const int env_tile = env_int("FF_GEMM_TILE", 0);
+    if (ft == 0) ft = env_tile;
     // the 128 x 160 producer / consumer kernel needs a K-major A operand; B may be K-major or (split staging) N-contiguous
     static const int pc_bl1 = env_int("FF_GEMM_PC_BL1", 1);
     const bool pc_ok = a_layout == 0 && (b_layout == 0 || (pc_bl1 && N % 8 == 0));
@@ -786,7 +788,6 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     // but 2-3 workgroups per CU) measured 10-25 % faster there when A is row-major (sweep in tools/gemm_bench.py)
     // one 128 x 160 tile per CU (producer / consumer kernel) when that grid, times a small split-K, lands on 224..256 workgroups
     static const int pc_on = env_int("FF_GEMM_PC", 1);
-    if (ft == 128160 && !pc_ok) ft = 0;
     const long long t160 = (long long)cdiv(M, 128) * cdiv(N, 160) * nz;
     int pc_split = 0;
     if (pc_on && pc_ok && N % 160 == 0 && K % 64 == 0 && t160 <= 256)
@@ -811,7 +812,6 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     if (pc128 >= 2 && p.tile == 6412) p.tile = 128002;         // ... and instead of the 64 x 128 tiles (1: keep those)
     return p;
 }
-static bool big_tile(const GemmParams& P) { return P.tile == 128; }
 
 template <int BM, int BN, int AL, int BL, int NS> static int launch_bf16_dma(const GemmParams& P, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
@@ -842,7 +842,7 @@ template <int BM, int BN> static int run_bf16_dma_tile(const GemmParams& P, int 
     return ns == 2 ? dispatch_bf16_dma<BM, BN, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<BM, BN, 4>(P, st) : dispatch_bf16_dma<BM, BN, 3>(P, st);
 }
 template <int BM, int BN, int AL, int BL, int NS, int WPC> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
+    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16) + 1024;      // + the pre-touch scratch words (4 MFMA waves x 64 lanes)
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -855,7 +855,7 @@ template <int BM, int BN, int AL, int BL, int NS, int WPC> static int launch_bf1
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
     gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC><<<dim3(grid), dim3(512), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
                                                                                  P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
-                                                                                 (int)P.b_map.ld, seg, P);
+                                                                                 (int)P.b_map.ld, seg, P.prefetch, P);
     return check_launch("gemm_bf16_pc");
 }
 // 128 x 128 tiles, two 8-wave workgroups per CU (experiment: FF_GEMM_TILE=128002 / FF_GEMM_PC128=1)
@@ -869,10 +869,11 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     static const int ns_env = env_int("FF_GEMM_STAGES", 0);
     // default 2 stages: 64 KiB (128x128) / 16 KiB (64x64) per workgroup, so several workgroups per CU overlap each other's
     // DMA-issue and barrier stalls - measured faster than deeper rings at lower occupancy (tools/gemm_bench.py --sweep)
-    const int ns = g_force_stages > 0 ? g_force_stages : ns_env > 0 ? ns_env : 2;
+    const int ns = P.force_stages > 0 ? P.force_stages : ns_env > 0 ? ns_env : 2;
     if (P.tile == 128160) {      // 3 stages (108 KiB) by default: one workgroup per CU, so the ring has to cover the DMA latency by itself
-        const int pns = g_force_stages > 0 ? g_force_stages : ns_env > 0 ? ns_env : 3;
-        return pns == 4 ? launch_bf16_pc<128, 160, 0, 0, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 0, 3, 1>(P, st);      // (2 stages would not hold the parked fp32 tile)
+        const int pns = P.force_stages > 0 ? P.force_stages : ns_env > 0 ? ns_env : 3;      // (2 stages would not hold the parked fp32 tile)
+        if (P.b_layout == 0) return pns == 4 ? launch_bf16_pc<128, 160, 0, 0, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 0, 3, 1>(P, st);
+        return pns == 4 ? launch_bf16_pc<128, 160, 0, 1, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 1, 3, 1>(P, st);
     }
     if (P.tile == 128002) return dispatch_bf16_pc128<2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
@@ -901,9 +902,12 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
              P.M, P.N, P.K, P.nz);
     P.tile = kFBM;
     if (dtype == FF_DTYPE_BF16) {
-        const TilePlan plan = plan_bf16(P.M, P.N, P.K, P.nz, P.split_k, P.a_layout, P.b_layout);
+        const TilePlan plan = plan_bf16(P.M, P.N, P.K, P.nz, P.split_k, P.a_layout, P.b_layout, P.force_tile);
         P.tile = plan.tile;
         P.split_k = plan.split;
+        // L2 pre-touch of the producer / consumer kernels: distance in k-steps | share flag << 8 (ff_gemm_tiles.h)
+        static const int pf_dist = env_int("FF_GEMM_PF", kPrefetchDist), pf_share = env_int("FF_GEMM_PF_SHARE", 1);
+        P.prefetch = pf_dist > 0 ? (std::min(pf_dist, 255) | (pf_share ? 256 : 0)) : 0;
     } else if (P.split_k <= 0) P.split_k = gemm_pick_split(dtype, P.M, P.N, P.K, P.nz);
     const int kq = dtype == FF_DTYPE_BF16 ? kBK : kFBK;
     P.k_per_split = cdiv(cdiv(P.K, P.split_k), kq) * kq;
@@ -985,7 +989,9 @@ extern "C" int ff_debug_timeline_read(unsigned long long* out, int n_blocks) {
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" size_t ff_gemm_workspace_bytes(const ff_gemm_desc* d) {
-    return ff::gemm_workspace_bytes(d->dtype, d->M, d->N, d->K, 1, d->split_k);
+    int split = d->split_k;
+    if (split <= 0 && d->tile > 0 && d->dtype == FF_DTYPE_BF16) split = ff::plan_bf16(d->M, d->N, d->K, 1, 0, d->a_layout, d->b_layout, d->tile).split;
+    return ff::gemm_workspace_bytes(d->dtype, d->M, d->N, d->K, 1, split);
 }
 
 extern "C" int ff_gemm(const ff_gemm_desc* d, const void* A, const void* B, void* C, void* aux_out, const void* aux_in,
@@ -999,6 +1005,7 @@ extern "C" int ff_gemm(const ff_gemm_desc* d, const void* A, const void* B, void
     P.a_layout = d->a_layout; P.b_layout = d->b_layout;
     P.a_map = make_rowmap(d->a_map); P.b_map = make_rowmap(d->b_map); P.c_map = make_rowmap(d->c_map); P.r_map = P.c_map;
     P.scale = d->scale; P.act = d->act; P.act_bwd = d->act_bwd; P.split_k = d->split_k;
+    P.force_tile = d->tile; P.force_stages = d->stages;
     P.nz = 1;
     P.p[0] = GemmProblem{A, B, C, aux_out, aux_in, residual, gate};
     return gemm_launch(P, d->dtype, workspace, workspace_bytes, (hipStream_t)stream);
@@ -1036,16 +1043,11 @@ extern "C" int ff_gemm_profile_read(ff_gemm_profile_record* out, int max_records
     return n;
 }
 
-extern "C" void ff_gemm_set_tuning(int tile, int stages) {   /* tuning / microbenchmarks: 0 = automatic */
-    ff::g_force_tile = tile > 0 ? tile : -1;
-    ff::g_force_stages = stages > 0 ? stages : -1;
-}
-
 extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_k) {   /* introspection: the tile / split-K the launcher would use */
     using namespace ff;
     FF_CHECK(d && bm && bn && split_k, FF_ERR_SHAPE, "ff_gemm_plan: null argument");
     if (d->dtype == FF_DTYPE_BF16) {
-        const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout);
+        const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout, d->tile);
         *bm = p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : 64;
         *bn = p.tile == 64 ? 64 : p.tile == 128160 ? 160 : 128;
         *split_k = p.split;

@@ -12,8 +12,11 @@ from typing import Optional, Sequence
 import torch
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion.so")
-ABI_VERSION = 2
+# FLAMINGO_FUSION_LIB: "debug" = the development build next to the shipped library (build.py --debug: -DFF_DEBUG, the only build whose
+# kernels' A/B switches read the environment), or a path; default = the shipped library
+_which = os.environ.get("FLAMINGO_FUSION_LIB", "")
+LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion_debug.so") if _which == "debug" else (_which or os.path.join(PKG_DIR, "libflamingo_fusion.so"))
+ABI_VERSION = 3
 
 FF_OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -39,7 +42,7 @@ def rowmap(ld: int, seg_stride: int = 0, rows_per_seg: int = 0) -> RowMap:
 class GemmDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_layout", C.c_int), ("b_layout", C.c_int),
                 ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap), ("scale", C.c_float), ("act", C.c_int), ("act_bwd", C.c_int),
-                ("split_k", C.c_int)]
+                ("split_k", C.c_int), ("tile", C.c_int), ("stages", C.c_int)]
 
 
 class GemmProfileRecord(C.Structure):
@@ -99,7 +102,6 @@ _SIGNATURES = {
     "ff_gemm": (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ff_gemm_profile_enable": (_I, [_I]),
     "ff_gemm_profile_read": (_I, [C.POINTER(GemmProfileRecord), _I]),
-    "ff_gemm_set_tuning": (None, [_I, _I]),
     "ff_gemm_plan": (_I, [C.POINTER(GemmDesc), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "ff_layernorm_fwd": (_I, [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "ff_layernorm_bwd_workspace_bytes": (_SZ, [C.POINTER(LnDesc)]),

@@ -546,7 +546,7 @@ def shifted_cross_entropy(logits: torch.Tensor, labels: torch.Tensor, reduction:
 # primitive wrappers (parity tests / micro-benchmarks): thin, allocation + one C call each
 # ----------------------------------------------------------------------------------------------------
 def gemm(A, B, *, a_layout=0, b_layout=0, scale=1.0, act=None, act_bwd=None, aux_in=None, residual=None, gate=None,
-         want_aux_out=False, split_k=0):
+         want_aux_out=False, split_k=0, tile=0, stages=0):
     lib = ffi.lib()
     ffi.require_cuda(A, B)
     M, K = (A.shape if a_layout == 0 else A.shape[::-1])
@@ -554,7 +554,7 @@ def gemm(A, B, *, a_layout=0, b_layout=0, scale=1.0, act=None, act_bwd=None, aux
     C_ = torch.empty((M, N), dtype=A.dtype, device=A.device)
     aux_out = torch.empty_like(C_) if want_aux_out else None
     d = ffi.GemmDesc(ffi.dtype_code(A.dtype), M, N, K, a_layout, b_layout, ffi.rowmap(A.stride(0)), ffi.rowmap(B.stride(0)),
-                     ffi.rowmap(N), float(scale), ffi.ACTS.get(act, ffi.ACT_NONE), ffi.ACTS.get(act_bwd, ffi.ACT_NONE), split_k)
+                     ffi.rowmap(N), float(scale), ffi.ACTS.get(act, ffi.ACT_NONE), ffi.ACTS.get(act_bwd, ffi.ACT_NONE), split_k, tile, stages)
     ws = _empty_bytes(lib.ff_gemm_workspace_bytes(d), A.device)
     ffi.check(lib.ff_gemm(d, A.data_ptr(), B.data_ptr(), C_.data_ptr(), ffi.ptr(aux_out), ffi.ptr(aux_in), ffi.ptr(residual), ffi.ptr(gate),
                           ws.data_ptr(), ws.numel(), ffi.stream_handle(A.device)), "ff_gemm")

@@ -5,9 +5,10 @@
  * sizes and a HIP stream; no torch / C++ types; kernels are enqueued on the caller's stream and never
  * synchronise or allocate.  All tensors are caller-owned, 16-byte aligned, innermost dimension contiguous.
  * Return value: FF_OK or a negative error code; ff_last_error() gives a thread-local message.
- * State: the compute entry points keep none between calls and may be used from several threads on distinct streams / buffers.
- * The two debugging aids ff_gemm_profile_* and ff_gemm_set_tuning are process-global switches (measurement, tile sweeps) and are NOT
- * thread-safe: use them from one thread, with no other call in flight.
+ * State: none that is shared.  The entry points may be used from several threads on distinct streams / buffers; no environment variable is
+ * read (the A/B switches of development builds exist only under -DFF_DEBUG, build.py --debug); every plan override travels in a
+ * descriptor (ff_gemm_desc.split_k / tile / stages).  Two things are kept per THREAD, like errno: the ff_last_error() message and the
+ * launch-timing log of ff_gemm_profile_* (a thread that enables it records the launches it issues itself).
  *
  * What each entry point replaces in the reference (dhansmair/flamingo-mini, paths relative to its root):
  *   ff_resampler_fwd/bwd     PerceiverResampler.forward + its autograd   flamingo_mini/perceiver_resampler.py:143-188
@@ -36,7 +37,7 @@ enum { FF_OK = 0, FF_ERR_SHAPE = -1, FF_ERR_UNSUPPORTED = -2, FF_ERR_WORKSPACE =
 enum { FF_DTYPE_F32 = 0, FF_DTYPE_BF16 = 1 };
 enum { FF_ACT_NONE = -1, FF_ACT_GELU = 0, FF_ACT_SQRELU = 1, FF_ACT_RELU = 2 }; /* utils.py:26-30 */
 
-int ff_version(void);          /* ABI version, bumped on any signature change */
+int ff_version(void);          /* ABI version, bumped on any signature change (3: ff_gemm_desc.tile / .stages replace ff_gemm_set_tuning) */
 const char* ff_arch(void);     /* "gfx950" */
 const char* ff_last_error(void);
 
@@ -71,6 +72,9 @@ typedef struct ff_gemm_desc {
     int act;      /* FF_ACT_* or FF_ACT_NONE */
     int act_bwd;  /* FF_ACT_* or FF_ACT_NONE */
     int split_k;  /* 0 = choose automatically */
+    int tile;     /* bf16 block tile: 0 = choose automatically; 128 = 128x128 (4 waves), 6412 = 64x128, 64 = 64x64,
+                   * 128002 = 128x128 producer/consumer (8 waves), 128160 = 128x160 producer/consumer (A K-major only) */
+    int stages;   /* depth of the LDS operand ring: 0 = default, 2..4 */
 } ff_gemm_desc;
 
 size_t ff_gemm_workspace_bytes(const ff_gemm_desc* d);
@@ -88,9 +92,6 @@ typedef struct ff_gemm_profile_record {
 } ff_gemm_profile_record;
 int ff_gemm_profile_enable(int max_records);
 int ff_gemm_profile_read(ff_gemm_profile_record* out, int max_records);
-/* Tuning aid: force the bf16 block tile (128 = 128x128, 6412 = 64x128, 64 = 64x64; 0 = automatic) and the LDS ring depth
- * (2..4; 0 = default 2). */
-void ff_gemm_set_tuning(int tile, int stages);
 /* Introspection: block tile and split-K factor ff_gemm would choose for this problem (no device access). */
 int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_k);
 
@@ -182,6 +183,12 @@ int ff_attention_bwd(const ff_attn_desc* d, const void* Q, const void* K, const 
  *   +8 layers.i.1.0.weight  +9 layers.i.1.0.bias  +10 layers.i.1.1.weight  +11 layers.i.1.3.weight
  * `saved` persists fwd -> bwd (activations, statistics); `scratch` is transient.
  * bwd writes every gradient (no accumulation); dx_f may be NULL (CLIP frozen) — d time_pos_emb is still exact.
+ * Deviation from SURVEY.md 8-b2's minimum export set (ff_resampler_layer_fwd/bwd + ff_resampler_prologue/epilogue_*): the resampler is
+ * exported as the whole stack, like the reference's own call site (modeling_flamingo.py:176 calls the module once).  Only the stack-level
+ * call can share the statistics of x_f + time_pos_emb between the `depth` norm_media LayerNorms, group the weight gradients of four layers
+ * per launch and finish all 3 * depth + 1 LayerNorm-backward reductions with three launches; a per-layer ABI would fix the launch
+ * structure at one layer per call.  The pieces a per-layer caller would need are exported individually (ff_gemm, ff_layernorm_*,
+ * ff_attention_*, ff_rows_reduce) and parity-tested on their own.
  * ------------------------------------------------------------------------------------------------------ */
 #define FF_RESAMPLER_GLOBAL_PARAMS 4
 #define FF_RESAMPLER_LAYER_PARAMS 12

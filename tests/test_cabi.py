@@ -172,10 +172,10 @@ def test_gemm_plan_for_the_benchmark_shapes():
         return bm.value, bn.value, sk.value
 
     assert plan(1024, 5120, 1280) == (128, 160, 1)           # FFW up-projection: 8 x 32 tiles of 128 x 160 = one per CU (producer / consumer kernel)
-    assert plan(1024, 5120, 1280, 0, 1) == (128, 128, 1)     # the same shape with an M-major weight (FFW2 dgrad): 320 tiles of 128^2, two 8-wave workgroups per CU
+    assert plan(1024, 5120, 1280, 0, 1) == (128, 160, 1)     # the same shape with an N-contiguous weight (FFW2 dgrad): the same grid, the B tile staged as 128 + 32 columns
     assert plan(1280, 5120, 1024, 1, 1) == (128, 128, 1)     # its weight gradient (transposed A): 400 tiles of 128^2
     assert plan(1024, 1280, 5120) == (128, 160, 4)           # FFW down-projection: 64 tiles x split-K 4 = 256 workgroups
-    assert plan(1024, 1280, 5120, 0, 1) == (128, 128, 5)     # FFW1 dgrad: 80 output tiles of 128^2, long K -> split-K 5
+    assert plan(1024, 1280, 5120, 0, 1) == (128, 160, 4)     # FFW1 dgrad: 64 tiles x split-K 4
     assert plan(1024, 512, 1280) == (64, 64, 2)              # q projection: small, 64^2 tiles + 2 splits
     assert plan(4096, 4096, 4096) == (128, 128, 1)
     bm, bn, sk = plan(512, 1024, 10272, 1, 1)                # resampler dWk/dWv: 32 tiles, K = 10272

@@ -29,24 +29,19 @@ def test_gemm_layouts(dtype, al, bl, M, N, K):
 
 @pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_every_instantiated_tile(al, bl):
-    """Force each bf16 block tile (ff_gemm_set_tuning) on a ragged problem: partial tiles in M and N, a K tail, split-K."""
-    from flamingo_mini_amd import ffi
+    """Force each bf16 block tile (ff_gemm_desc.tile / .stages) on a ragged problem: partial tiles in M and N, a K tail, split-K."""
     M, N, K = 408, 424, 328
     A = dev(rnd((M, K) if al == 0 else (K, M), 11), torch.bfloat16)
     B = dev(rnd((N, K) if bl == 0 else (K, N), 12), torch.bfloat16)
     a, b = as64(A), as64(B)
     ref = (a if al == 0 else a.T) @ (b.T if bl == 0 else b)
-    lib = ffi.lib()
-    try:
-        # 128002 / 128160: the 8-wave producer / consumer kernel (128 x 128 for every layout, 128 x 160 for K-major operands)
-        for tile in (128, 6412, 64, 128002) + ((128160,) if (al, bl) == (0, 0) else ()):
-            for stages in (2, 3, 4):
-                lib.ff_gemm_set_tuning(tile, stages)
-                for split in (1, 2):
-                    C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split)
-                    assert rel(C, ref) < 1e-2, (tile, stages, split)
-    finally:
-        lib.ff_gemm_set_tuning(0, 0)
+    # 128002 / 128160: the 8-wave producer / consumer kernels (128 x 128 for every layout; 128 x 160 for a K-major A operand, B K-major or -
+    # staged as a 128-column and a 32-column piece - N-contiguous)
+    for tile in (128, 6412, 64, 128002) + ((128160,) if al == 0 else ()):
+        for stages in (2, 3, 4):
+            for split in (1, 2):
+                C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)
+                assert rel(C, ref) < 1e-2, (tile, stages, split)
 
 
 def test_gemm_balanced_producer_consumer_tile():
@@ -64,24 +59,27 @@ def test_gemm_balanced_producer_consumer_tile():
     A, B, R = dev(rnd((1024, 5120), 23, 0.5), dt), dev(rnd((1280, 5120), 24, 0.02), dt), dev(rnd((1024, 1280), 25), dt)
     C = F().gemm(A, B, residual=R, gate=gate)
     assert rel(C, as64(R) + g * (as64(A) @ as64(B).T)) < TOL[dt]["out"]
-    lib = ffi.lib()
-    try:
-        lib.ff_gemm_set_tuning(128160, 0)
-        M, N, K = 200, 336, 1096
-        A, B = dev(rnd((M, K), 26, 0.5), dt), dev(rnd((N, K), 27, 0.05), dt)
-        R, H = dev(rnd((M, N), 28), dt), dev(rnd((M, N), 29), dt)
-        acc, r, h = as64(A) @ as64(B).T, as64(R), as64(H)
+    M, N, K = 200, 336, 1096
+    R, H = dev(rnd((M, N), 28), dt), dev(rnd((M, N), 29), dt)
+    A = dev(rnd((M, K), 26, 0.5), dt)
+    for bl in (0, 1):        # B K-major, and N-contiguous (the data gradients dY . W: the 160-wide tile staged as 128 + 32 columns)
+        B = dev(rnd((N, K) if bl == 0 else (K, N), 27, 0.05), dt)
+        acc, r, h = as64(A) @ (as64(B).T if bl == 0 else as64(B)), as64(R), as64(H)
+        kw = dict(b_layout=bl, tile=128160)
         for split_k in (1, 3):
             for act in ("gelu", "sqrelu", "relu"):
-                C, aux = F().gemm(A, B, act=act, want_aux_out=True, split_k=split_k)
+                C, aux = F().gemm(A, B, act=act, want_aux_out=True, split_k=split_k, **kw)
                 assert rel(aux, acc) < TOL[dt]["out"] and rel(C, O.act_fwd(acc, act)) < TOL[dt]["out"]
-                C = F().gemm(A, B, act_bwd=act, aux_in=H, gate=gate, split_k=split_k)
+                C = F().gemm(A, B, act_bwd=act, aux_in=H, gate=gate, split_k=split_k, **kw)
                 assert rel(C, acc * g * O.act_bwd(np.ones_like(h), h, act)) < TOL[dt]["out"]
-            C = F().gemm(A, B, residual=R, gate=gate, split_k=split_k)
+            C = F().gemm(A, B, residual=R, gate=gate, split_k=split_k, **kw)
             assert rel(C, r + g * acc) < TOL[dt]["out"]
-            assert rel(F().gemm(A, B, scale=0.25, split_k=split_k), 0.25 * acc) < TOL[dt]["out"]
-    finally:
-        lib.ff_gemm_set_tuning(0, 0)
+            assert rel(F().gemm(A, B, scale=0.25, split_k=split_k, **kw), 0.25 * acc) < TOL[dt]["out"]
+    # the data-gradient shapes the planner now hands to it: d H = d y2 . W3 (1024 x 5120 x 1280) and d xn = d H . W1 (1024 x 1280 x 5120, split-K)
+    A, B = dev(rnd((1024, 1280), 31, 0.5), dt), dev(rnd((1280, 5120), 32, 0.05), dt)
+    assert rel(F().gemm(A, B, b_layout=1), as64(A) @ as64(B)) < TOL[dt]["out"]
+    A, B = dev(rnd((1024, 5120), 33, 0.5), dt), dev(rnd((5120, 1280), 34, 0.02), dt)
+    assert rel(F().gemm(A, B, b_layout=1), as64(A) @ as64(B)) < TOL[dt]["out"]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

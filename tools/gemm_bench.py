@@ -69,16 +69,14 @@ def main():
         fl = 2.0 * M * N * K
         cells = []
         for tile, stages, split in configs:
-            lib.ff_gemm_set_tuning(tile, stages)
             it = [0]
 
             def run():
                 i = it[0] % ncopy
                 it[0] += 1
-                F.gemm(As[i], Bs[i], a_layout=al, b_layout=bl, split_k=split)
+                F.gemm(As[i], Bs[i], a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)
             us, t_used, s_used = gpu_us(run, args.iters)
             cells.append(f"{us:5.1f}/{fl / us / 1e6:4.0f}TF".rjust(12))
-        lib.ff_gemm_set_tuning(0, 0)
         a2 = As[0] if al == 0 else As[0].t()
         b2 = Bs[0].t() if bl == 0 else Bs[0]
         ref = wall_us(lambda: torch.matmul(a2, b2), args.iters)

@@ -8,7 +8,6 @@ from flamingo_mini_amd import ffi, functional as F
 from gemm_bench import gpu_us
 
 lib = ffi.lib()
-lib.ff_gemm_set_tuning(128, 2)
 for al, bl in ((0, 0), (1, 1), (0, 1)):
     print(f"layouts {al}{bl}: rows = tile grid (MxN tiles of 128), columns = K; cell = us")
     Ks = (64, 128, 256, 512, 1024, 2048, 4096)
@@ -19,6 +18,6 @@ for al, bl in ((0, 0), (1, 1), (0, 1)):
         for K in Ks:
             A = torch.randn((M, K) if al == 0 else (K, M), device="cuda", dtype=torch.bfloat16)
             B = torch.randn((N, K) if bl == 0 else (K, N), device="cuda", dtype=torch.bfloat16)
-            us, _, _ = gpu_us(lambda: F.gemm(A, B, a_layout=al, b_layout=bl, split_k=1), 12)
+            us, _, _ = gpu_us(lambda: F.gemm(A, B, a_layout=al, b_layout=bl, split_k=1, tile=128, stages=2), 12)
             cells.append(f"{us:7.1f}")
         print(f"  {tm:2d}x{tn:2d} {tm * tn:6d} | " + " ".join(cells))

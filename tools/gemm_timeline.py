@@ -26,10 +26,9 @@ CASES = [("tiny 4x8 K=64", 512, 1024, 64, 0, 0, 128, 1, 2), ("4x8 K=1024", 512, 
          ("xa.kv.fwd 128 ns3", 2048, 1024, 1024, 0, 0, 128, 1, 3),
          ("xa.q.wgrad 64 s2", 512, 1280, 1024, 1, 1, 64, 2, 2), ("xa.q.wgrad 64 s2 ns4", 512, 1280, 1024, 1, 1, 64, 2, 4)]
 for name, M, N, K, al, bl, tile, split, stages in CASES:
-    lib.ff_gemm_set_tuning(tile, stages)
     A = torch.randn((M, K) if al == 0 else (K, M), device="cuda", dtype=torch.bfloat16)
     B = torch.randn((N, K) if bl == 0 else (K, N), device="cuda", dtype=torch.bfloat16)
-    run = lambda: F.gemm(A, B, a_layout=al, b_layout=bl, split_k=split)
+    run = lambda: F.gemm(A, B, a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)
     us, _, _ = gpu_us(run, 10)
     torch.cuda.synchronize(); run(); torch.cuda.synchronize()
     te = tile if tile != 6412 else 64

@@ -14,12 +14,11 @@ for name, M, N, K in SHAPES:
     R = torch.randn((M, N), device="cuda", dtype=torch.bfloat16)
     gate = torch.tensor([0.5], device="cuda", dtype=torch.bfloat16)
     for tile, stages in [(0, 0)] + ([(128160, 4)] if os.environ.get("FF_GEMM_PC", "1") == "1" else []):
-        lib.ff_gemm_set_tuning(tile, stages)
         def run(i):
             if name == "ff1.fwd":
-                F.gemm(As[i % 24], Bs[i % 24], act="gelu", want_aux_out=True)
+                F.gemm(As[i % 24], Bs[i % 24], act="gelu", want_aux_out=True, tile=tile, stages=stages)
             else:
-                F.gemm(As[i % 24], Bs[i % 24], residual=R, gate=gate)
+                F.gemm(As[i % 24], Bs[i % 24], residual=R, gate=gate, tile=tile, stages=stages)
         for i in range(5):
             run(i)
         torch.cuda.synchronize()
@@ -32,4 +31,3 @@ for name, M, N, K in SHAPES:
             e.record(); torch.cuda.synchronize()
             best = min(best, s.elapsed_time(e) / 100 * 1e3)
         print(f"PC={os.environ.get('FF_GEMM_PC', '1')} {name} {M}x{N}x{K} tile={tile or 'auto'} stages={stages or 'auto'}: {best:6.1f} us/call (incl. split-K reduce), {2.0 * M * N * K / best / 1e6:5.0f} TFLOP/s")
-    lib.ff_gemm_set_tuning(0, 0)

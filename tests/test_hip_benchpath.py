@@ -71,8 +71,9 @@ def check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act="gelu", c
         dy_r, dvf_r, g_r = O.gated_xattn_block_bwd(dy2, cache, p64[i], act=act)
         # the two gate gradients are dot products over all b * L * dim elements, (1 - tanh^2 alpha) * sum(d branch_sum .* branch): their error is
         # held to the tolerance times the natural scale of such a sum, || a .* b ||_2 (cache[2] = attn_out, cache[3] = ffw_out of the oracle)
+        dy1 = dy2 + O.feedforward_bwd(dy2 * cache[5], cache[1], p64[i], "ffw.", act, {})       # gradient at the attention branch's sum
         gate_scale = {"alpha_ffw": float(np.linalg.norm(dy2 * cache[3])) * float(1.0 - cache[5][0] ** 2),
-                      "alpha_attn": float(np.linalg.norm(dy_r * cache[2])) * float(1.0 - cache[4][0] ** 2)}
+                      "alpha_attn": float(np.linalg.norm(dy1 * cache[2])) * float(1.0 - cache[4][0] ** 2)}
         note(f"block{i}.dy", rel(hs[i].grad, dy_r), t["grad"])
         dvf_sum += dvf_r
         for k, prm in m.named_parameters():

@@ -600,6 +600,353 @@ __global__ __launch_bounds__(256) void xa_dattn_bwd_kernel(const XaFusedArgs a_i
 }
 
 // =====================================================================================================
+// Resident-operand variants (bf16, 64-wide heads, a sample's text in one 32-row tile, its keys in one 64-row tile: the training shape of
+// every published configuration - 32 tokens, one image).  One 8-wave workgroup per (sample, head).
+//
+// The kernels above read the 32 x dim activation rows twice (once from global memory for the LayerNorm statistics, once by DMA as the
+// A operand) and stream A and B tiles through one ring with two issuing waves; their timeline is statistics 5.5 us + projection 11 us,
+// both bound by how fast ONE CU can pull bytes (~12-20 B/clk), not by MFMA or HBM.  Here the activation rows are brought in ONCE, by DMA
+// issued from all eight waves in the first microsecond, and STAY in LDS as the [dim / 64][32][64] K-major operand (80 KiB at dim 1280):
+// the LayerNorm statistics are computed from LDS, the rows are normalised in place, and the projection streams only the weight slice
+// (64 x dim, 8 KiB per k-step) through a ring that four DMA waves fill while four MFMA waves (2 row blocks x 2 column halves) consume -
+// per workgroup 245 KiB of operand traffic instead of 325 KiB, and none of it behind a dependent global round trip.
+// =====================================================================================================
+namespace {
+
+constexpr int kResBM = 32, kResDH = 64;
+// LDS bytes: activation rows + weight ring + fixed tiles (+ LayerNorm vectors and statistics in the forward kernel)
+constexpr size_t res_lds_fwd(int dim, int nsb) {
+    return (size_t)(dim / kBK) * kResBM * kBK * 2 + (size_t)nsb * kResDH * kBK * 2 + 2 * 8192 + (size_t)2 * dim * 2 + 2 * kResBM * 4 + 64;
+}
+constexpr size_t res_lds_bwd(int dim, int nsb) {
+    return (size_t)(dim / kBK) * kResBM * kBK * 2 + (size_t)nsb * kResDH * kBK * 2 + 4 * 8192 + (size_t)5 * kTile * 4 + 64;
+}
+
+// workgroup barrier that only waits for this wave's LDS operations (a __syncthreads() would also drain the LDS-DMA still in flight)
+FF_DEV void res_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// all eight waves: bring rows [0, n_rows) x [0, dim) of `rows` (leading dimension dim) into sA as [dim / 64][32][64] K-major swizzled tiles
+FF_DEV void res_issue_rows(const bf16* rows, int dim, int n_rows, bf16* sA, int w, int l) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)rows, 0, 0x7fffffff, 0x00020000);
+    const int p = w & 3, row = p * 8 + (l >> 3), cp = l & 7;            // a wave always carries the same 8 rows: one loop-invariant offset
+    const unsigned voff = row < n_rows ? (unsigned)(row * dim + ((cp ^ (row & 7)) << 3)) * 2u : kOobOffset;
+    const int nk = dim / kBK;
+    for (int tile = w >> 2; tile < nk; tile += 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, FF_LDS_PTR(void, sA + tile * (kResBM * kBK) + p * 8 * kBK), 16, voff, (unsigned)tile * (kBK * 2), 0, 0);
+}
+
+// The projection with a resident A operand: acc[j][r] = sum_k A[rb*16 + c][k] * B[ch*32 + j*16 + g*4 + r][k] for the four MFMA waves
+// (cw = rb | ch << 1), the weight tiles streamed by the four DMA waves.  BL 0: B rows = output columns, k contiguous (Wq head slice);
+// BL 1: B stored [k][ldb] with the output columns contiguous from n_base (Wo head slice).  `vb` / ring prologue: see res_ring_start.
+template <int NSB, int BL>
+FF_DEV void res_ring_start(__amdgpu_buffer_rsrc_t rb, bf16* sB, const RowMap& b_map, int n_base, int n_lim, int nk, int pw, int l, unsigned (&vb)[2]) {
+    dma_prepare<kResDH, BL, 4>(b_map, n_base, n_lim, pw, l, vb);
+    const unsigned b_step = BL == 0 ? 2u : (unsigned)b_map.ld * 2u;
+#pragma unroll
+    for (int s = 0; s < NSB - 1; s++)
+        if (s < nk) dma_tile_fast<kResDH, BL, 4>(rb, sB + s * (kResDH * kBK), vb, (unsigned)(s * kBK) * b_step, pw);
+}
+template <int NSB, int BL>
+FF_DEV void res_project(const bf16* sA, bf16* sB, __amdgpu_buffer_rsrc_t rb, const RowMap& b_map, const unsigned (&vb)[2], int nk, int w, f32x4 (&acc)[2]) {
+    const unsigned b_step = BL == 0 ? 2u : (unsigned)b_map.ld * 2u;
+    if (w >= 4) {           // DMA waves
+        const int pw = w - 4;
+        for (int kt = 0; kt < nk; kt++) {
+            wait_tiles<2, NSB - 2>(min(nk - 1 - kt, NSB - 2));          // tile kt has landed; up to NSB - 2 younger ones stay in flight
+            __builtin_amdgcn_s_barrier();                               // ... for everybody; the MFMA waves have left stage (kt - 1) % NSB
+            if (kt + NSB - 1 < nk)
+                dma_tile_fast<kResDH, BL, 4>(rb, sB + ((kt + NSB - 1) % NSB) * (kResDH * kBK), vb, (unsigned)((kt + NSB - 1) * kBK) * b_step, pw);
+        }
+    } else {                // MFMA waves
+        const int rb16 = (w & 1) * 16, ch32 = (w >> 1) * 32;
+        for (int kt = 0; kt < nk; kt++) {
+            __builtin_amdgcn_s_barrier();
+            const bf16* sAt = sA + kt * (kResBM * kBK);
+            const bf16* sBt = sB + (kt % NSB) * (kResDH * kBK);
+#pragma unroll
+            for (int ks = 0; ks < kBK / 32; ks++) {
+                const bf16x8 fa = frag_read2<kResBM, 0>(sAt, rb16, ks);
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[j] = mfma_bf16(frag_read2<kResDH, BL>(sBt, ch32 + j * 16, ks), fa, acc[j]);      // D[n][m]
+            }
+        }
+    }
+}
+// the four MFMA waves park their accumulators (x scale) in a SwzLayout tile: row = rb*16 + c, columns ch*32 + j*16 + g*4 .. + 3
+FF_DEV void res_park(bf16* tile, const f32x4 (&acc)[2], float scale, int w, int c, int g) {
+    const int row = (w & 1) * 16 + c, ch32 = (w >> 1) * 32;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = (bf16)(acc[j][r] * scale);
+        *(bf16x4*)(tile + SwzLayout::off(row, ch32 + j * 16 + g * 4)) = v;
+    }
+}
+
+}  // namespace
+
+template <int NSB>
+__global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs a_in, const bf16* __restrict__ y, const bf16* __restrict__ gamma,
+                                                               const bf16* __restrict__ beta, const bf16* __restrict__ Wq, const bf16* __restrict__ K,
+                                                               const bf16* __restrict__ V, const int* __restrict__ tt, bf16* __restrict__ yn,
+                                                               bf16* __restrict__ Qs, bf16* __restrict__ O, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const XaFusedArgs a = fetch_args(a_in);
+    constexpr int DH = kResDH, BM = kResBM, NT = DH / 16;
+    const int lin = xcd_remap(blockIdx.x, a.heads * a.batch);          // head fastest: the workgroups reading the same rows of y share an L2
+    const int h = lin % a.heads, b = lin / a.heads;
+    const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nk = a.dim / kBK, n_rows = a.n_q;
+    bf16* sA = (bf16*)smem;
+    bf16* sB = sA + nk * (BM * kBK);
+    bf16* sK = sB + NSB * (DH * kBK);
+    bf16* sV = sK + SwzLayout::tile_elems;
+    bf16* s_g = sV + SwzLayout::tile_elems;
+    bf16* s_b = s_g + a.dim;
+    float* s_mean = (float*)(s_b + a.dim);
+    float* s_rstd = s_mean + BM;
+    bf16* sQ = sB;                                                      // the weight ring is dead when Q is parked
+
+    // ---- every byte the workgroup will read is requested now: its text_time row, the activation rows, gamma / beta, K / V, the first weight tiles ----
+    const int m_own = w * 16 + c;                                      // own query of an attention wave (waves 0, 1)
+    const bool own_ok = w < 2 && m_own < n_rows;
+    const ff_attn_desc d = attn_view(a, DH);
+    RowRange rr = row_range(d, tt, b, own_ok ? m_own : a.n_q);
+    const bf16* yb = y + (long long)b * a.n_q * a.dim;
+    res_issue_rows(yb, a.dim, n_rows, sA, w, l);
+    {   // gamma, beta: dim / 8 sixteen-byte pieces each, lane-linear in LDS
+        const int nch = a.dim / 8;
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gamma, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rbt = __builtin_amdgcn_make_buffer_rsrc((void*)beta, 0, 0x7fffffff, 0x00020000);
+        for (int i0 = w * 64; i0 < nch; i0 += 512) {
+            const unsigned off = i0 + l < nch ? (unsigned)(i0 + l) * 16u : kOobOffset;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, FF_LDS_PTR(void, s_g + i0 * 8), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbt, FF_LDS_PTR(void, s_b + i0 * 8), 16, off, 0, 0, 0);
+        }
+    }
+    const bf16* Kb = K + b * a.k.sb + h * a.k.sh;
+    const bf16* Vb = V + b * a.v.sb + h * a.v.sh;
+    {   // the (single) key tile: waves 0-3 carry K, waves 4-7 V
+        const bf16* src = w < 4 ? Kb : Vb;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
+        dma_tile<64, 0, 4>(rk, w < 4 ? sK : sV, RowMap{w < 4 ? a.k.sr : a.v.sr, 0, 0}, 0, a.n_kv, 0, kBK, w & 3, l);
+    }
+    const bf16* Wh = Wq + (long long)h * DH * a.dim;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wh, 0, 0x7fffffff, 0x00020000);
+    const RowMap w_map{a.dim, 0, 0};
+    unsigned vb[2] = {kOobOffset, kOobOffset};
+    if (w >= 4) {
+        res_ring_start<NSB, 0>(rw, sB, w_map, 0, DH, nk, w - 4, l, vb);
+        wait_vmcnt<2 * (NSB - 1)>();                                   // everything but the weight tiles (issued last) has landed (nk >= NSB - 1)
+    } else wait_vmcnt<0>();
+    res_barrier();                                                     // (raw barrier: the weight tiles stay in flight across it)
+
+    // ---- LayerNorm of the rows, from LDS and in place: 16 threads per row, two-pass statistics like torch ----
+    {
+        constexpr int MAXC = 12;                                       // 16-byte pieces per thread: dim <= 1536
+        const int r = t >> 4, s16 = t & 15;
+        const int nch = nk * 8;
+        uint4 raw[MAXC];
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXC; u++) {
+            const int ci = s16 + 16 * u;
+            if (ci < nch) {
+                raw[u] = *(const uint4*)(sA + (ci >> 3) * (BM * kBK) + r * kBK + (((ci & 7) ^ (r & 7)) << 3));
+                float v[8];
+                unpack16(raw[u], v, bf16());
+#pragma unroll
+                for (int e = 0; e < 8; e++) sum += v[e];
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mu = sum / (float)a.dim;
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXC; u++) {
+            if (s16 + 16 * u < nch) {
+                float v[8];
+                unpack16(raw[u], v, bf16());
+#pragma unroll
+                for (int e = 0; e < 8; e++) sq += (v[e] - mu) * (v[e] - mu);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rs = rsqrtf(sq / (float)a.dim + a.eps);
+        const bool rok = r < n_rows;
+        const long long grow = (long long)b * a.n_q + (rok ? r : 0);
+        if (s16 == 0 && rok && h == 0) { mean[grow] = mu; rstd[grow] = rs; }
+        bf16* ynr = yn ? yn + grow * a.dim : nullptr;
+#pragma unroll
+        for (int u = 0; u < MAXC; u++) {
+            const int ci = s16 + 16 * u;
+            if (ci < nch) {
+                float v[8], gv[8], bv[8];
+                unpack16(raw[u], v, bf16());
+                Vec<bf16>::load(s_g + ci * 8, gv);
+                Vec<bf16>::load(s_b + ci * 8, bv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = (v[e] - mu) * rs * gv[e] + bv[e];
+                Vec<bf16>::store(sA + (ci >> 3) * (BM * kBK) + r * kBK + (((ci & 7) ^ (r & 7)) << 3), v);
+                // the normalised rows are an operand of d to_q.weight: each head's workgroup writes its share of a row's pieces
+                if (ynr && rok && (ci % a.heads) == h) Vec<bf16>::store(ynr + ci * 8, v);
+            }
+        }
+    }
+    res_barrier();
+
+    // ---- q[m][n] = sum_k LN(y)[m][k] Wq[h*DH + n][k] ----
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    res_project<NSB, 0>(sA, sB, rw, w_map, vb, nk, w, acc);
+    __syncthreads();                                                   // the ring is dead: it becomes the Q tile
+    if (w < 4) res_park(sQ, acc, a.scale, w, c, g);
+    __syncthreads();
+    if (t < 256) {                                                     // saved for backward: 32 rows x 8 pieces
+        const int r = t >> 3, ch = t & 7;
+        if (r < n_rows) *(uint4*)(Qs + ((long long)b * a.n_q + r) * a.inner + h * DH + ch * 8) = *(const uint4*)(sQ + SwzLayout::off(r, ch * 8));
+    }
+    // ---- O = softmax_masked(q K^T) V: waves 0 and 1, 16 own queries each, the key tile already in LDS ----
+    if (w < 2) {
+        if (!own_ok) { rr.lo = rr.hi = 0; rr.softmax = 0; rr.uniform = 0; }
+        OwnFrag<bf16, DH> fq;
+        fq.template load_tile<SwzLayout>(sQ, m_own, g, own_ok);
+        f32x4 o[NT];
+#pragma unroll
+        for (int dt = 0; dt < NT; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m = kNegBig, lsum = 0.f;
+        const int bhi = __any(rr.hi > rr.lo) ? min(a.n_kv, kTile) : 0;
+        attn_fwd_loop<bf16, DH, DmaStage64>(d, fq, rr, 0, bhi, Kb, Vb, sK, sV, o, m, lsum, 0);
+        lsum = group_sum(lsum);
+        if (own_ok) {
+            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+            store_acc_row<bf16, DH>(O + ((long long)b * a.n_q + m_own) * a.inner + h * DH, o, inv, g);
+            if (g == 0) lse[((long long)b * a.heads + h) * a.n_q + m_own] = lsum > 0.f ? m + __logf(lsum) : kPosBig;
+        }
+    }
+}
+
+template <int NSB>
+__global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs a_in, const bf16* __restrict__ dy1, const bf16* __restrict__ Wo,
+                                                               const bf16* __restrict__ gate, const bf16* __restrict__ Qs, const bf16* __restrict__ K,
+                                                               const bf16* __restrict__ V, const int* __restrict__ tt, const bf16* __restrict__ O,
+                                                               const float* __restrict__ lse, bf16* __restrict__ dQ, bf16* __restrict__ dK,
+                                                               bf16* __restrict__ dV, float* __restrict__ Dsum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const XaFusedArgs a = fetch_args(a_in);
+    constexpr int DH = kResDH, BM = kResBM, NT = DH / 16;
+    typedef SwzLayout L;
+    const int lin = xcd_remap(blockIdx.x, a.heads * a.batch);
+    const int h = lin % a.heads, b = lin / a.heads;
+    const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nk = a.dim / kBK, n_rows = a.n_q;
+    bf16* sA = (bf16*)smem;
+    bf16* sB = sA + nk * (BM * kBK);
+    bf16* sQ = sB + NSB * (DH * kBK);
+    bf16* sK = sQ + L::tile_elems;
+    bf16* sV = sK + L::tile_elems;
+    bf16* sO = sV + L::tile_elems;
+    int* s_lo = (int*)(sO + L::tile_elems);
+    int* s_hi = s_lo + kTile;
+    int* s_flag = s_hi + kTile;
+    float* s_lse = (float*)(s_flag + kTile);
+    float* s_D = s_lse + kTile;
+    bf16* sDO = sB;                                                     // the weight ring is dead when dO is parked
+
+    // ---- requests first: text_time / lse of the own query, the d y1 rows, Q / K / V / O tiles, the first weight tiles ----
+    const int m_own = (w & 3) * 16 + c;                                 // waves 0-3: own query (dQ pass) resp. own key (dK / dV pass)
+    const bool att = w < 4;
+    const bool own_ok = att && m_own < n_rows;
+    const ff_attn_desc d = attn_view(a, DH);
+    const RowRange rr_full = row_range(d, tt, b, own_ok ? m_own : a.n_q);
+    RowRange rr = rr_full;
+    if (!own_ok || !rr.softmax) rr.lo = rr.hi = 0;                      // zero / uniform rows: no gradient reaches the scores
+    const long long sidx = ((long long)b * a.heads + h) * a.n_q + m_own;
+    const float Lq = own_ok ? lse[sidx] : kPosBig;
+    if (t < kTile) { s_lo[t] = 0; s_hi[t] = 0; s_flag[t] = 0; s_lse[t] = kPosBig; s_D[t] = 0.f; }
+    res_issue_rows(dy1 + (long long)b * a.n_q * a.dim, a.dim, n_rows, sA, w, l);
+    const bf16* Kb = K + b * a.k.sb + h * a.k.sh;
+    const bf16* Vb = V + b * a.v.sb + h * a.v.sh;
+    const bf16* Qb = Qs + (long long)b * a.n_q * a.inner + h * DH;
+    const bf16* Ob = O + (long long)b * a.n_q * a.inner + h * DH;
+    {   // four 64-row tiles, two waves each
+        const int which = w >> 1;                                       // 0: Q, 1: K, 2: V, 3: O
+        const bf16* src = which == 0 ? Qb : which == 1 ? Kb : which == 2 ? Vb : Ob;
+        bf16* dst = which == 0 ? sQ : which == 1 ? sK : which == 2 ? sV : sO;
+        const long long sr = which == 0 || which == 3 ? (long long)a.inner : which == 1 ? a.k.sr : a.v.sr;
+        const int lim = which == 0 || which == 3 ? a.n_q : a.n_kv;
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
+        dma_tile<64, 0, 2>(rt, dst, RowMap{sr, 0, 0}, 0, lim, 0, kBK, w & 1, l);
+    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wo, 0, 0x7fffffff, 0x00020000);
+    const RowMap w_map{a.inner, 0, 0};
+    unsigned vb[2] = {kOobOffset, kOobOffset};
+    if (w >= 4) {
+        res_ring_start<NSB, 1>(rw, sB, w_map, h * DH, (h + 1) * DH, nk, w - 4, l, vb);
+        wait_vmcnt<2 * (NSB - 1)>();
+    } else wait_vmcnt<0>();
+    res_barrier();
+
+    // ---- dO[m][n] = tanh(alpha) * sum_k dy1[m][k] Wo[k][h*DH + n] ----
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    res_project<NSB, 1>(sA, sB, rw, w_map, vb, nk, w, acc);
+    __syncthreads();                                                    // ring dead -> dO tile
+    const float gt = tanhf(to_f32(gate[0]));
+    if (w < 4) res_park(sDO, acc, gt, w, c, g);
+    else {                // rows 32 .. 63 of the dO tile do not exist: zero them (they are "other" rows of the dK / dV products)
+        const int row = 32 + (w - 4) * 8 + (l >> 3), ch = l & 7;
+        *(uint4*)(sDO + row * 64 + ch * 8) = uint4{0, 0, 0, 0};
+    }
+    __syncthreads();
+
+    // ---- own rows = queries: D = sum_d dO * O, dQ ----
+    OwnFrag<bf16, DH> fq, fdo, fo;
+    fq.template load_tile<L>(sQ, m_own, g, own_ok);
+    fdo.template load_tile<L>(sDO, m_own, g, own_ok);
+    fo.template load_tile<L>(sO, m_own, g, own_ok);
+    const float Dq = group_sum(fdo.dot(fo));
+    if (own_ok && g == 0) {
+        if (Dsum) Dsum[sidx] = Dq;
+        s_lo[m_own] = rr_full.lo; s_hi[m_own] = rr_full.hi; s_flag[m_own] = rr_full.softmax | (rr_full.uniform << 1);
+        s_lse[m_own] = Lq; s_D[m_own] = Dq;
+    }
+    if (att) {
+        f32x4 dq[NT];
+#pragma unroll
+        for (int dt = 0; dt < NT; dt++) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int bhi = __any(rr.hi > rr.lo) ? min(a.n_kv, kTile) : 0;
+        attn_dq_loop<bf16, DH, DmaStage64>(d, fq, fdo, rr, Lq, Dq, 0, bhi, Kb, Vb, sK, sV, dq, 0);
+        if (own_ok) store_acc_row<bf16, DH>(dQ + ((long long)b * a.n_q + m_own) * a.inner + h * DH, dq, 1.f, g);
+    }
+    __syncthreads();                                                    // the per-query tables are complete
+
+    // ---- own rows = keys (all of the sample's queries and keys are in this tile): dK, dV ----
+    if (att) {
+        const int key = m_own;
+        const bool kok = key < a.n_kv;
+        OwnFrag<bf16, DH> fk, fv;
+        fk.template load_tile<L>(sK, key, g, kok);
+        fv.template load_tile<L>(sV, key, g, kok);
+        f32x4 acc_k[NT], acc_v[NT];
+#pragma unroll
+        for (int dt = 0; dt < NT; dt++) { acc_k[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_v[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        attn_dkv_step<bf16, DH, L>(key, fk, fv, sQ, sDO, s_lo, s_hi, s_flag, s_lse, s_D, acc_k, acc_v);
+        if (kok) {
+            store_acc_row<bf16, DH>(dK + b * a.dk.sb + (long long)key * a.dk.sr + h * a.dk.sh, acc_k, 1.f, g);
+            store_acc_row<bf16, DH>(dV + b * a.dv.sb + (long long)key * a.dv.sr + h * a.dv.sh, acc_v, 1.f, g);
+        }
+    }
+}
+
+// =====================================================================================================
 // host side
 // =====================================================================================================
 bool xa_fused_supported(int dtype, int dim_head, int dim, int inner) {
@@ -659,13 +1006,48 @@ static int launch_fwd(const XaFusedArgs& a, const void* y, const void* gamma, co
     return check_launch("xa_qattn_fwd");
 }
 
+// ring depth of the resident-operand kernels for this problem, 0 = not applicable (bf16, 64-wide heads, one 32-row text tile, one key tile,
+// rows 16-byte aligned in every tensor, everything within the 160 KiB of LDS)
+static int res_ring_depth(const XaFusedArgs& a, int dtype, int dim_head, bool bwd) {
+    static const int on = dbg_switch("FF_XATTN_RES", 1);
+    if (!on || dtype != FF_DTYPE_BF16 || dim_head != 64 || a.n_q > kResBM || a.n_kv > kTile || a.dim % kBK != 0 || a.dim > 1536 || a.inner % 8 != 0) return 0;
+    if ((a.k.sr | a.k.sh | a.k.sb | a.v.sr | a.v.sh | a.v.sb | a.dk.sr | a.dk.sh | a.dk.sb | a.dv.sr | a.dv.sh | a.dv.sb) % 8 != 0) return 0;
+    const int nk = a.dim / kBK;
+    for (int nsb : {6, 4})
+        if (nk >= nsb && (bwd ? res_lds_bwd(a.dim, nsb) : res_lds_fwd(a.dim, nsb)) <= 160 * 1024) return nsb;
+    return 0;
+}
+template <int NSB>
+static int launch_fwd_res(const XaFusedArgs& a, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K, const void* V,
+                          const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st) {
+    const size_t lds = res_lds_fwd(a.dim, NSB);
+    auto kernel = xa_qattn_fwd_res_kernel<NSB>;
+    FF_TRY(allow_lds(kernel, lds, "xa_qattn_fwd_res"));
+    kernel<<<dim3(a.heads * a.batch), dim3(512), lds, st>>>(a, (const bf16*)y, (const bf16*)gamma, (const bf16*)beta, (const bf16*)Wq, (const bf16*)K,
+                                                             (const bf16*)V, tt, (bf16*)yn, (bf16*)Qs, (bf16*)O, mean, rstd, lse);
+    return check_launch("xa_qattn_fwd_res");
+}
+template <int NSB>
+static int launch_bwd_res(const XaFusedArgs& a, const void* dy1, const void* Wo, const void* gate, const void* Qs, const void* K, const void* V,
+                          const int* tt, const void* O, const float* lse, void* dQ, void* dK, void* dV, float* Dsum, hipStream_t st) {
+    const size_t lds = res_lds_bwd(a.dim, NSB);
+    auto kernel = xa_dattn_bwd_res_kernel<NSB>;
+    FF_TRY(allow_lds(kernel, lds, "xa_dattn_bwd_res"));
+    kernel<<<dim3(a.heads * a.batch), dim3(512), lds, st>>>(a, (const bf16*)dy1, (const bf16*)Wo, (const bf16*)gate, (const bf16*)Qs, (const bf16*)K,
+                                                             (const bf16*)V, tt, (const bf16*)O, lse, (bf16*)dQ, (bf16*)dK, (bf16*)dV, Dsum);
+    return check_launch("xa_dattn_bwd_res");
+}
+
 int xa_qattn_fwd(const XaFusedArgs& a, int dtype, int dim_head, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K,
                  const void* V, const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st) {
     FF_CHECK(xa_fused_supported(dtype, dim_head, a.dim, a.inner), FF_ERR_UNSUPPORTED, "xa_qattn_fwd: unsupported dtype / head size");
     FF_CHECK(y && gamma && beta && Wq && K && V && tt && Qs && O && mean && rstd && lse, FF_ERR_SHAPE, "xa_qattn_fwd: null argument");
     const int pid = profile_begin(dtype, -4, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
     int rc;
-    if (a.n_q <= 32) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_fwd<T, DH, 32>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st)));
+    const int nsb = res_ring_depth(a, dtype, dim_head, false);
+    if (nsb == 6) rc = launch_fwd_res<6>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st);
+    else if (nsb == 4) rc = launch_fwd_res<4>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st);
+    else if (a.n_q <= 32) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_fwd<T, DH, 32>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st)));
     else FF_XA_DISPATCH(dtype, dim_head, rc = (launch_fwd<T, DH, 64>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st)));
     profile_end(pid, st);
     return rc;
@@ -694,7 +1076,10 @@ int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1,
     *single_tile = single ? 1 : 0;
     const int pid = profile_begin(dtype, -5, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
     int rc;
-    if (a.n_q <= 32) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 32, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
+    const int nsb = res_ring_depth(a, dtype, dim_head, true);
+    if (nsb == 6) rc = launch_bwd_res<6>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dQ, dK, dV, Dsum, st);
+    else if (nsb == 4) rc = launch_bwd_res<4>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dQ, dK, dV, Dsum, st);
+    else if (a.n_q <= 32) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 32, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
     else if (single) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 64, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
     else FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 64, false>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
     profile_end(pid, st);

@@ -215,3 +215,38 @@ def test_deferred_weight_gradients_accumulate_correctly():
     for m, ref in zip(blocks, once):
         for k, p in m.named_parameters():
             assert rel(p.grad, 2.0 * ref[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("b,L,nv,dim", [(3, 20, 64, 1280), (2, 32, 40, 768), (5, 7, 64, 1536), (4, 32, 64, 1024)],
+                         ids=["L20", "L32-40keys", "L7-dim1536", "L32-dim1024"])
+def test_resident_fused_kernels_bf16_vs_oracle(b, L, nv, dim):
+    """The resident-operand kernels (xa_qattn_fwd_res / xa_dattn_bwd_res: bf16, 64-wide heads, <= 32 tokens, <= 64 keys per sample) at ragged
+    sizes - rows past the text, fewer than 64 keys, zero rows (tokens before the media tag) and uniform rows (a second tag without a second
+    image), both ring depths - forward, backward and the cached single-token call, against the oracle."""
+    dtype = torch.bfloat16
+    dv, heads, dh, ffm = 256, 8, 64, 2
+    p = xattn_params(dim, dv, heads, dh, ffm, tag=f"res{L}{nv}")
+    m = build_block(p, dim, dv, heads, dh, nv, ffm, "gelu", dtype)
+    ml = np.zeros((b, L), np.int64)
+    ml[0, 0] = 1
+    ml[1, min(3, L - 1)] = 1                   # tokens 0..2 see nothing
+    if b > 2:
+        ml[2, [1, L - 2]] = 1                  # the second tag has no image: uniform rows at the end
+    yd = dev(det((b, L, dim), "res-y"), dtype).requires_grad_(True)
+    vfd = dev(det((b, 1, nv, dv), "res-vf"), dtype).requires_grad_(True)
+    dyd = dev(det((b, L, dim), "res-dy"), dtype)
+    mlt = torch.as_tensor(ml).cuda()
+    out, kv = m(yd, vfd, mlt, output_kv=True)
+    out.backward(dyd)
+    p64 = {k: as64(v) for k, v in m.state_dict().items()}
+    outr, _, cache = O.gated_xattn_block_fwd(as64(yd), as64(vfd), ml, p64, n_visual=nv)
+    dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd), cache, p64)
+    t = TOL[dtype]
+    assert rel(out - yd, outr - as64(yd)) < t["out"]
+    assert rel(yd.grad, dyr) < t["grad"] and rel(vfd.grad, dvfr) < t["grad"]
+    for k in ("attn.to_q.weight", "attn.to_kv.weight", "attn.to_out.weight", "attn.norm.weight", "attn.norm.bias", "ffw.1.weight"):
+        assert rel(dict(m.named_parameters())[k].grad, gr[k]) < t["grad"], k
+    with torch.no_grad():                      # the decode call: one token per sequence against the cached keys / values
+        out_c, _ = m(yd[:, -1:].detach(), None, mlt, previous_kv=(kv[0].detach(), kv[1].detach()))
+    want = outr[:, -1:] - as64(yd)[:, -1:]
+    assert rel(out_c - yd[:, -1:].detach(), want) < t["out"]

@@ -9,6 +9,7 @@
 //
 // Accumulators are kept transposed (D[n][m] = mfma(Bfrag, Afrag)) so a lane owns 4 consecutive n of one row m
 // and the epilogue issues 8/16-byte row-contiguous loads and stores.
+#include <atomic>
 #include <type_traits>
 #include "ff_common.h"
 #include <stdlib.h>
@@ -732,18 +733,22 @@ static int dispatch_f32(const GemmParams& P, hipStream_t st) {
 // optional per-launch timing of the GEMM kernels with HIP events on the launch stream (bench.py's roofline leg)
 // ------------------------------------------------------------------------------------------------
 namespace {
+// The opt-in launch log is the one piece of process-wide state in the library, and it has to be: PyTorch issues the backward pass from its
+// autograd worker thread, so a per-thread log would only ever see forward launches.  Recording is thread-safe (slots are claimed with an
+// atomic counter); enabling / reading / disabling is done by one thread while no launch is in flight.  Disabled (the default), the only
+// cost is one relaxed atomic load per GEMM launch.
 struct ProfState {
-    bool on = false;
-    int cap = 0, n = 0;
+    std::atomic<bool> on{false};
+    int cap = 0;
+    std::atomic<int> n{0};
     hipEvent_t* ev = nullptr;     // 2 events per record
     ff_gemm_profile_record* rec = nullptr;
-};
-// per THREAD, like ff_last_error(): a thread that enables the log records the launches it issues itself; other threads are unaffected
-thread_local ProfState g_prof;
+} g_prof;
 }
 int profile_begin(int dtype, int tile, int a_layout, int b_layout, int M, int N, int K, int nz, int split_k, hipStream_t st) {
-    if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
-    const int i = g_prof.n++;
+    if (!g_prof.on.load(std::memory_order_relaxed)) return -1;
+    const int i = g_prof.n.fetch_add(1);
+    if (i >= g_prof.cap) return -1;
     ff_gemm_profile_record& r = g_prof.rec[i];
     r.dtype = dtype; r.tile = tile; r.a_layout = a_layout; r.b_layout = b_layout;
     r.M = M; r.N = N; r.K = K; r.nz = nz; r.split_k = split_k; r.ms = 0.f;
@@ -776,11 +781,12 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     // the 128 x 160 producer / consumer kernel needs a K-major A operand; B may be K-major or (split staging) N-contiguous
     static const int pc_bl1 = env_int("FF_GEMM_PC_BL1", 1);
     const bool pc_ok = a_layout == 0 && (b_layout == 0 || (pc_bl1 && N % 8 == 0));
-    if (ft == 128 || ft == 64 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok)) {
+    const bool skinny_ok = a_layout == 0 && b_layout == 0;      // the 32 x 64 tile stages K-major operands only
+    if (ft == 128 || ft == 64 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
         const long long t = ft == 128 || ft == 128002 ? t128 : ft == 64 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
-                                                                             : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
+                            : ft == 3264 ? (long long)cdiv(M, 32) * cdiv(N, 64) * nz : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
         p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
         return p;
     }
@@ -788,6 +794,20 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     // but 2-3 workgroups per CU) measured 10-25 % faster there when A is row-major (sweep in tools/gemm_bench.py)
     // one 128 x 160 tile per CU (producer / consumer kernel) when that grid, times a small split-K, lands on 224..256 workgroups
     static const int pc_on = env_int("FF_GEMM_PC", 1);
+    // Decode (one token per sequence: M = batch <= 32 rows): 32 x 64 tiles instead of 64 x 64 ones with half their rows empty; the grid is
+    // N / 64 workgroups, so short-K products need no split-K (and no reduce launch) at all and long-K ones split just enough to occupy
+    // ~160 CUs (measured in the caption leg: 8 -> 5 library launches per gated block and token)
+    static const int skinny_on = env_int("FF_GEMM_SKINNY", 1);
+    if (skinny_on && skinny_ok && M <= 32 && nz == 1) {
+        const int t = cdiv(N, 64);
+        int sp = 1;
+        if (K >= 2048) {
+            sp = std::min(8, std::max(1, 160 / t));
+            while (sp > 1 && K / (64 * sp) < 8) sp--;
+        }
+        p = TilePlan{3264, want_split > 0 ? want_split : sp};
+        return p;
+    }
     const long long t160 = (long long)cdiv(M, 128) * cdiv(N, 160) * nz;
     int pc_split = 0;
     if (pc_on && pc_ok && N % 160 == 0 && K % 64 == 0 && t160 <= 256)
@@ -876,6 +896,7 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
         return pns == 4 ? launch_bf16_pc<128, 160, 0, 1, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 1, 3, 1>(P, st);
     }
     if (P.tile == 128002) return dispatch_bf16_pc128<2>(P, st);
+    if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
     if (P.tile == 6412) return run_bf16_dma_tile<64, 128>(P, ns, st);
     return run_bf16_dma_tile<64, 64>(P, ns, st);
@@ -920,8 +941,8 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.partial = (float*)workspace;
     }
     {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
-        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : 64) : kFBM;
-        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
+        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : P.tile == 3264 ? 32 : 64) : kFBM;
+        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 || P.tile == 3264 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
         const int tiles_m = cdiv(P.M, tm_edge), tiles_n = cdiv(P.N, tn_edge);
         double best = 1e300;
         P.xcd_ms = 1; P.xcd_ns = 1;
@@ -1014,6 +1035,7 @@ extern "C" int ff_gemm(const ff_gemm_desc* d, const void* A, const void* B, void
 extern "C" int ff_gemm_profile_enable(int max_records) {
     using namespace ff;
     if (max_records <= 0) { g_prof.on = false; return FF_OK; }
+    g_prof.on = false;
     if (max_records > g_prof.cap) {
         hipEvent_t* ev = (hipEvent_t*)realloc(g_prof.ev, sizeof(hipEvent_t) * 2 * max_records);
         ff_gemm_profile_record* rec = (ff_gemm_profile_record*)realloc(g_prof.rec, sizeof(ff_gemm_profile_record) * max_records);
@@ -1031,7 +1053,7 @@ extern "C" int ff_gemm_profile_enable(int max_records) {
 }
 extern "C" int ff_gemm_profile_read(ff_gemm_profile_record* out, int max_records) {
     using namespace ff;
-    const int n = g_prof.n < max_records ? g_prof.n : max_records;
+    const int n = std::min(std::min(g_prof.n.load(), g_prof.cap), max_records);
     for (int i = 0; i < n; i++) {
         hipEventSynchronize(g_prof.ev[2 * i + 1]);
         float ms = 0.f;
@@ -1048,8 +1070,8 @@ extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_
     FF_CHECK(d && bm && bn && split_k, FF_ERR_SHAPE, "ff_gemm_plan: null argument");
     if (d->dtype == FF_DTYPE_BF16) {
         const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout, d->tile);
-        *bm = p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : 64;
-        *bn = p.tile == 64 ? 64 : p.tile == 128160 ? 160 : 128;
+        *bm = p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : p.tile == 3264 ? 32 : 64;
+        *bn = p.tile == 64 || p.tile == 3264 ? 64 : p.tile == 128160 ? 160 : 128;
         *split_k = p.split;
     } else {
         *bm = *bn = kFBM;

@@ -79,21 +79,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
             else Vec<Q>::store(q + i + c * QN, part);
         }
     };
-    for (long long i = base + (long long)threadIdx.x * VEC; i < min(n, base + kAdamChunk); i += 256 * VEC) {
-        float pf[VEC], gf[VEC], mf[VEC], vf[VEC];
-        if (vec) {
-            constexpr std::true_type S{};
-            constexpr std::false_type K{};
-            if (MASTER) ldv(w, i, pf, S); else ldv(p, i, pf, K);
-            ldv(g, i, gf, S); ldv(m, i, mf, S); ldv(v, i, vf, S);
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; e++) {
-                const bool ok = i + e < n;
-                pf[e] = ok ? (MASTER ? w[i + e] : to_f32(p[i + e])) : 0.f; gf[e] = ok ? to_f32(g[i + e]) : 0.f;
-                mf[e] = ok ? to_f32(m[i + e]) : 0.f; vf[e] = ok ? to_f32(v[i + e]) : 0.f;
-            }
-        }
+    const long long end = min(n, base + (long long)kAdamChunk);
+    auto update = [&](float (&pf)[VEC], const float (&gf)[VEC], float (&mf)[VEC], float (&vf)[VEC]) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
             const float gr = gf[e] * t.grad_scale;
@@ -102,19 +89,53 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t) {
             vf[e] = t.beta2 * vf[e] + (1.f - t.beta2) * gr * gr;
             pf[e] -= step_size * mf[e] / (sqrtf(vf[e]) / bc2_sqrt + t.eps);
         }
-        if (vec) {
-            constexpr std::true_type S{};
-            constexpr std::false_type K{};
+    };
+    if (vec) {
+        constexpr std::true_type S{};
+        constexpr std::false_type K{};
+        auto store = [&](long long i, const float (&pf)[VEC], const float (&mf)[VEC], const float (&vf)[VEC]) {
             stv(p, i, pf, K); stv(m, i, mf, S); stv(v, i, vf, S);      // the updated parameters are what the next forward reads: kept cacheable
             if (MASTER) stv(w, i, pf, S);
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; e++)
-                if (i + e < n) {
-                    p[i + e] = from_f32<T>(pf[e]); m[i + e] = from_f32<ST>(mf[e]); v[i + e] = from_f32<ST>(vf[e]);
-                    if (MASTER) w[i + e] = pf[e];
-                }
+        };
+        long long i = base + (long long)threadIdx.x * VEC;
+        // two pieces per thread and pass: eight 16-byte loads are in flight before the first one is needed (the tensors may alias as far as
+        // the compiler knows, so it would not hoist the second piece's loads above the first piece's stores by itself)
+        for (; i + 256 * VEC < end; i += 512 * VEC) {
+            const long long j = i + 256 * VEC;
+            float p0[VEC], g0[VEC], m0[VEC], v0[VEC], p1[VEC], g1[VEC], m1[VEC], v1[VEC];
+            if (MASTER) { ldv(w, i, p0, S); ldv(w, j, p1, S); } else { ldv(p, i, p0, K); ldv(p, j, p1, K); }
+            ldv(g, i, g0, S); ldv(g, j, g1, S);
+            ldv(m, i, m0, S); ldv(m, j, m1, S);
+            ldv(v, i, v0, S); ldv(v, j, v1, S);
+            update(p0, g0, m0, v0);
+            update(p1, g1, m1, v1);
+            store(i, p0, m0, v0);
+            store(j, p1, m1, v1);
         }
+        if (i < end) {
+            float pf[VEC], gf[VEC], mf[VEC], vf[VEC];
+            if (MASTER) ldv(w, i, pf, S); else ldv(p, i, pf, K);
+            ldv(g, i, gf, S); ldv(m, i, mf, S); ldv(v, i, vf, S);
+            update(pf, gf, mf, vf);
+            store(i, pf, mf, vf);
+        }
+        return;
+    }
+    for (long long i = base + (long long)threadIdx.x * VEC; i < end; i += 256 * VEC) {
+        float pf[VEC], gf[VEC], mf[VEC], vf[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const bool ok = i + e < n;
+            pf[e] = ok ? (MASTER ? w[i + e] : to_f32(p[i + e])) : 0.f; gf[e] = ok ? to_f32(g[i + e]) : 0.f;
+            mf[e] = ok ? to_f32(m[i + e]) : 0.f; vf[e] = ok ? to_f32(v[i + e]) : 0.f;
+        }
+        update(pf, gf, mf, vf);
+#pragma unroll
+        for (int e = 0; e < VEC; e++)
+            if (i + e < n) {
+                p[i + e] = from_f32<T>(pf[e]); m[i + e] = from_f32<ST>(mf[e]); v[i + e] = from_f32<ST>(vf[e]);
+                if (MASTER) w[i + e] = pf[e];
+            }
     }
 }
 

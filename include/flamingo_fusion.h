@@ -7,8 +7,10 @@
  * Return value: FF_OK or a negative error code; ff_last_error() gives a thread-local message.
  * State: none that is shared.  The entry points may be used from several threads on distinct streams / buffers; no environment variable is
  * read (the A/B switches of development builds exist only under -DFF_DEBUG, build.py --debug); every plan override travels in a
- * descriptor (ff_gemm_desc.split_k / tile / stages).  Two things are kept per THREAD, like errno: the ff_last_error() message and the
- * launch-timing log of ff_gemm_profile_* (a thread that enables it records the launches it issues itself).
+ * descriptor (ff_gemm_desc.split_k / tile / stages).  ff_last_error() is per thread, like errno.  The one process-wide object is the
+ * opt-in launch-timing log of ff_gemm_profile_* (off by default): it has to see the launches of every thread - PyTorch issues backward
+ * from its autograd worker thread - so recording into it is thread-safe (atomic slot counter), while enable / read / disable belong to
+ * one controlling thread with no launch in flight.
  *
  * What each entry point replaces in the reference (dhansmair/flamingo-mini, paths relative to its root):
  *   ff_resampler_fwd/bwd     PerceiverResampler.forward + its autograd   flamingo_mini/perceiver_resampler.py:143-188
@@ -73,7 +75,8 @@ typedef struct ff_gemm_desc {
     int act_bwd;  /* FF_ACT_* or FF_ACT_NONE */
     int split_k;  /* 0 = choose automatically */
     int tile;     /* bf16 block tile: 0 = choose automatically; 128 = 128x128 (4 waves), 6412 = 64x128, 64 = 64x64,
-                   * 128002 = 128x128 producer/consumer (8 waves), 128160 = 128x160 producer/consumer (A K-major only) */
+                   * 128002 = 128x128 producer/consumer (8 waves), 128160 = 128x160 producer/consumer (A K-major only),
+                   * 3264 = 32x64 producer/consumer (decode: M <= 32 rows; both operands K-major) */
     int stages;   /* depth of the LDS operand ring: 0 = default, 2..4 */
 } ff_gemm_desc;
 

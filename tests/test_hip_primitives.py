@@ -37,7 +37,7 @@ def test_gemm_every_instantiated_tile(al, bl):
     ref = (a if al == 0 else a.T) @ (b.T if bl == 0 else b)
     # 128002 / 128160: the 8-wave producer / consumer kernels (128 x 128 for every layout; 128 x 160 for a K-major A operand, B K-major or -
     # staged as a 128-column and a 32-column piece - N-contiguous)
-    for tile in (128, 6412, 64, 128002) + ((128160,) if al == 0 else ()):
+    for tile in (128, 6412, 64, 128002) + ((128160,) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
         for stages in (2, 3, 4):
             for split in (1, 2):
                 C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)
@@ -80,6 +80,25 @@ def test_gemm_balanced_producer_consumer_tile():
     assert rel(F().gemm(A, B, b_layout=1), as64(A) @ as64(B)) < TOL[dt]["out"]
     A, B = dev(rnd((1024, 5120), 33, 0.5), dt), dev(rnd((5120, 1280), 34, 0.02), dt)
     assert rel(F().gemm(A, B, b_layout=1), as64(A) @ as64(B)) < TOL[dt]["out"]
+
+
+def test_gemm_decode_rows_bf16():
+    """M <= 32 rows (one decoded token per sequence): the 32 x 64 tile plan on the gated block's decode products, with their epilogues."""
+    dt = torch.bfloat16
+    gate = dev(np.array([0.7]), dt)
+    g = np.tanh(as64(gate)[0])
+    for M in (32, 5, 1):
+        A, B, R = dev(rnd((M, 512), 41, 0.5), dt), dev(rnd((1280, 512), 42, 0.05), dt), dev(rnd((M, 1280), 43), dt)
+        C, aux = F().gemm(A, B, residual=R, gate=gate, want_aux_out=True)                    # to_out + gate + residual
+        acc = as64(A) @ as64(B).T
+        assert rel(aux, acc) < TOL[dt]["out"] and rel(C, as64(R) + g * acc) < TOL[dt]["out"]
+        A, B = dev(rnd((M, 1280), 44, 0.5), dt), dev(rnd((5120, 1280), 45, 0.05), dt)
+        C, aux = F().gemm(A, B, act="gelu", want_aux_out=True)                               # FFW up-projection
+        acc = as64(A) @ as64(B).T
+        assert rel(aux, acc) < TOL[dt]["out"] and rel(C, O.act_fwd(acc, "gelu")) < TOL[dt]["out"]
+        A, B, R = dev(rnd((M, 5120), 46, 0.5), dt), dev(rnd((1280, 5120), 47, 0.02), dt), dev(rnd((M, 1280), 48), dt)
+        C = F().gemm(A, B, residual=R, gate=gate)                                            # FFW down-projection: long K -> split-K
+        assert rel(C, as64(R) + g * (as64(A) @ as64(B).T)) < TOL[dt]["out"]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

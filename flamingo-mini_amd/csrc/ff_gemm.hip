@@ -203,7 +203,6 @@ FF_DEV void tile_epilogue_bf16(const GemmParams& P, const GemmProblem& pr, const
 
 struct TileCoord {
     int z, split, tm, tn;
-    int sub_r0, sub_rows, sub_c0, sub_cols;      // the XCD sub-grid the tile belongs to (used by the L2 pre-touch to share lines)
 };
 // a / b for 0 <= a < 2^20, 0 < b: one v_rcp + fix-up instead of the ~35-instruction integer division sequence
 FF_DEV int fast_div(int a, int b) {
@@ -228,7 +227,6 @@ FF_DEV TileCoord tile_coord(int nz, int split_k, int ms, int ns, int tiles_m, in
     int p = bid;
     const int lm = __builtin_ctz(ms), ln = __builtin_ctz(ns);
     c.tm = 0; c.tn = 0;
-    c.sub_r0 = 0; c.sub_rows = tiles_m; c.sub_c0 = 0; c.sub_cols = tiles_n;
     for (int sgrid = 0; sgrid < ms * ns; sgrid++) {
         const int sm = sgrid >> ln, sn = sgrid & (ns - 1);
         const int r0 = (sm * tiles_m) >> lm, r1 = ((sm + 1) * tiles_m) >> lm;
@@ -238,7 +236,6 @@ FF_DEV TileCoord tile_coord(int nz, int split_k, int ms, int ns, int tiles_m, in
             const int q = fast_div(p, cw);
             c.tm = r0 + q;
             c.tn = c0 + p - q * cw;
-            c.sub_r0 = r0; c.sub_rows = r1 - r0; c.sub_c0 = c0; c.sub_cols = cw;
             break;
         }
         p -= cnt;
@@ -420,10 +417,9 @@ template <int BN, int BL> struct BStage {
 };
 
 // WPC = workgroups per CU the register budget is sized for (2: <= 128 registers per lane, two 8-wave workgroups share a CU)
-// h_pf: L2 pre-touch distance in k-steps | share flag << 8 (0 = off; see touch_offset in ff_gemm_tiles.h)
 template <int BM, int BN, int AL, int BL, int NS, int WPC>
 __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
-                                                           int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, int h_pf, const GemmParams P) {
+                                                           int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
@@ -471,32 +467,12 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
         if (full && b_plain) BS::fast(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, pw);
         else BS::slow(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, pw, l);
     };
-    // L2 pre-touch by the MFMA waves: waves 0, 1 own the A tile's lines, waves 2, 3 the B tile's; one lane = one 128-byte line
-    const int pf_dist = h_pf & 255;
-    const int nk_full = (k_end - k_begin) / kBK;                   // only whole k-steps are touched
-    unsigned pf_voff = kOobOffset;
-    unsigned* pf_scratch = (unsigned*)(smem_raw + (size_t)NS * STAGE * sizeof(bf16)) + pw * 64;
-    const bool pf_a = pw < 2;
     if (producer) {
         dma_prepare<BM, AL>(a_map, m_base, hM, pw, l, va);
         BS::prepare(b_map, n_base, hN, pw, l, vb);
 #pragma unroll
         for (int s = 0; s < NS - 1; s++)
             if (s < nk) issue(s);
-    } else if (pf_dist > 0 && a_plain && b_plain) {
-        // lines this workgroup has in common with its co-resident neighbours of the XCD sub-grid are shared out among them
-        constexpr int kWindow = 32 * WPC;                         // workgroups of one XCD in flight at a time
-        int share_a = 1, mine_a = 0, share_b = 1, mine_b = 0;
-        if (h_pf >> 8) {
-            share_a = min(tc.sub_cols, kWindow);                   // tiles of one row panel run side by side: they all read the same A lines
-            mine_a = (tc.tn - tc.sub_c0) % share_a;
-            share_b = max(1, min(tc.sub_rows, kWindow / max(tc.sub_cols, 1)));
-            mine_b = (tc.tm - tc.sub_r0) % share_b;
-        }
-        const int idx = (pw & 1) * 64 + l;
-        pf_voff = pf_a ? touch_offset<BM, AL>(a_map, m_base, hM, idx, share_a, mine_a) : touch_offset<BN, BL>(b_map, n_base, hN, idx, share_b, mine_b);
-        for (int tp = NS - 1; tp < min(pf_dist, nk_full); tp++)     // tiles the loop below is too late for
-            touch_issue(pf_a ? ra : rb, pf_scratch, pf_voff, (unsigned)(k_begin + tp * kBK) * (pf_a ? a_step : b_step));
     }
     FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
     if (tc.z > 0) pr = P.p[tc.z];
@@ -512,8 +488,6 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
     } else {
         for (int kt = 0; kt < nk; kt++) {
             __builtin_amdgcn_s_barrier();
-            if (pf_dist > 0 && kt + pf_dist < nk_full)
-                touch_issue(pf_a ? ra : rb, pf_scratch, pf_voff, (unsigned)(k_begin + (kt + pf_dist) * kBK) * (pf_a ? a_step : b_step));
             const bf16* sA = smem + (kt % NS) * STAGE;
             const bf16* sB = sA + A_ELEMS;
 #pragma unroll
@@ -529,7 +503,6 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
                     for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
             }
         }
-        if (pf_dist > 0) wait_vmcnt<0>();           // (the touches are pending LDS writes of this wave: drained before its memory is reused)
     }
     const int c = l & 15, g = l >> 4;
     if (Q.split_k > 1) {   // fp32 partial slab; gemm_splitk_epilogue_kernel reduces the slabs and applies the epilogue
@@ -772,7 +745,6 @@ static int env_int(const char* name, int dflt) { return dbg_switch(name, dflt); 
 // 43.74 ms/step): no split for the small 64-tile GEMMs +0.5 ms, one-workgroup-per-CU split counts +0.7 ms, no 64x128 rule +0.5 ms -
 // in-model the operands arrive cold from HBM and more workgroups in flight hide that better than isolated timings suggest.
 struct TilePlan { int tile, split; };
-constexpr int kPrefetchDist = 0;      // default L2 pre-touch distance (k-steps ahead of the MFMA waves); 0 = off
 static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_layout = 0, int b_layout = 0, int ft = 0) {
     const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * nz, t64 = (long long)cdiv(M, 64) * cdiv(N, 64) * nz;
     TilePlan p;
@@ -862,7 +834,7 @@ template <int BM, int BN> static int run_bf16_dma_tile(const GemmParams& P, int 
     return ns == 2 ? dispatch_bf16_dma<BM, BN, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<BM, BN, 4>(P, st) : dispatch_bf16_dma<BM, BN, 3>(P, st);
 }
 template <int BM, int BN, int AL, int BL, int NS, int WPC> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16) + 1024;      // + the pre-touch scratch words (4 MFMA waves x 64 lanes)
+    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -875,7 +847,7 @@ template <int BM, int BN, int AL, int BL, int NS, int WPC> static int launch_bf1
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
     gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC><<<dim3(grid), dim3(512), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
                                                                                  P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
-                                                                                 (int)P.b_map.ld, seg, P.prefetch, P);
+                                                                                 (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_pc");
 }
 // 128 x 128 tiles, two 8-wave workgroups per CU (experiment: FF_GEMM_TILE=128002 / FF_GEMM_PC128=1)
@@ -926,9 +898,6 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         const TilePlan plan = plan_bf16(P.M, P.N, P.K, P.nz, P.split_k, P.a_layout, P.b_layout, P.force_tile);
         P.tile = plan.tile;
         P.split_k = plan.split;
-        // L2 pre-touch of the producer / consumer kernels: distance in k-steps | share flag << 8 (ff_gemm_tiles.h)
-        static const int pf_dist = env_int("FF_GEMM_PF", kPrefetchDist), pf_share = env_int("FF_GEMM_PF_SHARE", 1);
-        P.prefetch = pf_dist > 0 ? (std::min(pf_dist, 255) | (pf_share ? 256 : 0)) : 0;
     } else if (P.split_k <= 0) P.split_k = gemm_pick_split(dtype, P.M, P.N, P.K, P.nz);
     const int kq = dtype == FF_DTYPE_BF16 ? kBK : kFBK;
     P.k_per_split = cdiv(cdiv(P.K, P.split_k), kq) * kq;

@@ -109,32 +109,6 @@ template <int BR, int LAYOUT> FF_DEV bf16x8 frag_read2(const bf16* s, int r0, in
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// L2 pre-touch.  The operand tiles of a k-step are fetched by every workgroup that shares them (the 8 row-panel workgroups of one XCD
-// all pull the same weight tile at the same time) and arrive at HBM latency; a CU keeps only a bounded number of requests in flight, so
-// latency, not bandwidth, sets its operand rate.  The MFMA waves therefore touch the lines of tile kt + D a few
-// k-steps before the DMA asks for them - ONE 4-byte LDS-DMA load per 128-byte line into a scratch LDS word (no register destination, so
-// nothing to wait for or to keep alive), each workgroup only its share of the lines it has in common with its co-resident neighbours.
-// touch_offset: byte offset of the line lane `idx` (0 .. lanes-1 of the operand's lane range) touches, or kOobOffset.
-//   K-major tile: one line per row (64 k = 128 B);  M-major tile: 64 k-rows x ceil(BR * 2 / 128) segments of 128 B.
-// ------------------------------------------------------------------------------------------------
-template <int BR, int LAYOUT> FF_DEV unsigned touch_offset(const RowMap& map, int row_base, int row_lim, int idx, int share, int mine) {
-    const int line = idx * share + mine;
-    if (LAYOUT == 0) {
-        if (line >= BR || row_base + line >= row_lim) return kOobOffset;
-        return (unsigned)map.off(row_base + line) * 2u;
-    } else {
-        constexpr int SPR = (BR * 2 + 127) / 128;
-        const int kr = line / SPR, seg = line - kr * SPR;
-        const int col = row_base + seg * 64;
-        if (kr >= kBK || seg * 64 >= BR || col >= row_lim) return kOobOffset;
-        return (unsigned)((long long)kr * map.ld + col) * 2u;
-    }
-}
-FF_DEV void touch_issue(__amdgpu_buffer_rsrc_t rsrc, unsigned* scratch, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, scratch), 4, voff, soff, 0, 0);
-}
-
 template <int N> FF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 }  // namespace ff

@@ -25,7 +25,6 @@ struct GemmParams {
     int split_k, k_per_split;
     int tile;   // block tile chosen by the host (bf16: 128 = 128x128, 64 = 64x64, 6412 = 64x128, 128002 / 128160 = producer / consumer kernels)
     int force_tile, force_stages;   // explicit plan override from the descriptor (0 = automatic)
-    int prefetch;                   // L2 pre-touch of the producer / consumer kernels: distance in k-steps | share flag << 8
     int xcd_ms, xcd_ns;   // XCD partition of the tile grid (ms * ns sub-grids, one per XCD)
     float* partial;
     int a_vec_ok, b_vec_ok;

@@ -110,7 +110,7 @@ static size_t rs_ws_bytes(const RsDims& s) {
     size_t w = 0;
     auto g = [&](int M, int N, int K, int nz) { w = std::max(w, gemm_workspace_bytes(s.dt, M, N, K, nz, 0)); };
     g(Mq, s.inner, s.D, 1); g(Mkv, s.inner, s.D, 2); g(Mq, s.D, s.inner, 1); g(Mq, s.ffi, s.D, 1); g(Mq, s.D, s.ffi, 1);   // fwd
-    for (int nz = 1; nz <= kGemmMaxZ; nz++) {                                                                               // grouped wgrad
+    for (int nz = 1; nz <= 4; nz++) {                                                                                       // grouped wgrad (kRsGroup)
         g(s.D, s.ffi, Mq, nz); g(s.ffi, s.D, Mq, nz); g(s.D, s.inner, Mq, nz); g(s.inner, s.D, Mq, nz); g(s.inner, s.D, Mkv, nz);
     }
     g(Mkv, s.D, s.inner, 1);
@@ -289,8 +289,9 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
     }
     FF_TRY(layernorm_bwd_finish(s.dt, ln_sets, 3 * s.depth + 1, st));
     // ---- weight gradients, grouped over up to kGemmMaxZ layers per launch ----
-    for (int l0 = 0; l0 < s.depth; l0 += kGemmMaxZ) {
-        const int l1 = std::min(s.depth, l0 + kGemmMaxZ);
+    constexpr int kRsGroup = 4;      // layers per grouped weight-gradient launch (their tile counts are whole rounds of the chip already)
+    for (int l0 = 0; l0 < s.depth; l0 += kRsGroup) {
+        const int l1 = std::min(s.depth, l0 + kRsGroup);
         Gemm g3(s.dt, s.D, s.ffi, Mq), g1(s.dt, s.ffi, s.D, Mq), go(s.dt, s.D, s.inner, Mq), gq(s.dt, s.inner, s.D, Mq);
         g3.a(1, pD).b(1, pF).c(pF);                       // d W3 = d x_out^T . act(H)
         g1.a(1, pF).b(1, pD).c(pD);                       // d W1 = d H^T . LN(x_mid)
@@ -317,7 +318,7 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
             void* const* g = G + FF_RESAMPLER_GLOBAL_PARAMS + FF_RESAMPLER_LAYER_PARAMS * l;
             gkv.problem(W.L[l].dK, S.L[l].kv_in, g[5]);
             gkv.problem(W.L[l].dV, S.L[l].kv_in, g[6]);
-            if (gkv.P.nz == kGemmMaxZ || l == s.depth - 1) {
+            if (gkv.P.nz == kRsGroup || l == s.depth - 1) {
                 FF_TRY(gkv.run(W.ws, gws, st));
                 gkv.P.nz = 0;
             }
@@ -653,7 +654,7 @@ static int kvp_check(const ff_kvproj_desc* d) {
 }
 static size_t kvp_gemm_ws(const ff_kvproj_desc* d) {
     size_t w = 0;
-    for (int z = 1; z <= kGemmMaxZ; z++)      // the last group may hold fewer layers (and then pick a split-K plan)
+    for (int z = 1; z <= kKvProjGroup; z++)      // the last group may hold fewer layers (and then pick a split-K plan)
         w = std::max({w, gemm_workspace_bytes(d->dtype, d->rows, d->kv_dim, d->dim_visual, z, 0),
                       gemm_workspace_bytes(d->dtype, d->kv_dim, d->dim_visual, d->rows, z, 0),
                       gemm_workspace_bytes(d->dtype, d->rows, d->dim_visual, d->kv_dim, z, 0)});
@@ -672,10 +673,10 @@ static int kv_project_fwd(const ff_kvproj_desc* d, const void* vf, const void* c
     FF_TRY(kvp_check(d));
     FF_CHECK(vf && w_kv && kv_out && ws && ws_bytes >= kvp_gemm_ws(d), FF_ERR_WORKSPACE, "kv_project_fwd: null argument or workspace too small");
     const RowMap pV = plain_rows(d->dim_visual), pKV = plain_rows(d->kv_dim);
-    for (int l0 = 0; l0 < d->n_layers; l0 += kGemmMaxZ) {
+    for (int l0 = 0; l0 < d->n_layers; l0 += kKvProjGroup) {
         Gemm g(d->dtype, d->rows, d->kv_dim, d->dim_visual);
         g.a(0, pV).b(0, pV).c(pKV);
-        for (int l = l0; l < std::min(d->n_layers, l0 + kGemmMaxZ); l++) g.problem(vf, w_kv[l], kv_out[l]);
+        for (int l = l0; l < std::min(d->n_layers, l0 + kKvProjGroup); l++) g.problem(vf, w_kv[l], kv_out[l]);
         FF_TRY(g.run(ws, ws_bytes, st));
     }
     return FF_OK;
@@ -689,8 +690,8 @@ static int kv_project_bwd(const ff_kvproj_desc* d, const void* vf, const void* c
     const RowMap pV = plain_rows(d->dim_visual), pKV = plain_rows(d->kv_dim);
     char* terms = (char*)ws + gws;                                             // [n_layers][rows][dim_visual]: one product per layer
     const size_t term_bytes = (size_t)d->rows * d->dim_visual * es;
-    for (int l0 = 0; l0 < d->n_layers; l0 += kGemmMaxZ) {
-        const int l1 = std::min(d->n_layers, l0 + kGemmMaxZ);
+    for (int l0 = 0; l0 < d->n_layers; l0 += kKvProjGroup) {
+        const int l1 = std::min(d->n_layers, l0 + kKvProjGroup);
         Gemm gw(d->dtype, d->kv_dim, d->dim_visual, d->rows);                  // d W_l = d KV_l^T . vf
         gw.a(1, pKV).b(1, pV).c(pV);
         for (int l = l0; l < l1; l++) gw.problem(dkv[l], vf, dw_kv[l]);

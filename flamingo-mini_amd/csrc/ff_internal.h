@@ -6,7 +6,8 @@
 namespace ff {
 
 // ---- GEMM ----------------------------------------------------------------------------------
-constexpr int kGemmMaxZ = 4;
+constexpr int kGemmMaxZ = 12;     // same-shape problems per grouped launch (capacity; the callers choose how many they batch)
+constexpr int kKvProjGroup = 4;   // layers per K / V projection launch: 4 x 128 tiles of 128 x 128 = one full round of 2 workgroups per CU
 struct GemmProblem {
     const void* A;
     const void* B;

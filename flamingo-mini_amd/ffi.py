@@ -24,7 +24,7 @@ ACT_NONE, ACT_GELU, ACT_SQRELU, ACT_RELU = -1, 0, 1, 2
 ACTS = {"gelu": ACT_GELU, "sqrelu": ACT_SQRELU, "relu": ACT_RELU}
 ATTN_DENSE, ATTN_MEDIA = 0, 1
 RESAMPLER_GLOBAL_PARAMS, RESAMPLER_LAYER_PARAMS, XATTN_PARAMS = 4, 12, 11
-WGRAD_GROUP_MAX = 4
+WGRAD_GROUP_MAX = 12           # capacity of one ff_xattn_wgrad_grouped call (FF_WGRAD_GROUP_MAX); functional._WgradQueue.group = how many it batches
 
 
 class FusionLibraryError(RuntimeError):

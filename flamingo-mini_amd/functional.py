@@ -43,7 +43,7 @@ class _WgradQueue:
     """Deferred, grouped weight gradients of the cross-attention blocks (ff_xattn_block_bwd_kv_data / ff_xattn_wgrad_grouped).
 
     A block's backward enqueues only its data-gradient chain and parks the operands of its four weight-gradient GEMMs in a `stash`;
-    whenever WGRAD_GROUP_MAX same-shaped blocks are waiting (and once more at the end of the backward pass, through the autograd
+    whenever `group` same-shaped blocks are waiting (and once more at the end of the backward pass, through the autograd
     engine's queue_callback) their weight gradients are computed by grouped launches that fill the chip.  The gradient tensors were
     already handed to autograd (views of the block's flat buffer): they are FILLED by the flush, which is enqueued on the same stream
     before backward() returns, so everything that consumes .grad afterwards is ordered behind it.  Blocks whose parameters already
@@ -70,6 +70,8 @@ class _WgradQueue:
     def __init__(self):
         import os
         self.enabled = os.environ.get("FF_DEFER_WGRAD", "1") == "1"
+        # blocks per grouped launch: 400 tiles of 128 x 128 per block and product at flamingo-mini's size, 512 workgroups in flight on the chip
+        self.group = max(1, min(ffi.WGRAD_GROUP_MAX, int(os.environ.get("FF_WGRAD_GROUP", "4"))))
         self._passes: dict = {}              # graph-task id -> _Pass
 
     @property
@@ -101,13 +103,13 @@ class _WgradQueue:
         st.pending.append(entry)
         st.deferred_ids.update(id(p) for p in entry["wparams"])
         same = [e for e in st.pending if e["key"] == entry["key"]]
-        if len(same) >= ffi.WGRAD_GROUP_MAX:
+        if len(same) >= self.group:
             self._run(st, same)
 
     def _flush_pending(self, st) -> None:
         while st.pending:
             key = st.pending[0]["key"]
-            self._run(st, [e for e in st.pending if e["key"] == key][: ffi.WGRAD_GROUP_MAX])
+            self._run(st, [e for e in st.pending if e["key"] == key][: self.group])
 
     def flush(self, task) -> None:
         st = self._passes.get(task)

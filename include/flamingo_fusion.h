@@ -280,7 +280,7 @@ int ff_xattn_block_bwd_kv(const ff_xattn_desc* d, const void* y, const void* k, 
  * `params` / `grads` of the grouped call: n_blocks * FF_XATTN_PARAMS pointers, block after block, the SAME gradient pointers the
  * data pass received; dy_out / saved / stash: one pointer per block (the buffers of that block's data pass).
  * ------------------------------------------------------------------------------------------------------ */
-#define FF_WGRAD_GROUP_MAX 4
+#define FF_WGRAD_GROUP_MAX 12
 size_t ff_xattn_wgrad_stash_bytes(const ff_xattn_desc* d);
 size_t ff_xattn_wgrad_workspace_bytes(const ff_xattn_desc* d);
 int ff_xattn_block_bwd_kv_data(const ff_xattn_desc* d, const void* y, const void* k, const void* v, const int* text_time,

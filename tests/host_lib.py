@@ -233,7 +233,7 @@ class HostLib:
 
     def ff_xattn_wgrad_grouped(self, d, n, dy_out, saved, saved_n, stash, stash_n, params, grads, ws, ws_n, stream):
         self.calls.append(f"ff_xattn_wgrad_grouped[{n}]")
-        assert 1 <= n <= 4
+        assert 1 <= n <= 12
         for i in range(n):
             g = self.pending.pop(int(stash[i]))
             sub = (C.c_void_p * 11)(*[grads[i * 11 + j] for j in range(11)])

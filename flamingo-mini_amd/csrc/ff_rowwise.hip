@@ -198,7 +198,12 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
         constexpr bool KEEP = NCH <= 4;                 // x-hat and dy of the row stay in registers between the two passes
+        // ... and so do the operands only the second pass needs (the residual and the two gate-gradient factors): requested together with
+        // the first pass's loads, they arrive while the row statistics are being reduced instead of behind a second memory round trip
+        constexpr bool HOIST = KEEP && VEC > 1;
         float xk[KEEP ? NCH : 1][VEC], dk[KEEP ? NCH : 1][VEC];
+        uint4 rq[HOIST ? NCH : 1], ra[HOIST ? NCH : 1], rb[HOIST ? NCH : 1];
+        const long long doff = a.dx_map.off(row);
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
             const int c = lane + 64 * i;
@@ -213,6 +218,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
                 }
                 ld<T, VEC>(dyr + c * VEC, d);
                 ld<T, VEC>(gamma + c * VEC, g);
+                if constexpr (HOIST) {
+                    if (dx_res) rq[i] = *(const uint4*)(dx_res + doff + c * VEC);
+                    if (dot_a) ra[i] = *(const uint4*)(dot_a + doff + c * VEC);
+                    if (dot_b) rb[i] = *(const uint4*)(dot_b + doff + c * VEC);
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; e++) {
                     const float dyh = d[e] * g[e], xh = (v[e] - mu) * rs;
@@ -223,7 +233,14 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
             }
         }
         const float m1 = wave_sum(s1) / (float)a.cols, m2 = wave_sum(s2) / (float)a.cols;
-        const long long doff = a.dx_map.off(row);
+        auto unpack = [](const uint4& r, float (&o)[VEC]) {
+            if constexpr (VEC > 1) {
+                typedef typename Vec<T>::raw raw_t;
+                const raw_t x = __builtin_bit_cast(raw_t, r);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) o[e] = to_f32(x[e]);
+            }
+        };
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
             const int c = lane + 64 * i;
@@ -254,10 +271,12 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
                 }
                 if (dx_res) {
                     float q[VEC];
-                    ld<T, VEC>(dx_res + doff + c * VEC, q);
+                    if constexpr (HOIST) unpack(rq[i], q);
+                    else ld<T, VEC>(dx_res + doff + c * VEC, q);
                     if (dot_a) {
                         float u[VEC];
-                        ld<T, VEC>(dot_a + doff + c * VEC, u);
+                        if constexpr (HOIST) unpack(ra[i], u);
+                        else ld<T, VEC>(dot_a + doff + c * VEC, u);
 #pragma unroll
                         for (int e = 0; e < VEC; e++) da += q[e] * u[e];
                     }
@@ -270,7 +289,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
                     for (int e = 0; e < VEC; e++) r[e] = to_f32(from_f32<T>(o[e]));   // the value the next kernel will read
                     if (dot_b) {
                         float u[VEC];
-                        ld<T, VEC>(dot_b + doff + c * VEC, u);
+                        if constexpr (HOIST) unpack(rb[i], u);
+                        else ld<T, VEC>(dot_b + doff + c * VEC, u);
 #pragma unroll
                         for (int e = 0; e < VEC; e++) db += r[e] * u[e];
                     }

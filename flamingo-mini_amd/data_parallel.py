@@ -31,6 +31,9 @@ def _split_kv_buckets(model: torch.nn.Module, layers_per_bucket: int = 4) -> Non
     for m in model.modules():
         if hasattr(m, "kv_project_group") and m.kv_project_group == 0:
             m.kv_project_group = layers_per_bucket
+    # the deferred weight gradients of the blocks are flushed every `layers_per_bucket` layers as well (single-GPU default: 12, which is
+    # faster per launch but would hold back every bucket until a third of backward has passed)
+    F._wgrad_queue.group = min(F._wgrad_queue.group, layers_per_bucket)
 
 
 def _bucket_is_ours(owners, ids) -> bool:

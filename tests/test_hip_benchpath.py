@@ -101,7 +101,18 @@ def check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act="gelu", c
     return worst
 
 
-def _case(dtype, b, L, N, ml_np, tag, act="gelu"):
+def _case(dtype, b, L, N, ml_np, tag, act="gelu", group=None):
+    from flamingo_mini_amd import functional as F
+    saved_group = F._wgrad_queue.group
+    if group is not None:
+        F._wgrad_queue.group = group
+    try:
+        _run_case(dtype, b, L, N, ml_np, tag, act)
+    finally:
+        F._wgrad_queue.group = saved_group
+
+
+def _run_case(dtype, b, L, N, ml_np, tag, act):
     blocks = [build_block(xattn_params(DIM, DV, HEADS, DH, FFM, alpha_attn=0.5 - 0.05 * i, alpha_ffw=-0.4 - 0.06 * i, tag=f"{tag}{i}"),
                           DIM, DV, HEADS, DH, NV, FFM, act, dtype) for i in range(LAYERS)]
     y = dev(det((b, L, DIM), tag + "y"), dtype).requires_grad_(True)
@@ -117,7 +128,8 @@ def _case(dtype, b, L, N, ml_np, tag, act="gelu"):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 def test_config_B_hoisted_deferred_blocks_full_batch(dtype):
-    """32 sequences x 32 tokens, one image (media tag at token 0): the benchmark's shapes, the single-tile fused kernels."""
+    """32 sequences x 32 tokens, one image (media tag at token 0): the benchmark's shapes, the resident-operand fused kernels, all six
+    blocks' weight gradients in one grouped call (the single-GPU default batches up to 12)."""
     ml = np.zeros((32, 32), np.int64); ml[:, 0] = 1
     _case(dtype, 32, 32, 1, ml, "BP")
 
@@ -133,7 +145,7 @@ def test_hoisted_deferred_blocks_ragged_batch_long_text(dtype):
     ml[2, [0, 1, 2, 3]] = 1
     ml[3, [95]] = 1
     ml[4, [5, 6, 40]] = 1
-    _case(dtype, b, L, N, ml, "BR", act="sqrelu")
+    _case(dtype, b, L, N, ml, "BR", act="sqrelu", group=4)      # six blocks: one grouped weight-gradient call of four and a ragged one of two
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])

@@ -57,11 +57,14 @@ def _close(a, b, tol):
 
 @pytest.fixture
 def clean_patches():
+    from flamingo_mini_amd import functional as F
+    group = F._wgrad_queue.group
     yield
     import host_lib
     import oracle_backend
     host_lib.uninstall()
     oracle_backend.uninstall()
+    F._wgrad_queue.group = group
 
 
 def test_product_autograd_on_the_host_library_matches_the_oracle_model(clean_patches):
@@ -254,6 +257,7 @@ def test_a_backward_pass_that_raises_leaves_no_stale_weight_gradient_work(clean_
     from detgen import det
     from flamingo_mini_amd import functional as F
     host, blocks, (dim, dv, heads, dh, nv, ffm) = _host_blocks(5, "qf")
+    F._wgrad_queue.group = 4            # (the single-GPU default batches up to 12 blocks: here a full group and a trailing one are wanted)
     b, L = 2, 6
     y, vf, g = det((b, L, dim), "qf-y"), det((b, 1, nv, dv), "qf-vf"), det((b, L, dim), "qf-g")
     ml = np.zeros((b, L), np.int64); ml[:, 0] = 1

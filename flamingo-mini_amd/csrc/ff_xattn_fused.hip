@@ -615,8 +615,10 @@ namespace {
 
 constexpr int kResBM = 32, kResDH = 64;
 // LDS bytes: activation rows + weight ring + fixed tiles (+ LayerNorm vectors and statistics in the forward kernel)
+// (gamma / beta are padded to whole wave-level DMA instructions - 64 pieces of 8 elements: a DMA writes all 64 lanes, out-of-range ones as zeros)
+constexpr int res_vec_elems(int dim) { return (dim + 511) / 512 * 512; }
 constexpr size_t res_lds_fwd(int dim, int nsb) {
-    return (size_t)(dim / kBK) * kResBM * kBK * 2 + (size_t)nsb * kResDH * kBK * 2 + 2 * 8192 + (size_t)2 * dim * 2 + 2 * kResBM * 4 + 64;
+    return (size_t)(dim / kBK) * kResBM * kBK * 2 + (size_t)nsb * kResDH * kBK * 2 + 2 * 8192 + (size_t)2 * res_vec_elems(dim) * 2 + 64;
 }
 constexpr size_t res_lds_bwd(int dim, int nsb) {
     return (size_t)(dim / kBK) * kResBM * kBK * 2 + (size_t)nsb * kResDH * kBK * 2 + 4 * 8192 + (size_t)5 * kTile * 4 + 64;
@@ -708,9 +710,7 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
     bf16* sK = sB + NSB * (DH * kBK);
     bf16* sV = sK + SwzLayout::tile_elems;
     bf16* s_g = sV + SwzLayout::tile_elems;
-    bf16* s_b = s_g + a.dim;
-    float* s_mean = (float*)(s_b + a.dim);
-    float* s_rstd = s_mean + BM;
+    bf16* s_b = s_g + res_vec_elems(a.dim);                             // (each padded to whole DMA instructions, see res_vec_elems)
     bf16* sQ = sB;                                                      // the weight ring is dead when Q is parked
 
     // ---- every byte the workgroup will read is requested now: its text_time row, the activation rows, gamma / beta, K / V, the first weight tiles ----

@@ -75,7 +75,7 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
         # under data parallelism the to_kv gradients of the upper layers are final - and their all-reduce starts - while backward is still
         # working on the lower ones (the data-parallel reducers set 4 = one grouped launch per call; a single bucket of all 36 to_kv
         # weights, 75 MB at flamingo-mini's size, would only become ready at the very end of backward)
-        self.kv_project_group = 0
+        self.kv_project_group = int(os.environ.get("FF_KV_GROUP", "0"))      # (the environment variable: to trace the data-parallel launch structure on one GPU)
 
     def _init_weights(self, module):  # backbones initialise themselves; fusion modules use torch defaults like the reference
         pass

@@ -76,9 +76,10 @@ line = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().s
 k = line["roofline"]["kernel"]
 line["roofline"]["traffic"] = traffic["kernels"].get(k, {}).get("hbm_bytes_per_launch")
 json.dump(line, open(os.path.join(P, f"{rnd}_bench_default.json"), "w"), indent=1)
-stock = json.loads(open(os.path.join(src, "bench_stock_backbones.json")).read().strip().splitlines()[-1])
-json.dump(stock, open(os.path.join(P, f"{rnd}_bench_stock_backbones.json"), "w"), indent=1)
-for extra in ("gemm_table.txt",):
+if os.path.exists(os.path.join(src, "bench_stock_backbones.json")):      # (round 3 on: the default line carries it as `stock_backbones`)
+    stock = json.loads(open(os.path.join(src, "bench_stock_backbones.json")).read().strip().splitlines()[-1])
+    json.dump(stock, open(os.path.join(P, f"{rnd}_bench_stock_backbones.json"), "w"), indent=1)
+for extra in ("gemm_table.txt", "bucket_timeline.txt", "caption_decode_kernels.txt", "smoke.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(P, f"{rnd}_{extra}"))
 print("dominant kernel", k, "traffic", line["roofline"]["traffic"], "frac", line["roofline"]["frac"], "value", line["value"])

@@ -202,7 +202,7 @@ class ShardedAdamW(torch.optim.Optimizer):
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  master_dtype=None, process_group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False, update_fn=None,
-                 capturable: bool = False):
+                 capturable: bool = False, overlap: bool = True):
         from .optim import FusedAdamW
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -212,7 +212,10 @@ class ShardedAdamW(torch.optim.Optimizer):
         self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
         self.master_dtype = master_dtype
         self.capturable = capturable
-        self.stream = torch.cuda.Stream() if self.cuda else None
+        # the per-bucket pipeline runs on a side stream next to backward - also on a single GPU, where it is just the update: AdamW streams
+        # 14 bytes per parameter through HBM while the backward kernels around it are bound by launch latency and the CUs' load path
+        on_gpu = torch.cuda.is_available() and any(p.is_cuda for p in model.parameters())
+        self.stream = torch.cuda.Stream() if (self.cuda or (overlap and on_gpu and update_fn is None)) else None
         self.step_count = 0
         self.buckets = {}            # ids of the bucket's parameters -> state (independent of the order the buckets arrive in)
         self._work: List = []
@@ -360,7 +363,7 @@ class ShardedAdamW(torch.optim.Optimizer):
         if self.capturable and first and flat.is_cuda:
             self._scalars(flat.device)[0].add_(1.0)       # the step counter the captured updates read, advanced on the device
         self._updated.add(key)
-        if self.cuda:
+        if self.stream is not None:
             ready = torch.cuda.Event()
             ready.record()
             if not torch.cuda.is_current_stream_capturing():

@@ -7,7 +7,8 @@ import argparse, csv, re
 def category(name):
     if "ff::gemm_bf16" in name or "ff16gemm" in name or "gemm_f32" in name: return "fusion: GEMM main kernels (hand-written MFMA)"
     if "gemm_splitk" in name: return "fusion: split-K reduce + epilogue"
-    if "attn_fwd_kernel" in name or "attn_bwd" in name: return "fusion: attention core (fwd, dQ, dK/dV)"
+    if "xa_qattn" in name or "xa_dattn" in name: return "fusion: LayerNorm + projection + attention of the gated blocks (one launch each way)"
+    if "attn_fwd_kernel" in name or "attn_bwd" in name: return "fusion: attention core of the resampler (fwd, dQ, dK/dV)"
     if "adamw_kernel" in name: return "fusion: multi-tensor AdamW (ff_adamw_step)"
     if "shifted_ce" in name: return "fusion: shifted cross-entropy (fwd + bwd)"
     if "quick_gelu" in name: return "fusion: QuickGELU of the CLIP MLPs"

@@ -871,6 +871,13 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
     if (P.tile == 6412) return run_bf16_dma_tile<64, 128>(P, ns, st);
+    static const int pc64 = env_int("FF_GEMM_PC64", 0);      // development builds: the 8-wave producer / consumer kernel for the 64 x 64 tiles too
+    if (pc64) {
+        if (P.a_layout == 0 && P.b_layout == 0) return launch_bf16_pc<64, 64, 0, 0, 3, 2>(P, st);
+        if (P.a_layout == 0 && P.b_layout == 1) return launch_bf16_pc<64, 64, 0, 1, 3, 2>(P, st);
+        if (P.a_layout == 1 && P.b_layout == 0) return launch_bf16_pc<64, 64, 1, 0, 3, 2>(P, st);
+        return launch_bf16_pc<64, 64, 1, 1, 3, 2>(P, st);
+    }
     // 64 x 64 tiles (short-K projections: 8 k-steps of 16 KiB): 3 stages - several workgroups still share a CU at 24 KiB each, and with so
     // few k-steps the extra tile in flight is worth more than the occupancy (same-box A/B of the step: 35.44 -> 35.32 ms, twice)
     return run_bf16_dma_tile<64, 64>(P, P.force_stages > 0 ? P.force_stages : ns_env > 0 ? ns_env : 3, st);

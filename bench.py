@@ -539,6 +539,10 @@ def main():
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
             if key[1] == 128160:      # the 8-wave producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU>
                 name = f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 3, 1>"
+            elif key[1] == 64002:
+                name = f"ff::gemm_bf16_pc_kernel<64, 64, {key[2]}, {key[3]}, 3, 2>"
+            elif key[1] == 3264:
+                name = "ff::gemm_bf16_pc_kernel<32, 64, 0, 0, 4, 2>"
             elif key[1] == 128002:
                 name = f"ff::gemm_bf16_pc_kernel<128, 128, {key[2]}, {key[3]}, 2, 2>"
             tot_ms = sum(v["ms"] for v in groups.values())

@@ -754,10 +754,10 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     static const int pc_bl1 = env_int("FF_GEMM_PC_BL1", 1);
     const bool pc_ok = a_layout == 0 && (b_layout == 0 || (pc_bl1 && N % 8 == 0));
     const bool skinny_ok = a_layout == 0 && b_layout == 0;      // the 32 x 64 tile stages K-major operands only
-    if (ft == 128 || ft == 64 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok)) {
+    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
-        const long long t = ft == 128 || ft == 128002 ? t128 : ft == 64 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
+        const long long t = ft == 128 || ft == 128002 ? t128 : ft == 64 || ft == 64002 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
                             : ft == 3264 ? (long long)cdiv(M, 32) * cdiv(N, 64) * nz : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
         p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
         return p;
@@ -802,6 +802,9 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     static const int pc128 = env_int("FF_GEMM_PC128", 2);      // the producer / consumer kernel for every 128 x 128 launch (0: the 4-wave kernel)
     if (pc128 && p.tile == 128) p.tile = 128002;
     if (pc128 >= 2 && p.tile == 6412) p.tile = 128002;         // ... and instead of the 64 x 128 tiles (1: keep those)
+    // ... and for the 64 x 64 tiles (short-K projections, small weight gradients): 35.32 -> 35.10 ms/step in a same-box A/B (round 3)
+    static const int pc64 = env_int("FF_GEMM_PC64", 1);
+    if (pc64 && p.tile == 64) p.tile = 64002;
     return p;
 }
 
@@ -871,8 +874,7 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
     if (P.tile == 6412) return run_bf16_dma_tile<64, 128>(P, ns, st);
-    static const int pc64 = env_int("FF_GEMM_PC64", 0);      // development builds: the 8-wave producer / consumer kernel for the 64 x 64 tiles too
-    if (pc64) {
+    if (P.tile == 64002) {       // 64 x 64 tiles on the 8-wave producer / consumer kernel, 3-stage ring
         if (P.a_layout == 0 && P.b_layout == 0) return launch_bf16_pc<64, 64, 0, 0, 3, 2>(P, st);
         if (P.a_layout == 0 && P.b_layout == 1) return launch_bf16_pc<64, 64, 0, 1, 3, 2>(P, st);
         if (P.a_layout == 1 && P.b_layout == 0) return launch_bf16_pc<64, 64, 1, 0, 3, 2>(P, st);
@@ -920,7 +922,7 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
     }
     {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
         const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : P.tile == 3264 ? 32 : 64) : kFBM;
-        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 || P.tile == 3264 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
+        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 || P.tile == 64002 || P.tile == 3264 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
         const int tiles_m = cdiv(P.M, tm_edge), tiles_n = cdiv(P.N, tn_edge);
         double best = 1e300;
         P.xcd_ms = 1; P.xcd_ns = 1;
@@ -1049,7 +1051,7 @@ extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_
     if (d->dtype == FF_DTYPE_BF16) {
         const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout, d->tile);
         *bm = p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : p.tile == 3264 ? 32 : 64;
-        *bn = p.tile == 64 || p.tile == 3264 ? 64 : p.tile == 128160 ? 160 : 128;
+        *bn = p.tile == 64 || p.tile == 64002 || p.tile == 3264 ? 64 : p.tile == 128160 ? 160 : 128;
         *split_k = p.split;
     } else {
         *bm = *bn = kFBM;

@@ -75,7 +75,7 @@ typedef struct ff_gemm_desc {
     int act_bwd;  /* FF_ACT_* or FF_ACT_NONE */
     int split_k;  /* 0 = choose automatically */
     int tile;     /* bf16 block tile: 0 = choose automatically; 128 = 128x128 (4 waves), 6412 = 64x128, 64 = 64x64,
-                   * 128002 = 128x128 producer/consumer (8 waves), 128160 = 128x160 producer/consumer (A K-major only),
+                   * 64002 / 128002 = 64x64 / 128x128 producer/consumer (8 waves), 128160 = 128x160 producer/consumer (A K-major only),
                    * 3264 = 32x64 producer/consumer (decode: M <= 32 rows; both operands K-major) */
     int stages;   /* depth of the LDS operand ring: 0 = default, 2..4 */
 } ff_gemm_desc;

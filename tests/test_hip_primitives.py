@@ -37,7 +37,7 @@ def test_gemm_every_instantiated_tile(al, bl):
     ref = (a if al == 0 else a.T) @ (b.T if bl == 0 else b)
     # 128002 / 128160: the 8-wave producer / consumer kernels (128 x 128 for every layout; 128 x 160 for a K-major A operand, B K-major or -
     # staged as a 128-column and a 32-column piece - N-contiguous)
-    for tile in (128, 6412, 64, 128002) + ((128160,) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
+    for tile in (128, 6412, 64, 64002, 128002) + ((128160,) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
         for stages in (2, 3, 4):
             for split in (1, 2):
                 C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)

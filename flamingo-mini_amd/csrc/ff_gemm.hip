@@ -667,6 +667,19 @@ template <typename T> __global__ __launch_bounds__(256) void gemm_splitk_epilogu
     const float* src = Q.partial + ((long long)z * Q.split_k * Q.M + m) * Q.N + n;
     const long long slab = (long long)Q.M * Q.N;
     int sp = 0;
+    for (; sp + 3 < Q.split_k; sp += 4) {      // four slabs per pass: eight 16-byte loads in flight before the first add (the plans split 3 .. 8 ways)
+        f32x4 lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            lo[u] = *(const f32x4*)(src + (sp + u) * slab);
+            hi[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (nv == 8) hi[u] = *(const f32x4*)(src + (sp + u) * slab + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] += lo[u][e]; v[e + 4] += hi[u][e]; }
+    }
     for (; sp + 1 < Q.split_k; sp += 2) {
         const f32x4 a0 = *(const f32x4*)(src + sp * slab), b0 = *(const f32x4*)(src + (sp + 1) * slab);
         f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, b1 = a1;

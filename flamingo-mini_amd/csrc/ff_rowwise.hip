@@ -41,6 +41,62 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a_in, const T*
     if (add) ar = add + (long long)((row % a.add_rows_per_seg) / a.add_div) * a.cols;
     const int nchunk = a.cols / VEC;
     float mu, rs;
+    if (nchunk <= 4 * 64 && VEC > 1) {
+        // the row fits four 16-byte pieces per lane: it is read ONCE and stays in registers through the two statistics passes and the
+        // normalisation (the general path below re-reads it from cache twice: two more dependent round trips in a kernel that is one row long)
+        float v[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = lane + 64 * u;
+            if (c < nchunk) {
+                ld<T, VEC>(xr + c * VEC, v[u]);
+                if (ar) {
+                    float t[VEC];
+                    ld<T, VEC>(ar + c * VEC, t);
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) v[u][i] += t[i];
+                }
+            }
+        }
+        if (a.stats_given) {
+            mu = mean[row];
+            rs = rstd[row];
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (lane + 64 * u < nchunk)
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) s += v[u][i];
+            mu = wave_sum(s) / (float)a.cols;
+            float q = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (lane + 64 * u < nchunk)
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) q += (v[u][i] - mu) * (v[u][i] - mu);
+            rs = rsqrtf(wave_sum(q) / (float)a.cols + a.eps);
+            if (lane == 0 && mean) {
+                mean[row] = mu;
+                rstd[row] = rs;
+            }
+        }
+        if (!y) return;
+        T* yr = y + a.y_map.off(row);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = lane + 64 * u;
+            if (c < nchunk) {
+                float g[VEC], b[VEC], o[VEC];
+                ld<T, VEC>(gamma + c * VEC, g);
+                ld<T, VEC>(beta + c * VEC, b);
+#pragma unroll
+                for (int i = 0; i < VEC; i++) o[i] = (v[u][i] - mu) * rs * g[i] + b[i];
+                st<T, VEC>(yr + c * VEC, o);
+            }
+        }
+        return;
+    }
     if (a.stats_given) {
         mu = mean[row];
         rs = rstd[row];

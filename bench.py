@@ -75,6 +75,8 @@ def parse():
                     help="fused = ff_adamw_step on bf16 parameters with bf16 moments; fused-master = the same kernel with fp32 master weights and fp32 "
                          "moments (the reference's --fp16 recipe, training/train.sh:24); sharded(-master) = data_parallel.ShardedAdamW (reduce-scatter -> "
                          "update of this rank's 1/N slice -> all-gather per gradient bucket, replaces the gradient all-reduce); torch = torch.optim.AdamW(fused=True)")
+    ap.add_argument("--reduce-dtype", default="native", choices=["native", "f32"],
+                    help="N > 1 with the all-reduce path: exchange gradient buckets in their own dtype (bf16, ReduceOp.AVG) or widened to fp32")
     ap.add_argument("--companions", default="auto", choices=["auto", "on", "off"],
                     help="N=1 only: after the main measurement, re-run the same workload in child processes (a) with the untouched Hugging Face backbones "
                          "and no tuning file, (b) with the fp32-master / fp32-moment optimizer, and add both to the JSON line (auto = on for the default config B run)")
@@ -410,7 +412,7 @@ def main():
     opt = make_optimizer(use_graph)
     sharded = args.optimizer.startswith("sharded") and opt is not None
     # ShardedAdamW does the exchange itself (reduce-scatter / all-gather per bucket); otherwise the buckets are all-reduced
-    reducer = None if sharded else GradientAllReducer(model)
+    reducer = None if sharded else GradientAllReducer(model, reduce_dtype=torch.float32 if args.reduce_dtype == "f32" else None)
 
     def eager_step():
         for p in params:                 # == model.zero_grad(set_to_none=True) without walking the ~1000 frozen parameters (4 ms of host time)

@@ -39,6 +39,12 @@ def remove_grad_ready_callback(fn) -> None:
         _grad_ready_callbacks.remove(fn)
 
 
+def _graph_task_id() -> int:
+    """Id of the autograd engine's running backward pass; -1 outside any backward."""
+    get = getattr(torch._C, "_current_graph_task_id", None)
+    return get() if get is not None else -1
+
+
 class _WgradQueue:
     """Deferred, grouped weight gradients of the cross-attention blocks (ff_xattn_block_bwd_kv_data / ff_xattn_wgrad_grouped).
 
@@ -69,7 +75,9 @@ class _WgradQueue:
 
     def __init__(self):
         import os
-        self.enabled = os.environ.get("FF_DEFER_WGRAD", "1") == "1"
+        # the per-pass bookkeeping needs the engine's graph-task id; a torch build without that (private) accessor runs the plain,
+        # non-deferred backward instead of guessing which pass an entry belongs to
+        self.enabled = os.environ.get("FF_DEFER_WGRAD", "1") == "1" and hasattr(torch._C, "_current_graph_task_id")
         # Blocks per grouped launch.  At flamingo-mini's size a block contributes 400 tiles of 128 x 128 per product and the chip holds 512
         # workgroups at a time: 4 blocks = 3.1 rounds (the last one a quarter full), 12 blocks = 9.4 - measured 35.9 -> 35.5 ms per step
         # (weight-gradient launches 704 -> 830 TFLOP/s).  Data-parallel reducers lower it to 4 so that gradient buckets keep becoming final
@@ -83,12 +91,12 @@ class _WgradQueue:
 
     def forget_dead_passes(self) -> None:
         """Called from a forward: outside any backward pass, whatever the queue still holds belongs to passes that raised."""
-        if self._passes and torch._C._current_graph_task_id() < 0:
+        if self._passes and _graph_task_id() < 0:
             self._passes.clear()
 
     def seen_in_this_pass(self, params) -> bool:
         """True if one of `params` already has a deferred gradient in the running pass (the caller must then not defer again)."""
-        st = self._passes.get(torch._C._current_graph_task_id())
+        st = self._passes.get(_graph_task_id())
         if st is None:
             return False
         hit = [id(p) for p in params if id(p) in st.deferred_ids]
@@ -98,7 +106,7 @@ class _WgradQueue:
         return bool(hit)
 
     def push(self, entry) -> None:
-        task = torch._C._current_graph_task_id()
+        task = _graph_task_id()
         st = self._passes.get(task)
         if st is None:
             st = self._passes[task] = self._Pass()

@@ -170,3 +170,68 @@ def test_config_B_resampler_full_batch(dtype):
     bad = {k: v for k, v in worst.items() if not v < t["grad"]}
     print(f"[benchpath resampler {dtype}] worst parameter-gradient errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:4], flush=True)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_reused_block_and_accumulated_gradients_on_the_deferred_path(dtype):
+    """The two situations in which a block must NOT defer its weight gradients, on the real kernels at config B's geometry: a module applied
+    twice in one backward pass (weight sharing / activation-checkpoint recompute: the engine sums the two contributions the moment the second
+    one is returned, functional._WgradQueue.seen_in_this_pass) and a second backward onto existing .grad tensors (gradient accumulation).
+    Oracle: the chain m0 -> m1 -> m0 in float64; the gradients of m0 are the sum of its two uses, and after the second pass twice that."""
+    from flamingo_mini_amd import functional as F
+    b, L, N, tag = 4, 32, 1, "reuse"
+    t = TOL[dtype]
+    blocks = [build_block(xattn_params(DIM, DV, HEADS, DH, FFM, alpha_attn=0.5 - 0.1 * i, alpha_ffw=-0.4 - 0.1 * i, tag=f"{tag}{i}"),
+                          DIM, DV, HEADS, DH, NV, FFM, "gelu", dtype) for i in range(2)]
+    order = [0, 1, 0]
+    ml_np = np.zeros((b, L), dtype=bool)
+    ml_np[:, 0] = True
+    ml = torch.as_tensor(ml_np).cuda()
+    y = dev(det((b, L, DIM), tag + "y"), dtype).requires_grad_(True)
+    vf = dev(det((b, N, NV, DV), tag + "vf"), dtype).requires_grad_(True)
+    g = dev(det((b, L, DIM), tag + "g"), dtype)
+
+    def one_pass():
+        kvs = F.kv_project(vf, [m.attn.to_kv.weight for m in blocks])
+        h = y
+        for i in order:
+            h, _ = blocks[i](h, vf, ml, hoisted_kv=kvs[i])
+        h.backward(g)
+        assert not F._wgrad_queue.pending
+        return h
+
+    out = one_pass()
+    p64 = [{k: as64(v) for k, v in m.state_dict().items()} for m in blocks]
+    vf64, h, caches = as64(vf), as64(y), []
+    for i in order:
+        h, _, c = O.gated_xattn_block_fwd(h, vf64, ml_np, p64[i], act="gelu")
+        caches.append(c)
+    assert rel(out, h) < t["out"] * 3
+    d, dvf = as64(g), np.zeros_like(vf64)
+    grads = [dict(), dict()]
+    for pos in reversed(range(len(order))):
+        i = order[pos]
+        d, dvf_i, g_r = O.gated_xattn_block_bwd(d, caches[pos], p64[i], act="gelu")
+        dvf += dvf_i
+        for k, v in g_r.items():
+            grads[i][k] = grads[i].get(k, 0.0) + v
+    worst = {}
+
+    def check(scale, what):
+        worst[f"{what}.dy"] = rel(y.grad, scale * d) / (t["grad"] * 3)
+        worst[f"{what}.dvf"] = rel(vf.grad, scale * dvf) / (t["grad"] * 3)
+        for i, m in enumerate(blocks):
+            for k, prm in m.named_parameters():
+                ref = scale * grads[i][k]
+                if ref.size == 1:       # gate gradients: a dot product over all elements, held on the scale of the larger of the two
+                    top = max(abs(float(v)) for gr in grads for kk, v in gr.items() if v.size == 1) * scale
+                    worst[f"{what}.block{i}.{k}"] = abs(float(prm.grad) - float(ref)) / (t["grad"] * 3 * top + 1e-30)
+                else:
+                    worst[f"{what}.block{i}.{k}"] = rel(prm.grad, ref) / (t["grad"] * 3)
+
+    check(1.0, "reuse")
+    one_pass()                          # no zero_grad: every .grad exists now, so nothing defers and autograd accumulates
+    check(2.0, "accumulate")
+    print(f"[benchpath {tag} {dtype}] worst error / bound:", {k: round(v, 3) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]}, flush=True)
+    bad = {k: round(v, 3) for k, v in worst.items() if not v < 1.0}
+    assert not bad, f"error / bound >= 1: {bad}"

@@ -22,12 +22,37 @@ from typing import Callable, Dict, Optional
 import torch
 
 
+def _refuse_live_autograd_graphs(model: torch.nn.Module) -> None:
+    """A parameter's AccumulateGrad node lives as long as some autograd graph refers to it and remembers the stream it was created on.  If
+    outputs of an earlier eager forward (built on the default stream) are still alive, the captured backward would hand its gradients to
+    those nodes: the engine then synchronises the capturing stream with the default stream in the middle of the capture - on ROCm 7 a
+    segmentation fault in the runtime at the end of the capture (tools/capture_after_eager.py), not an error message.  Refuse up front.
+    The probe: a mark left in the node's metadata survives only if somebody else keeps the node alive."""
+    def accumulator(p):
+        return p.view_as(p).grad_fn.next_functions[0][0]
+
+    stale = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        accumulator(p).metadata["ff_capture_probe"] = True
+        node = accumulator(p)
+        if node.metadata.pop("ff_capture_probe", False):
+            stale.append(name)
+    if stale:
+        raise RuntimeError(
+            f"GraphedTrainStep: an autograd graph from an earlier forward still refers to {len(stale)} parameter(s) of the model (e.g. "
+            f"{stale[0]}). Delete the outputs / losses of earlier forward passes (or run them under torch.no_grad()) before capturing: "
+            "their gradient-accumulation nodes are bound to the stream of that forward and cannot take part in a stream capture.")
+
+
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
                  warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a GPU")
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
+        _refuse_live_autograd_graphs(model)
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self._loss_fn = loss_fn or (lambda out: out.loss)
         side = torch.cuda.Stream()

@@ -172,10 +172,19 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
                          past_key_values=lm_past, return_dict=True, **kwargs)
         if head_mask is not None:
             lm_kwargs["head_mask"] = head_mask
-        out = self.lm(**lm_kwargs)
+        try:
+            out = self.lm(**lm_kwargs)
+        finally:
+            # The conditioning is per call: dropping it here releases the hoisted K / V of every layer and - more importantly - the autograd
+            # graph behind them.  The reference leaves it on the hooks until the next call; a graph kept alive that way pins the parameters'
+            # AccumulateGrad nodes to the stream of THIS forward, which breaks a later capture of the step on another stream (graphs.py).
+            for hook in hooks:
+                hook.condition(None, None)
         logits = self.lm_head(out.last_hidden_state)
 
-        new_xattn_past = [hook.kv_output for hook in self.get_modified_layers()] if use_cache else None
+        new_xattn_past = [hook.kv_output for hook in hooks] if use_cache else None
+        for hook in hooks:
+            hook.kv_output = None
 
         loss = None
         if labels is not None:   # tokens < n predict n (reference :288-298)

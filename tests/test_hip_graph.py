@@ -182,3 +182,19 @@ def test_sharded_adamw_on_one_rccl_rank_equals_fused_adamw(one_rank_rccl, master
     assert len(opt_s.buckets) == 4, {k: st["sig"][0] for k, st in opt_s.buckets.items()}     # resampler, the hoisted to_kv weights, two blocks
     for (n, pa), (_, pb) in zip(plain.named_parameters(), sharded.named_parameters()):
         assert rel(pb, pa) < 1e-2, n
+
+
+@pytest.mark.parametrize("mode,expect", [("drop", 0), ("nograd", 0), ("keep", 3)])
+def test_capture_after_an_eager_forward_of_the_same_model(mode, expect):
+    """tools/capture_after_eager.py in a child process (the failure this guards against was a segmentation fault inside the runtime):
+    an eager forward with gradients enabled before the capture is fine once its outputs are gone (the hooks keep no conditioning),
+    a forward under no_grad always is, and outputs that are still alive make GraphedTrainStep refuse (exit code 3) instead of crashing."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "capture_after_eager.py"), mode], capture_output=True, text=True, timeout=600)
+    assert res.returncode == expect, (res.returncode, res.stdout[-600:], res.stderr[-600:])
+    assert ("refused:" in res.stdout) == (expect == 3)
+    if expect == 0:
+        assert "captured; replays:" in res.stdout

@@ -241,3 +241,49 @@ def test_generation_strategies_cpu_with_oracle_checker(family):
             model.generate(ids, no_repeat_ngram_size=2, **kw)
     finally:
         oracle_backend.uninstall()
+
+
+def test_graphed_step_refuses_live_autograd_graphs():
+    """graphs._refuse_live_autograd_graphs: outputs of an earlier forward keep the parameters' AccumulateGrad nodes (and the stream they
+    were created on) alive - capturing a step then crashed inside the ROCm runtime; the constructor must say so instead."""
+    from flamingo_mini_amd.graphs import _refuse_live_autograd_graphs
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
+    net[1].weight.requires_grad_(False)
+    _refuse_live_autograd_graphs(net)                      # nothing alive
+    out = net(torch.randn(3, 4)).sum()
+    with pytest.raises(RuntimeError, match="autograd graph from an earlier forward"):
+        _refuse_live_autograd_graphs(net)
+    out.backward()                                         # buffers are freed by backward, the nodes are still referenced by `out`
+    with pytest.raises(RuntimeError, match="autograd graph from an earlier forward"):
+        _refuse_live_autograd_graphs(net)
+    del out
+    _refuse_live_autograd_graphs(net)
+    with torch.no_grad():
+        kept = net(torch.randn(3, 4))
+    _refuse_live_autograd_graphs(net)
+    assert kept.grad_fn is None
+
+
+def test_forward_leaves_no_conditioning_on_the_hooks():
+    """The conditioning (visual features, hoisted K / V, cached K / V) is per call: after forward() the hooks hold nothing, so neither the
+    tensors nor the autograd graph behind them outlive the outputs (the reference keeps them until the next call)."""
+    import gc
+    import oracle_backend
+    from flamingo_mini_amd.graphs import _refuse_live_autograd_graphs
+    oracle_backend.install()
+    try:
+        model, z = build(torch.float64, "cpu", "gpt2")
+        model.flamingo.hoist_kv = True
+        px = torch.from_numpy(z["px"])
+        ids, ml = torch.from_numpy(z["ids"]), torch.from_numpy(z["ml"])
+        model.train()
+        out = model(input_ids=ids, attention_mask=torch.ones_like(ids), media_locations=ml, pixel_values=px, labels=ids)
+        for hook in model.flamingo.get_modified_layers():
+            assert hook.visual_features is None and hook.hoisted_kv is None and hook.xattn_layer_past is None and hook.kv_output is None
+        with pytest.raises(RuntimeError, match="autograd graph from an earlier forward"):
+            _refuse_live_autograd_graphs(model)            # `out` is alive
+        del out
+        gc.collect()
+        _refuse_live_autograd_graphs(model)                # nothing else holds on to the graph
+    finally:
+        oracle_backend.uninstall()

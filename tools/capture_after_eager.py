@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Does building a GraphedTrainStep after an eager forward of the same model (whose autograd graph is still alive) break the capture?
-(round 3, session 1: a segmentation fault in capture_end with exactly that sequence)   python tools/capture_after_eager.py keep|drop|nograd"""
+"""Building a GraphedTrainStep after an eager forward of the same model.   python tools/capture_after_eager.py keep|drop|nograd
+Round 3, sessions 1 and 14: with the autograd graph of that forward still alive - through its outputs, or through the conditioning the
+hooks used to keep - the capture ended in a segmentation fault (AccumulateGrad nodes bound to the default stream inside a stream capture).
+Now: `drop` and `nograd` capture and replay; `keep` is refused by GraphedTrainStep with an explanation (exit code 3)."""
 import gc, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
@@ -22,5 +24,9 @@ if mode == "drop":
     del out
     gc.collect()
 opt = FusedAdamW(list(model.parameters_trainable()), lr=1e-4, capturable=True)
-step = GraphedTrainStep(model, opt, batch, warmup=1)
+try:
+    step = GraphedTrainStep(model, opt, batch, warmup=1)
+except RuntimeError as e:
+    print("refused:", e, flush=True)
+    sys.exit(3)
 print("captured; replays:", [round(float(step()), 4) for _ in range(3)], flush=True)

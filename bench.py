@@ -545,6 +545,8 @@ def main():
                 name = f"ff::gemm_bf16_pc_kernel<64, 64, {key[2]}, {key[3]}, 3, 2>"
             elif key[1] == 3264:
                 name = "ff::gemm_bf16_pc_kernel<32, 64, 0, 0, 4, 2>"
+            elif key[1] == 3216:
+                name = "ff::gemm_bf16_rows32_kernel"
             elif key[1] == 128002:
                 name = f"ff::gemm_bf16_pc_kernel<128, 128, {key[2]}, {key[3]}, 2, 2>"
             tot_ms = sum(v["ms"] for v in groups.values())

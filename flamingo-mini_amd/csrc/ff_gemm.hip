@@ -539,6 +539,89 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight-streaming kernel for decode-shaped products: M <= 32 activation rows (one token per sequence), both operands K-major.
+// Nothing is staged in LDS: a workgroup owns 16 output columns, its NW waves split K between them, every lane loads the 16 bytes of weight
+// row (n0 + c), k-chunk g that ARE its B fragment of v_mfma_f32_16x16x32_bf16, plus the two matching A fragments of the 32 activation rows,
+// keeps two batches of four k-steps in flight, and the partial 32 x 16 tiles of the waves meet in LDS (NW x 2 KiB) for the usual epilogue.
+// Measured in isolation (tools/decode_gemm_bench.py: cold weights, graph replay, us per launch incl. the gap) against the 32 x 64 tiles:
+// to_out 1280 x 512: 3.7 vs 5.0; to_q 512 x 1280: 5.8-6.7 vs 7.9; FFW up 5120 x 1280: 12.2-13.0 vs 9.6; FFW down 1280 x 5120: 20-23 vs 10.7
+// (incl. its split-K reduce).  The long products lose because every workgroup re-reads ALL activation rows as fragments - 2 bytes of
+// activations per byte of weights, 26 MB of 64-byte gathers on the same few hundred L2 lines; with those loads removed the same kernel
+// needs 5.9 / 7.4 us, of which 2.9 us is the fixed cost of a launch.  The planner therefore uses it for short-K products only (K <= 1024).
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_rows32_kernel(const GemmParams P) {
+    __shared__ f32x4 red[NW][2][64];
+    const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n0 = blockIdx.x * 16;
+    const GemmProblem& pr = P.p[0];
+    const int steps = P.K / 32, spw = (steps + NW - 1) / NW;
+    const int s_begin = w * spw, s_end = min(steps, s_begin + spw);
+    // buffer loads: a lane without a row (n0 + c >= N, c >= M) and a k-step beyond the wave's share read zeros through an out-of-range
+    // offset - no branches around the loads
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pr.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)pr.B, 0, 0x7fffffff, 0x00020000);
+    const int gk = g * 8;                           // k-chunk of lane group g in k-step s: elements s * 32 + 8 g .. + 7
+    const unsigned b_off = n0 + c < P.N ? (unsigned)(P.b_map.off(n0 + c) + gk) * 2u : kOobOffset;
+    const unsigned a0_off = c < P.M ? (unsigned)(P.a_map.off(c) + gk) * 2u : kOobOffset;
+    const unsigned a1_off = 16 + c < P.M ? (unsigned)(P.a_map.off(16 + c) + gk) * 2u : kOobOffset;
+    constexpr int SB = 4;                           // k-steps per batch; two batches (2 x 12 loads of 16 bytes per lane) in flight
+    bf16x8 fb0[SB], fa00[SB], fa10[SB], fb1[SB], fa01[SB], fa11[SB];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, bool in) {      // (nontemporal weight loads measured 3-10 % slower here)
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, in ? off : kOobOffset, soff, 0));
+    };
+    auto load = [&](bf16x8* fb, bf16x8* fa0, bf16x8* fa1, int s0) {
+#pragma unroll
+        for (int i = 0; i < SB; i++) {
+            const bool in = s0 + i < s_end;         // wave-uniform
+            const int st = s0 + i;
+            const unsigned soff = in ? (unsigned)st * 64u : 0u;
+            fb[i] = ld(rb, b_off, soff, in);
+            fa0[i] = ld(ra, a0_off, soff, in);
+            fa1[i] = ld(ra, a1_off, soff, in);
+        }
+    };
+    auto mma = [&](const bf16x8* fb, const bf16x8* fa0, const bf16x8* fa1, int s0) {
+#pragma unroll
+        for (int i = 0; i < SB; i++)
+            if (s0 + i < s_end) {
+                acc0 = mfma_bf16(fb[i], fa0[i], acc0);      // D[n][m]: lane (c, g) holds row m = c (+16), columns n0 + 4 g .. + 3
+                acc1 = mfma_bf16(fb[i], fa1[i], acc1);
+            }
+    };
+    load(fb0, fa00, fa10, s_begin);
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * SB) {
+        load(fb1, fa01, fa11, s0 + SB);
+        mma(fb0, fa00, fa10, s0);
+        load(fb0, fa00, fa10, s0 + 2 * SB);
+        mma(fb1, fa01, fa11, s0 + SB);
+    }
+    red[w][0][l] = acc0;
+    red[w][1][l] = acc1;
+    __syncthreads();
+    if (t < 128) {                                  // wave 0: rows 0..15, wave 1: rows 16..31
+        const int i = t >> 6;
+        f32x4 sum = red[0][i][l];
+#pragma unroll
+        for (int ww = 1; ww < NW; ww++) sum += red[ww][i][l];
+        const int m = i * 16 + c, n = n0 + g * 4;
+        if (m < P.M && n < P.N) {
+            float v[4] = {sum[0], sum[1], sum[2], sum[3]};
+            epilogue4<bf16>(P, pr, m, n, v);
+        }
+    }
+}
+static int launch_bf16_rows32(const GemmParams& P, hipStream_t st) {
+    const int steps = P.K / 32, grid = cdiv(P.N, 16);
+    if (steps <= 40) hipLaunchKernelGGL(gemm_bf16_rows32_kernel<4>, dim3(grid), dim3(256), 0, st, P);      // up to 10 k-steps per wave
+    else if (steps <= 80) hipLaunchKernelGGL(gemm_bf16_rows32_kernel<8>, dim3(grid), dim3(512), 0, st, P);
+    else hipLaunchKernelGGL(gemm_bf16_rows32_kernel<16>, dim3(grid), dim3(1024), 0, st, P);
+    return check_launch("gemm_bf16_rows32");
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 kernel (exact): 64x64x16 tiles, LDS tiles always stored [k][row]
 // ------------------------------------------------------------------------------------------------
 constexpr int kFBM = 64, kFBK = 16, kFLd = 80;
@@ -767,6 +850,8 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     static const int pc_bl1 = env_int("FF_GEMM_PC_BL1", 1);
     const bool pc_ok = a_layout == 0 && (b_layout == 0 || (pc_bl1 && N % 8 == 0));
     const bool skinny_ok = a_layout == 0 && b_layout == 0;      // the 32 x 64 tile stages K-major operands only
+    const bool rows_ok = skinny_ok && M <= 32 && nz == 1 && K % 32 == 0;      // the weight-streaming kernel (tile code 3216)
+    if (ft == 3216 && rows_ok) return TilePlan{3216, 1};
     if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
@@ -783,6 +868,9 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     // N / 64 workgroups, so short-K products need no split-K (and no reduce launch) at all and long-K ones split just enough to occupy
     // ~160 CUs (measured in the caption leg: 8 -> 5 library launches per gated block and token)
     static const int skinny_on = env_int("FF_GEMM_SKINNY", 1);
+    // ... and, round 3, no tiles at all for short-K products (the attention output projection): the weight-streaming kernel, never split
+    static const int rows_on = env_int("FF_GEMM_ROWS32", 1);
+    if (rows_on && rows_ok && K <= 1024 && want_split <= 1) return TilePlan{3216, 1};
     if (skinny_on && skinny_ok && M <= 32 && nz == 1) {
         const int t = cdiv(N, 64);
         int sp = 1;
@@ -884,6 +972,7 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
         return pns == 4 ? launch_bf16_pc<128, 160, 0, 1, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 1, 3, 1>(P, st);
     }
     if (P.tile == 128002) return dispatch_bf16_pc128<2>(P, st);
+    if (P.tile == 3216) return launch_bf16_rows32(P, st);
     if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
     if (P.tile == 6412) return run_bf16_dma_tile<64, 128>(P, ns, st);
@@ -934,8 +1023,8 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.partial = (float*)workspace;
     }
     {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
-        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : P.tile == 3264 ? 32 : 64) : kFBM;
-        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 64 || P.tile == 64002 || P.tile == 3264 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
+        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : P.tile == 3264 || P.tile == 3216 ? 32 : 64) : kFBM;
+        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 3216 ? 16 : P.tile == 64 || P.tile == 64002 || P.tile == 3264 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
         const int tiles_m = cdiv(P.M, tm_edge), tiles_n = cdiv(P.N, tn_edge);
         double best = 1e300;
         P.xcd_ms = 1; P.xcd_ns = 1;
@@ -1063,8 +1152,8 @@ extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_
     FF_CHECK(d && bm && bn && split_k, FF_ERR_SHAPE, "ff_gemm_plan: null argument");
     if (d->dtype == FF_DTYPE_BF16) {
         const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout, d->tile);
-        *bm = p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : p.tile == 3264 ? 32 : 64;
-        *bn = p.tile == 64 || p.tile == 64002 || p.tile == 3264 ? 64 : p.tile == 128160 ? 160 : 128;
+        *bm = p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : p.tile == 3264 || p.tile == 3216 ? 32 : 64;
+        *bn = p.tile == 3216 ? 16 : p.tile == 64 || p.tile == 64002 || p.tile == 3264 ? 64 : p.tile == 128160 ? 160 : 128;
         *split_k = p.split;
     } else {
         *bm = *bn = kFBM;

@@ -180,6 +180,11 @@ def test_gemm_plan_for_the_benchmark_shapes():
     assert plan(4096, 4096, 4096) == (128, 128, 1)
     bm, bn, sk = plan(512, 1024, 10272, 1, 1)                # resampler dWk/dWv: 32 tiles, K = 10272
     assert (bm, bn) == (128, 128) and sk >= 4
+    # decode (at most 32 rows)
+    assert plan(32, 1280, 512) == (32, 16, 1) and plan(1, 1280, 1024) == (32, 16, 1)      # short K (to_out): weight-streaming kernel
+    assert plan(32, 5120, 1280) == (32, 64, 1) and plan(32, 1280, 5120)[:2] == (32, 64)      # long K: 32 x 64 tiles (activation re-reads, see ff_gemm.hip)
+    assert plan(32, 1280, 520) == (32, 64, 1)                # K % 32 != 0: the 32 x 64 tiles
+    assert plan(33, 5120, 1280)[0] > 32
 
 
 def test_reference_parameter_counts():

@@ -82,23 +82,37 @@ def test_gemm_balanced_producer_consumer_tile():
     assert rel(F().gemm(A, B, b_layout=1), as64(A) @ as64(B)) < TOL[dt]["out"]
 
 
-def test_gemm_decode_rows_bf16():
-    """M <= 32 rows (one decoded token per sequence): the 32 x 64 tile plan on the gated block's decode products, with their epilogues."""
+@pytest.mark.parametrize("tile", [0, 3264], ids=["weight-streaming", "32x64-tiles"])
+def test_gemm_decode_rows_bf16(tile):
+    """M <= 32 rows (one decoded token per sequence) on the gated block's decode products, with their epilogues: the weight-streaming kernel
+    the planner picks (gemm_bf16_rows32_kernel: 16 output columns per workgroup, K split over its waves, no tiles) and the 32 x 64 tile plan
+    it replaced (still what a K that is not a multiple of 32 gets)."""
     dt = torch.bfloat16
     gate = dev(np.array([0.7]), dt)
     g = np.tanh(as64(gate)[0])
-    for M in (32, 5, 1):
+    kw = dict(tile=tile) if tile else {}
+    for M in (32, 17, 5, 1):
         A, B, R = dev(rnd((M, 512), 41, 0.5), dt), dev(rnd((1280, 512), 42, 0.05), dt), dev(rnd((M, 1280), 43), dt)
-        C, aux = F().gemm(A, B, residual=R, gate=gate, want_aux_out=True)                    # to_out + gate + residual
+        C, aux = F().gemm(A, B, residual=R, gate=gate, want_aux_out=True, **kw)              # to_out + gate + residual
         acc = as64(A) @ as64(B).T
         assert rel(aux, acc) < TOL[dt]["out"] and rel(C, as64(R) + g * acc) < TOL[dt]["out"]
         A, B = dev(rnd((M, 1280), 44, 0.5), dt), dev(rnd((5120, 1280), 45, 0.05), dt)
-        C, aux = F().gemm(A, B, act="gelu", want_aux_out=True)                               # FFW up-projection
+        C, aux = F().gemm(A, B, act="gelu", want_aux_out=True, **kw)                         # FFW up-projection
         acc = as64(A) @ as64(B).T
         assert rel(aux, acc) < TOL[dt]["out"] and rel(C, O.act_fwd(acc, "gelu")) < TOL[dt]["out"]
         A, B, R = dev(rnd((M, 5120), 46, 0.5), dt), dev(rnd((1280, 5120), 47, 0.02), dt), dev(rnd((M, 1280), 48), dt)
-        C = F().gemm(A, B, residual=R, gate=gate)                                            # FFW down-projection: long K -> split-K
+        C = F().gemm(A, B, residual=R, gate=gate, **kw)                                      # FFW down-projection: long K
         assert rel(C, as64(R) + g * (as64(A) @ as64(B).T)) < TOL[dt]["out"]
+        A, B = dev(rnd((M, 1280), 49, 0.5), dt), dev(rnd((512, 1280), 50, 0.05), dt)
+        C = F().gemm(A, B, scale=0.125, **kw)                                                # to_q * scale
+        assert rel(C, 0.125 * (as64(A) @ as64(B).T)) < TOL[dt]["out"]
+        # ragged: a partial last column group (N % 16 = 4), k-steps that do not divide among the waves (41), and a K tail (the tile plan)
+        for N, K in ((1284, 1312), (1284, 1304)):
+            A, B, H = dev(rnd((M, K), 51, 0.5), dt), dev(rnd((N, K), 52, 0.05), dt), dev(rnd((M, N), 53), dt)
+            acc, h = as64(A) @ as64(B).T, as64(H)
+            for act in ("gelu", "sqrelu", "relu"):
+                C = F().gemm(A, B, act_bwd=act, aux_in=H, gate=gate, **kw)
+                assert rel(C, acc * g * O.act_bwd(np.ones_like(h), h, act)) < TOL[dt]["out"], (M, N, K, act)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

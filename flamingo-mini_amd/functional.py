@@ -72,7 +72,6 @@ class _WgradQueue:
             self.done: list = []
             self.deferred_ids: set = set()   # parameters with a deferred gradient in this pass
             self.summed_ids: set = set()     # ... that received a second contribution: autograd holds their SUM, nothing to repair
-            self.side: set = set()           # side streams that carry launches of this pass (joined by flush)
 
     def __init__(self):
         import os
@@ -85,10 +84,6 @@ class _WgradQueue:
         # - and their exchange keeps starting - every four layers of backward (data_parallel._split_kv_buckets).
         self.group = max(1, min(ffi.WGRAD_GROUP_MAX, int(os.environ.get("FF_WGRAD_GROUP", "12"))))
         self._passes: dict = {}              # graph-task id -> _Pass
-        # Experiment (FF_WGRAD_STREAM=1): the grouped launches go to a side stream that forks from the backward stream when their operands are
-        # complete and is joined again at the end of the pass, so the weight gradients run beside the (latency-bound) data-gradient chain.
-        self.side_stream = os.environ.get("FF_WGRAD_STREAM", "0") == "1"
-        self._side: dict = {}                # device -> torch.cuda.Stream
 
     @property
     def pending(self) -> list:
@@ -108,7 +103,6 @@ class _WgradQueue:
         if hit:
             st.summed_ids.update(hit)
             self._flush_pending(st)          # the first contribution must be complete before autograd adds the second one to it
-            self._join_side(st)
         return bool(hit)
 
     def push(self, entry) -> None:
@@ -123,11 +117,6 @@ class _WgradQueue:
         if len(same) >= self.group:
             self._run(st, same)
 
-    @staticmethod
-    def _join_side(st) -> None:
-        for side in st.side:
-            torch.cuda.current_stream(side.device).wait_stream(side)
-
     def _flush_pending(self, st) -> None:
         while st.pending:
             key = st.pending[0]["key"]
@@ -139,7 +128,6 @@ class _WgradQueue:
             return
         try:
             self._flush_pending(st)
-            self._join_side(st)
             for e in st.done:        # every AccumulateGrad of this backward pass has run by now
                 for p, (off, n) in zip(e["wparams"], e["wslices"]):
                     if p.grad is None or id(p) in st.summed_ids:
@@ -156,34 +144,17 @@ class _WgradQueue:
         st.pending = [e for e in st.pending if id(e) not in ids]
         e0 = group[0]
         desc, dev = e0["desc"], e0["device"]
+        ws = _empty_bytes(lib.ff_xattn_wgrad_workspace_bytes(desc), dev)
         params = [p for e in group for p in e["params"]]
         n = ffi.XATTN_PARAMS
         grad_ptrs = (ffi.C.c_void_p * (n * len(group)))()
         for i, e in enumerate(group):
             for j in range(n):
                 grad_ptrs[i * n + j] = e["grad_ptrs"][j]
-
-        def launch():
-            ws = _empty_bytes(lib.ff_xattn_wgrad_workspace_bytes(desc), dev)
-            ffi.check(lib.ff_xattn_wgrad_grouped(desc, len(group), ffi.ptr_array([e["dout"] for e in group]), ffi.ptr_array([e["saved"] for e in group]),
-                                                 e0["saved"].numel(), ffi.ptr_array([e["stash"] for e in group]), e0["stash"].numel(),
-                                                 ffi.ptr_array(params), grad_ptrs, ws.data_ptr(), ws.numel(), ffi.stream_handle(dev)),
-                      "ff_xattn_wgrad_grouped")
-
-        if self.side_stream and not _grad_ready_callbacks:
-            cur = torch.cuda.current_stream(dev)
-            side = self._side.get(dev)
-            if side is None:
-                side = self._side[dev] = torch.cuda.Stream(dev)
-            side.wait_stream(cur)            # the operands (d out, stash, saved activations) are complete on the backward stream
-            with torch.cuda.stream(side):
-                launch()
-            for e in group:                  # keep the operands and the gradient buffers out of the allocator's hands until the side stream is done
-                for t in (e["dout"], e["saved"], e["stash"], e["flat"]):
-                    t.record_stream(side)
-            st.side.add(side)
-        else:
-            launch()
+        ffi.check(lib.ff_xattn_wgrad_grouped(desc, len(group), ffi.ptr_array([e["dout"] for e in group]), ffi.ptr_array([e["saved"] for e in group]),
+                                             e0["saved"].numel(), ffi.ptr_array([e["stash"] for e in group]), e0["stash"].numel(),
+                                             ffi.ptr_array(params), grad_ptrs, ws.data_ptr(), ws.numel(), ffi.stream_handle(dev)),
+                  "ff_xattn_wgrad_grouped")
         for e in group:
             _announce(e["flat"], e["own"])
         st.done.extend(group)

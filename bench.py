@@ -540,15 +540,15 @@ def main():
             tm, tn = (64, 128) if key[1] == 6412 else (key[1], key[1])
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
             if key[1] == 128160:      # the 8-wave producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU>
-                name = f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 3, 1>"
+                name = f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 4, 1, 8>"      # ..., DMA waves>
             elif key[1] == 64002:
-                name = f"ff::gemm_bf16_pc_kernel<64, 64, {key[2]}, {key[3]}, 3, 2>"
+                name = f"ff::gemm_bf16_pc_kernel<64, 64, {key[2]}, {key[3]}, 3, 2, 4>"
             elif key[1] == 3264:
-                name = "ff::gemm_bf16_pc_kernel<32, 64, 0, 0, 4, 2>"
+                name = "ff::gemm_bf16_pc_kernel<32, 64, 0, 0, 4, 2, 4>"
             elif key[1] == 3216:
                 name = "ff::gemm_bf16_rows32_kernel"
             elif key[1] == 128002:
-                name = f"ff::gemm_bf16_pc_kernel<128, 128, {key[2]}, {key[3]}, 2, 2>"
+                name = f"ff::gemm_bf16_pc_kernel<128, 128, {key[2]}, {key[3]}, 2, 2, 4>"
             tot_ms = sum(v["ms"] for v in groups.values())
             tot_fl = sum(v["flops"] for v in groups.values())
             # HBM bytes per launch of this kernel: PMC counters cannot be read from inside this process (rocprofv3 wraps the command), so the

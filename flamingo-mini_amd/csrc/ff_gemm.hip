@@ -384,48 +384,60 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, cons
 // two), and 1024 x 1280 x 5120 -> 64 tiles x split-K 4.  K-major operands only (BN = 160 has no M-major staging).
 // Measured (tools/pc_bench.py, cold operands): 32.3 -> 28.1 us and 31.4 -> 28.4 us incl. the split-K reduce; in-model 37.60 -> 37.41
 // ms/step.  A k-step still takes ~1.05 us = 14 B/clk of operand bytes (the 4-wave kernel alone on a CU: ~10; two of them: ~21 together):
-// eight DMA waves instead of four, or a 4-deep ring, change nothing - the limit is the CU's outstanding-request depth times the cold
-// operands' latency, not DMA issue.
+// eight DMA waves instead of four, or a 4-deep ring, change nothing by themselves - together (round 3) they are worth 0.3 % of the step and are
+// what the 128 x 160 launches use now.  tools/experiments/fill_rate.hip: with nothing consuming, four DMA waves pull L2-resident tiles at
+// 15-16 B/clk, eight at 19-22, everything at ~12 when the bytes come from HBM - the kernel sits where a mix of warm activations and cold
+// weights puts it.
 // ------------------------------------------------------------------------------------------------
 // Staging of the B operand tile: one piece, or - BN = 160 with N the contiguous index (M-major) - a 128-column piece and a 32-column piece:
 // a 160-element k-row is 320 bytes, which no whole number of 1-KiB wave-level DMA instructions covers, 256 + 64 bytes do (4 + 1
 // instructions per wave and k-step, the same count as for the K-major tile).  Fragment reads pick the piece by their column.
-template <int BN, int BL> struct BStage {
-    static constexpr bool SPLIT = BL == 1 && BN == 160;
+// NW = number of issuing waves.  With eight of them the 160-wide tile is always staged in two pieces (160 rows / columns do not divide by
+// 8 waves x 8 rows): the 128 piece by all eight waves, the 32 piece by the first four - the other four issue the same instruction with an
+// out-of-range source into a scratch kilobyte each (`dummy`), so that every wave has the same number of DMA instructions per k-step and the
+// counted vmcnt waits stay uniform.  For K-major tiles the two pieces are consecutive rows: the LDS image is that of the unsplit tile.
+template <int BN, int BL, int NW = 4> struct BStage {
+    static constexpr bool SPLIT = BN == 160 && (BL == 1 || NW == 8);
+    static constexpr int N128 = 128 / (NW * 8);        // DMA instructions per wave for the 128 piece
+    static constexpr int PER_WAVE = SPLIT ? N128 + 1 : BN / (NW * 8);
     static FF_DEV void prepare(const RowMap& map, int n_base, int n_lim, int w, int l, unsigned* v) {
         if constexpr (SPLIT) {
-            dma_prepare<128, 1>(map, n_base, n_lim, w, l, v);
-            dma_prepare<32, 1>(map, n_base + 128, n_lim, w, l, v + 4);
-        } else dma_prepare<BN, BL>(map, n_base, n_lim, w, l, v);
+            dma_prepare<128, BL, NW>(map, n_base, n_lim, w, l, v);
+            dma_prepare<32, BL, 4>(map, n_base + 128, n_lim, w & 3, l, v + N128);
+            if (NW == 8 && w >= 4) v[N128] = kOobOffset;
+        } else dma_prepare<BN, BL, NW>(map, n_base, n_lim, w, l, v);
     }
-    static FF_DEV void fast(__amdgpu_buffer_rsrc_t r, bf16* st, const unsigned* v, unsigned soff, int w) {
+    static FF_DEV void fast(__amdgpu_buffer_rsrc_t r, bf16* st, const unsigned* v, unsigned soff, int w, bf16* dummy = nullptr) {
         if constexpr (SPLIT) {
-            dma_tile_fast<128, 1>(r, st, v, soff, w);
-            dma_tile_fast<32, 1>(r, st + 128 * kBK, v + 4, soff, w);
-        } else dma_tile_fast<BN, BL>(r, st, v, soff, w);
+            dma_tile_fast<128, BL, NW>(r, st, v, soff, w);
+            if (NW == 8 && w >= 4) dma_tile_fast<32, BL, 4>(r, dummy, v + N128, soff, 0);
+            else dma_tile_fast<32, BL, 4>(r, st + 128 * kBK, v + N128, soff, w & 3);
+        } else dma_tile_fast<BN, BL, NW>(r, st, v, soff, w);
     }
-    static FF_DEV void slow(__amdgpu_buffer_rsrc_t r, bf16* st, const RowMap& map, int n_base, int n_lim, int k0, int k_end, int w, int l) {
+    static FF_DEV void slow(__amdgpu_buffer_rsrc_t r, bf16* st, const RowMap& map, int n_base, int n_lim, int k0, int k_end, int w, int l, bf16* dummy = nullptr) {
         if constexpr (SPLIT) {
-            dma_tile<128, 1>(r, st, map, n_base, n_lim, k0, k_end, w, l);
-            dma_tile<32, 1>(r, st + 128 * kBK, map, n_base + 128, n_lim, k0, k_end, w, l);
-        } else dma_tile<BN, BL>(r, st, map, n_base, n_lim, k0, k_end, w, l);
+            dma_tile<128, BL, NW>(r, st, map, n_base, n_lim, k0, k_end, w, l);
+            if (NW == 8 && w >= 4) dma_tile<32, BL, 4>(r, dummy, map, n_base + 128, 0, k0, k_end, 0, l);      // row limit 0: every lane out of range
+            else dma_tile<32, BL, 4>(r, st + 128 * kBK, map, n_base + 128, n_lim, k0, k_end, w & 3, l);
+        } else dma_tile<BN, BL, NW>(r, st, map, n_base, n_lim, k0, k_end, w, l);
     }
     static FF_DEV bf16x8 frag(const bf16* s, int col0, int ks) {      // col0: wave-uniform
-        if constexpr (SPLIT) return col0 < 128 ? frag_read2<128, 1>(s, col0, ks) : frag_read2<32, 1>(s + 128 * kBK, col0 - 128, ks);
+        if constexpr (SPLIT && BL == 1) return col0 < 128 ? frag_read2<128, 1>(s, col0, ks) : frag_read2<32, 1>(s + 128 * kBK, col0 - 128, ks);
         else return frag_read2<BN, BL>(s, col0, ks);
     }
 };
 
 // WPC = workgroups per CU the register budget is sized for (2: <= 128 registers per lane, two 8-wave workgroups share a CU)
-template <int BM, int BN, int AL, int BL, int NS, int WPC>
-__global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
+// NPW = producer (DMA) waves: 4, or 8 (a 12-wave workgroup: one MFMA wave and two DMA waves per SIMD)
+template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4>
+__global__ __launch_bounds__(256 + NPW * 64, WPC) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
                                                            int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
-    constexpr int PER_TILE = BM / 32 + BN / 32;   // DMA instructions per producer wave per k-step
-    typedef BStage<BN, BL> BS;
+    typedef BStage<BN, BL, NPW> BS;
+    constexpr int PER_TILE = BM / (NPW * 8) + BS::PER_WAVE;   // DMA instructions per producer wave per k-step
     static_assert(WN % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
     static_assert((AL == 0 || BM == 128 || BM == 64) && (BL == 0 || BN == 128 || BN == 64 || BN == 160), "M-major staging exists for 64 / 128 / 160-wide tiles only");
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
@@ -443,8 +455,9 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
     const int t = threadIdx.x, l = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool producer = w >= 4;
-    const int pw = w & 3;                          // index among the four producers / the four consumers
-    const int wm = pw >> 1, wn = pw & 1;
+    const int pw = producer ? w - 4 : w;           // index among the producers / the four consumers
+    const int wm = (w & 3) >> 1, wn = w & 1;
+    bf16* dummy = smem + NS * STAGE + (pw & 3) * 512;   // NPW = 8, 160-wide tile: scratch kilobyte of producers 4..7 (see BStage)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)opB, 0, 0x7fffffff, 0x00020000);
     const int nk = (k_end - k_begin + kBK - 1) / kBK;
@@ -455,20 +468,20 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    unsigned va[BM / 32], vb[BN / 32];
+    unsigned va[BM / (NPW * 8)], vb[BS::PER_WAVE];
     const bool a_plain = AL == 0 || a_map.rows_per_seg <= 0, b_plain = BL == 0 || b_map.rows_per_seg <= 0;
     const unsigned a_step = AL == 0 ? 2u : (unsigned)a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)b_map.ld * 2u;   // bytes per unit of k
     auto issue = [&](int tile) {
         bf16* st = smem + (tile % NS) * STAGE;
         const int k0 = k_begin + tile * kBK;
         const bool full = k0 + kBK <= k_end;       // wave-uniform
-        if (full && a_plain) dma_tile_fast<BM, AL>(ra, st, va, (unsigned)k0 * a_step, pw);
-        else dma_tile<BM, AL>(ra, st, a_map, m_base, hM, k0, k_end, pw, l);
-        if (full && b_plain) BS::fast(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, pw);
-        else BS::slow(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, pw, l);
+        if (full && a_plain) dma_tile_fast<BM, AL, NPW>(ra, st, va, (unsigned)k0 * a_step, pw);
+        else dma_tile<BM, AL, NPW>(ra, st, a_map, m_base, hM, k0, k_end, pw, l);
+        if (full && b_plain) BS::fast(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, pw, dummy);
+        else BS::slow(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, pw, l, dummy);
     };
     if (producer) {
-        dma_prepare<BM, AL>(a_map, m_base, hM, pw, l, va);
+        dma_prepare<BM, AL, NPW>(a_map, m_base, hM, pw, l, va);
         BS::prepare(b_map, n_base, hN, pw, l, vb);
 #pragma unroll
         for (int s = 0; s < NS - 1; s++)
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(512, WPC) void gemm_bf16_pc_kernel(const void* hA, 
         }
     }
     __syncthreads();
-    tile_epilogue_bf16<BM, BN, 512>(Q, pr, ct, m_base, n_base);      // all eight waves share the row loop
+    tile_epilogue_bf16<BM, BN, 256 + NPW * 64>(Q, pr, ct, m_base, n_base);      // all waves share the row loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -937,19 +950,19 @@ template <int BM, int BN, int NS> static int dispatch_bf16_dma(const GemmParams&
 template <int BM, int BN> static int run_bf16_dma_tile(const GemmParams& P, int ns, hipStream_t st) {
     return ns == 2 ? dispatch_bf16_dma<BM, BN, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<BM, BN, 4>(P, st) : dispatch_bf16_dma<BM, BN, 3>(P, st);
 }
-template <int BM, int BN, int AL, int BL, int NS, int WPC> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16);
+template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
+    constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16) + (NPW == 8 && BN == 160 ? 4096 : 0);
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm pc lds=%zu): %s", lds, hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
-    gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC><<<dim3(grid), dim3(512), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
+    gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC, NPW><<<dim3(grid), dim3(256 + NPW * 64), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
                                                                                  P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
                                                                                  (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_pc");
@@ -966,8 +979,15 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     // default 2 stages: 64 KiB (128x128) / 16 KiB (64x64) per workgroup, so several workgroups per CU overlap each other's
     // DMA-issue and barrier stalls - measured faster than deeper rings at lower occupancy (tools/gemm_bench.py --sweep)
     const int ns = P.force_stages > 0 ? P.force_stages : ns_env > 0 ? ns_env : 2;
-    if (P.tile == 128160) {      // 3 stages (108 KiB) by default: one workgroup per CU, so the ring has to cover the DMA latency by itself
-        const int pns = P.force_stages > 0 ? P.force_stages : ns_env > 0 ? ns_env : 3;      // (2 stages would not hold the parked fp32 tile)
+    if (P.tile == 128160) {      // one workgroup per CU, so the ring has to cover the DMA latency by itself (2 stages would not hold the parked fp32 tile)
+        // Round 3: eight DMA waves (12-wave workgroups) AND a 4-deep ring (148 KiB) - each alone changes nothing (round 2), together 35.46 ->
+        // 35.36 ms/step in a same-box A/B (gpurun_out/r3s22); FF_GEMM_NPW=4 / FF_GEMM_STAGES=3 in the development build restore the old launch.
+        static const int npw = env_int("FF_GEMM_NPW", 8);
+        const int pns = P.force_stages > 0 ? P.force_stages : ns_env > 0 ? ns_env : npw == 8 ? 4 : 3;
+        if (npw == 8) {
+            if (P.b_layout == 0) return pns == 4 ? launch_bf16_pc<128, 160, 0, 0, 4, 1, 8>(P, st) : launch_bf16_pc<128, 160, 0, 0, 3, 1, 8>(P, st);
+            return pns == 4 ? launch_bf16_pc<128, 160, 0, 1, 4, 1, 8>(P, st) : launch_bf16_pc<128, 160, 0, 1, 3, 1, 8>(P, st);
+        }
         if (P.b_layout == 0) return pns == 4 ? launch_bf16_pc<128, 160, 0, 0, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 0, 3, 1>(P, st);
         return pns == 4 ? launch_bf16_pc<128, 160, 0, 1, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 1, 3, 1>(P, st);
     }

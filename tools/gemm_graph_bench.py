@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""One GEMM shape of the library in isolation without host launch overhead: a HIP graph of NB back-to-back launches, each on its own B
+(weight) buffer - NB x bytes beyond the 256 MB on-die cache, so weights arrive cold as in the model - and either one shared A buffer (warm
+activations, the model's case) or rotating ones; replayed and timed with events.  us per launch include the gap between graph nodes.
+    python tools/gemm_graph_bench.py M N K [a_layout b_layout [tile [stages]]]        env: COLD_A=1 rotates A as well"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from flamingo_mini_amd import functional as F
+
+args = [int(a) for a in sys.argv[1:]]
+M, N, K = args[:3]
+al, bl = (args[3], args[4]) if len(args) >= 5 else (0, 0)
+tile = args[5] if len(args) >= 6 else 0
+stages = args[6] if len(args) >= 7 else 0
+dt = torch.bfloat16
+nb = max(4, min(48, int(400e6 / (N * K * 2))))
+Bs = [torch.randn((N, K) if bl == 0 else (K, N), device="cuda", dtype=dt) * 0.05 for _ in range(nb)]
+na = nb if os.environ.get("COLD_A", "0") == "1" else 1
+As = [torch.randn((M, K) if al == 0 else (K, M), device="cuda", dtype=dt) for _ in range(na)]
+
+
+def run():
+    for i, B in enumerate(Bs):
+        F.gemm(As[i % na], B, a_layout=al, b_layout=bl, tile=tile, stages=stages)
+
+
+run()
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    run()
+    with torch.cuda.graph(g, stream=side):
+        run()
+torch.cuda.synchronize()
+for _ in range(3):
+    g.replay()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+reps = 10
+for _ in range(reps):
+    g.replay()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / (reps * nb)
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FF_"))
+print(f"{M}x{N}x{K} a{al} b{bl} tile {tile or 'auto'} [{tag}]: {us:7.2f} us   {2.0 * M * N * K / us / 1e6:6.0f} TFLOP/s   ({nb} B buffers, {na} A)", flush=True)

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256 + NPW * 64, WPC) void gemm_bf16_pc_kernel(const
     const void* opA = hA;
     const void* opB = hB;
     const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
-    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd & 255, (h_xcd >> 8) & 255, tiles_m, tiles_n);
+    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd & 255, h_xcd >> 8, tiles_m, tiles_n);
     if (tc.z > 0) { opA = P.p[tc.z].A; opB = P.p[tc.z].B; }
     const int m_base = tc.tm * BM, n_base = tc.tn * BN;
     const int k_begin = tc.split * h_kps;
@@ -489,14 +489,8 @@ __global__ __launch_bounds__(256 + NPW * 64, WPC) void gemm_bf16_pc_kernel(const
     }
     FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
     if (tc.z > 0) pr = P.p[tc.z];
-#ifdef FF_DEBUG      // development build: FF_GEMM_PCMODE in bits 16.. of h_xcd - 1: no fragment reads / MFMA, 2: no DMA, 3: reads only, 4: MFMA only
-    const int pcmode = h_xcd >> 16;
-#else
-    constexpr int pcmode = 0;
-#endif
     if (producer) {
         for (int kt = 0; kt < nk; kt++) {
-            if (pcmode == 2) { __builtin_amdgcn_s_barrier(); continue; }
             const int younger = min(nk - 1 - kt, NS - 2);
             if (NS >= 4 && younger == 2) wait_vmcnt<2 * PER_TILE>();
             else if (NS >= 3 && younger >= 1) wait_vmcnt<PER_TILE>();
@@ -507,31 +501,15 @@ __global__ __launch_bounds__(256 + NPW * 64, WPC) void gemm_bf16_pc_kernel(const
     } else {
         for (int kt = 0; kt < nk; kt++) {
             __builtin_amdgcn_s_barrier();
-            if (pcmode == 1) continue;
             const bf16* sA = smem + (kt % NS) * STAGE;
             const bf16* sB = sA + A_ELEMS;
 #pragma unroll
             for (int ks = 0; ks < kBK / 32; ks++) {
                 bf16x8 fa[MT], fb[NT];
-                if (pcmode != 4) {
 #pragma unroll
-                    for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
+                for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
 #pragma unroll
-                    for (int j = 0; j < NT; j++) fb[j] = BS::frag(sB, wn * WN + j * 16, ks);
-                } else {
-                    const bf16x8 fixed = __builtin_bit_cast(bf16x8, f32x4{(float)l, 1.f, 2.f, (float)kt});
-#pragma unroll
-                    for (int i = 0; i < MT; i++) fa[i] = fixed;
-#pragma unroll
-                    for (int j = 0; j < NT; j++) fb[j] = fixed;
-                }
-                if (pcmode == 3) {      // keep the reads alive without the MFMAs
-#pragma unroll
-                    for (int i = 0; i < MT; i++) acc[i][0] += __builtin_bit_cast(f32x4, fa[i]);
-#pragma unroll
-                    for (int j = 0; j < NT; j++) acc[0][j] += __builtin_bit_cast(f32x4, fb[j]);
-                    continue;
-                }
+                for (int j = 0; j < NT; j++) fb[j] = BS::frag(sB, wn * WN + j * 16, ks);
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -984,9 +962,8 @@ template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4> static i
     }
     const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
-    static const int pcmode = env_int("FF_GEMM_PCMODE", 0);      // development build: timing experiments (see the kernel), wrong results
     gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC, NPW><<<dim3(grid), dim3(256 + NPW * 64), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
-                                                                                 P.nz, P.xcd_ms | (P.xcd_ns << 8) | (pcmode << 16), (int)P.a_map.ld,
+                                                                                 P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
                                                                                  (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_pc");
 }

@@ -60,13 +60,13 @@ FF_DEV void epilogue4(const GemmParams& P, const GemmProblem& pr, int m, int n, 
     }
     if (P.act >= 0) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = act_fwd(v[r], P.act);
+        for (int r = 0; r < 4; r++) v[r] = act_fwd_t<T>(v[r], P.act);
     }
     if (P.act_bwd >= 0) {
         float h[4];
         load4(pr.aux_in, off, h);
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] *= act_grad(h[r], P.act_bwd);
+        for (int r = 0; r < 4; r++) v[r] *= act_grad_t<T>(h[r], P.act_bwd);
     }
     if (pr.residual) {
         float q[4];
@@ -128,13 +128,13 @@ FF_DEV void epilogue8(const GemmParams& P, const GemmProblem& pr, int m, int n, 
     }
     if (has_act) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = act_fwd(v[e], P.act);
+        for (int e = 0; e < 8; e++) v[e] = act_fwd_t<T>(v[e], P.act);
     }
     if (has_act_bwd) {
         float h[8];
         load8(pr.aux_in, off, h);
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] *= act_grad(h[e], P.act_bwd);
+        for (int e = 0; e < 8; e++) v[e] *= act_grad_t<T>(h[e], P.act_bwd);
     }
     if (has_res) {
         float q[8];

@@ -21,9 +21,23 @@ na = nb if os.environ.get("COLD_A", "0") == "1" else 1
 As = [torch.randn((M, K) if al == 0 else (K, M), device="cuda", dtype=dt) for _ in range(na)]
 
 
+EPI = os.environ.get("EPI", "")      # "": plain; "act": gelu + aux_out (FFW up-projection); "act_bwd": gelu' from aux_in, gated (its data gradient)
+H = torch.randn(M, N, device="cuda", dtype=dt) if EPI.startswith("act_bwd") else None
+gate = torch.tensor([0.5], device="cuda", dtype=dt)
+R = torch.randn(M, N, device="cuda", dtype=dt) if EPI == "res" else None
+
+
 def run():
     for i, B in enumerate(Bs):
-        F.gemm(As[i % na], B, a_layout=al, b_layout=bl, tile=tile, stages=stages)
+        kw = dict(a_layout=al, b_layout=bl, tile=tile, stages=stages)
+        if EPI in ("act", "act_sqrelu"):
+            F.gemm(As[i % na], B, act="gelu" if EPI == "act" else "sqrelu", want_aux_out=True, **kw)
+        elif EPI in ("act_bwd", "act_bwd_sqrelu"):
+            F.gemm(As[i % na], B, act_bwd="gelu" if EPI == "act_bwd" else "sqrelu", aux_in=H, gate=gate, **kw)
+        elif EPI == "res":
+            F.gemm(As[i % na], B, residual=R, gate=gate, **kw)
+        else:
+            F.gemm(As[i % na], B, **kw)
 
 
 run()
@@ -45,5 +59,5 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / (reps * nb)
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FF_"))
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FF_") or k == "EPI")
 print(f"{M}x{N}x{K} a{al} b{bl} tile {tile or 'auto'} [{tag}]: {us:7.2f} us   {2.0 * M * N * K / us / 1e6:6.0f} TFLOP/s   ({nb} B buffers, {na} A)", flush=True)

@@ -982,7 +982,9 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     if (P.tile == 128160) {      // one workgroup per CU, so the ring has to cover the DMA latency by itself (2 stages would not hold the parked fp32 tile)
         // Round 3: eight DMA waves (12-wave workgroups) AND a 4-deep ring (148 KiB) - each alone changes nothing (round 2), together 35.46 ->
         // 35.36 ms/step in a same-box A/B (gpurun_out/r3s22); FF_GEMM_NPW=4 / FF_GEMM_STAGES=3 in the development build restore the old launch.
-        static const int npw = env_int("FF_GEMM_NPW", 8);
+        static const int npw_full = env_int("FF_GEMM_NPW", 8), npw_split = env_int("FF_GEMM_NPW_SPLIT", 4);
+        // (split-K launches - fp32 partial slabs, no epilogue for the extra waves to share - were ~1 us slower with the 12-wave workgroup: 24.5 -> 25.9 us)
+        const int npw = P.split_k > 1 ? npw_split : npw_full;
         const int pns = P.force_stages > 0 ? P.force_stages : ns_env > 0 ? ns_env : npw == 8 ? 4 : 3;
         if (npw == 8) {
             if (P.b_layout == 0) return pns == 4 ? launch_bf16_pc<128, 160, 0, 0, 4, 1, 8>(P, st) : launch_bf16_pc<128, 160, 0, 0, 3, 1, 8>(P, st);

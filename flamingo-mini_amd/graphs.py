@@ -32,13 +32,16 @@ def _refuse_live_autograd_graphs(model: torch.nn.Module) -> None:
         return p.view_as(p).grad_fn.next_functions[0][0]
 
     stale = []
-    for name, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        accumulator(p).metadata["ff_capture_probe"] = True
-        node = accumulator(p)
-        if node.metadata.pop("ff_capture_probe", False):
-            stale.append(name)
+    try:
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            accumulator(p).metadata["ff_capture_probe"] = True
+            node = accumulator(p)
+            if node.metadata.pop("ff_capture_probe", False):
+                stale.append(name)
+    except (AttributeError, IndexError, TypeError):      # a torch build whose autograd nodes cannot be probed this way: capture unguarded
+        return
     if stale:
         raise RuntimeError(
             f"GraphedTrainStep: an autograd graph from an earlier forward still refers to {len(stale)} parameter(s) of the model (e.g. "

@@ -7,6 +7,8 @@ import json
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 RND = sorted(re.match(r"(r\d+)_", os.path.basename(p)).group(1) for p in glob.glob(os.path.join(P, "r*_bench_default.json")))[-1]
@@ -52,3 +54,19 @@ def test_pmc_traffic_names_the_dominant_kernel():
     assert t[r["kernel"]]["hbm_bytes_per_launch"] == r["traffic"]
     algorithmic = r["avg_launch_gflop"] * 0 + 1      # operands + output of the launch, bf16: see DESIGN.md section 5 for the per-launch figure
     assert t[r["kernel"]]["hbm_bytes_per_launch"] > 20e6 * algorithmic
+
+
+def test_roofline_table_is_regenerable_from_the_committed_profiles():
+    """profiles/rNN_roofline_table.md is derived data: tools/roofline_table.py must reproduce it from the kernel statistics, the counter traffic
+    and the GEMM table committed next to it (so the table cannot drift from the session it claims to describe)."""
+    import glob
+    import subprocess
+    import sys
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_table.md")))
+    if not tables:
+        pytest.skip("no roofline table committed")
+    path = tables[-1]
+    rnd = os.path.basename(path).split("_")[0]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), rnd], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-800:]
+    assert out.stdout.strip() == open(path).read().strip()

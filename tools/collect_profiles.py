@@ -83,3 +83,10 @@ for extra in ("gemm_table.txt", "bucket_timeline.txt", "caption_decode_kernels.t
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(P, f"{rnd}_{extra}"))
 print("dominant kernel", k, "traffic", line["roofline"]["traffic"], "frac", line["roofline"]["frac"], "value", line["value"])
+
+# derived table: every library kernel against its roofline (tests/test_profiles_consistency.py regenerates and compares it)
+table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), rnd, P], capture_output=True, text=True)
+if table.returncode == 0:
+    open(os.path.join(P, f"{rnd}_roofline_table.md"), "w").write(table.stdout)
+else:
+    print("roofline table failed:", table.stderr[-400:])

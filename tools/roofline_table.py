@@ -1,13 +1,14 @@
 #!/usr/bin/env python
 """Per-kernel roofline table of the fusion library from the committed profiles of one round:
-    python tools/roofline_table.py r03 > profiles/r03_roofline_table.md
+    python tools/roofline_table.py r03 [directory] > profiles/r03_roofline_table.md
 rocprofv3 kernel statistics (average duration, launches per step) x the counter traffic of the same session (HBM bytes per launch, corrected as
 MI355X_MICROARCH.md prescribes) give the achieved HBM rate of every kernel; the GEMM table of the bench (HIP events) gives FLOP rates."""
 import csv, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
-P = lambda n: os.path.join(ROOT, "profiles", f"{rnd}_{n}")
+DIR = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")      # (tools/collect_profiles.py points it at a session's collected/ directory)
+P = lambda n: os.path.join(DIR, f"{rnd}_{n}")
 stats = {r["Name"]: r for r in csv.DictReader(open(P("bench_b32_bf16_kernel_stats.csv")))}
 summary = open(P("bench_b32_bf16_summary.md")).read()
 steps = int(summary.split(" ms over ")[1].split(" steps")[0])

@@ -20,7 +20,8 @@ SOURCES = ["ff_api.hip", "ff_gemm.hip", "ff_rowwise.hip", "ff_attention.hip", "f
 HEADERS = ["ff_common.h", "ff_internal.h", "ff_gemm_tiles.h", "ff_attention_core.h", os.path.join("..", "..", "include", "flamingo_fusion.h")]
 ARCH = "gfx950"
 # kernarg preload: leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+); kernels fall back to loads on old firmware
-FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + os.environ.get("FF_EXTRA_FLAGS", "").split()
+# -fvisibility=hidden: only what include/flamingo_fusion.h declares (under its visibility pragma) is exported - no mangled C++ internals
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + os.environ.get("FF_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:
@@ -66,8 +67,9 @@ def build(force: bool = False, verbose: bool = False, debug: bool = False) -> st
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         list(ex.map(compile_one, jobs))
     objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(lib_path, objs):
-        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs, capture_output=True, text=True)
+    if force or jobs or _stale(lib_path, objs + [os.path.join(CSRC, "exports.map")]):
+        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={os.path.join(CSRC, 'exports.map')}", "-o", lib_path] + objs,
+                           capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
         if verbose:

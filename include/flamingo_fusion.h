@@ -32,6 +32,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the declarations of this header are exported (tests/test_cabi.py compares the
+ * dynamic symbol table of the built .so with them). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct ihipStream_t* ff_stream_t; /* == hipStream_t */
 
@@ -88,7 +93,8 @@ int ff_gemm(const ff_gemm_desc* d, const void* A, const void* B, void* C, void* 
 
 /* Optional measurement aid (bench.py's roofline leg): while enabled, every GEMM main-kernel launch is bracketed by two
  * HIP events on its own stream.  ff_gemm_profile_read() waits for the recorded launches, fills `out` (returns the count)
- * and clears the log.  ff_gemm_profile_enable(0) switches it off.  Not thread-safe; one stream at a time. */
+ * and clears the log.  ff_gemm_profile_enable(0) switches it off.  Recording is thread-safe (launches of any thread on any stream claim
+ * their slot atomically); enable / read / disable belong to ONE controlling thread, called while no launch is in flight. */
 typedef struct ff_gemm_profile_record {
     int dtype, tile, a_layout, b_layout;
     int M, N, K, nz, split_k;
@@ -335,6 +341,9 @@ int ff_shifted_ce_bwd(int dtype, int batch, int seq, int vocab, const void* logi
 int ff_quick_gelu_fwd(int dtype, long long n, const void* x, void* y, ff_stream_t stream);
 int ff_quick_gelu_bwd(int dtype, long long n, const void* x, const void* dy, void* dx, ff_stream_t stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,19 @@ def test_library_exports_exactly_the_header():
     assert lib.ff_version() == ffi.ABI_VERSION and lib.ff_arch() == b"gfx950"
 
 
+def test_dynamic_symbol_table_holds_nothing_but_the_header():
+    """`nm -D` of the shipped library: every defined global function is one the header declares (the library is built with
+    -fvisibility=hidden and linked with csrc/exports.map: no mangled C++ internals, no per-kernel host handles, no helper leaks)."""
+    import shutil
+    import subprocess
+    from flamingo_mini_amd import ffi
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    ffi.lib()
+    out = subprocess.run([nm, "-D", "--defined-only", ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = sorted(line.split()[-1] for line in out.splitlines() if len(line.split()) >= 3)     # functions AND objects, any binding
+    assert defined == declared_functions(), sorted(set(defined) ^ set(declared_functions()))
+
+
 def _header_prototypes():
     """name -> (return kind, [parameter kinds]) parsed from the header; kinds: 'ptr', 'int', 'size', 'i64', 'float', 'str'."""
     text = open(os.path.join(ROOT, "include", "flamingo_fusion.h")).read()

@@ -5,6 +5,9 @@ while dim defaults to 1024): always pass dim / dim_visual explicitly.
 Extra, optional key understood by this implementation only (stored like any other HF config kwarg):
     random_init_backbones (bool): build CLIP / LM from built-in architecture tables with random weights when the
     HF hub files are not available (benchmarks, tests).  Default False = `from_pretrained` like the reference.
+    backbone_overrides (dict): {'lm': {...}, 'clip': {...}} keyword overrides of those random-init backbone configs.
+    backbone_op_substitutions (bool): default False = the frozen CLIP / LM stay exactly as Hugging Face builds them (stock
+    PyTorch-ROCm); True swaps three ops inside them for result-identical faster forms (backbones.py).
 """
 from __future__ import annotations
 

@@ -25,15 +25,18 @@ import torch.distributed as dist
 from . import functional as F
 
 
-def _split_kv_buckets(model: torch.nn.Module, layers_per_bucket: int = 4) -> None:
+def _bucket_launch_structure(model: torch.nn.Module, layers_per_bucket: int = 4) -> list:
     """With collectives in play the hoisted K / V projection runs as one call per `layers_per_bucket` layers (FlamingoBaseModel.
-    kv_project_group): each call is its own autograd node with its own gradient bucket, ready as soon as its layers' backward is done."""
+    kv_project_group): each call is its own autograd node with its own gradient bucket, ready as soon as its layers' backward is done;
+    and the deferred weight gradients of the blocks are flushed every `layers_per_bucket` layers as well (single-GPU default: 12, which is
+    faster per launch but would hold back every bucket until a third of backward has passed).  These are settings OF THE MODEL
+    (set_launch_structure), not of the process: returns [(module, previous settings)] for close() to restore."""
+    undo = []
     for m in model.modules():
-        if hasattr(m, "kv_project_group") and m.kv_project_group == 0:
-            m.kv_project_group = layers_per_bucket
-    # the deferred weight gradients of the blocks are flushed every `layers_per_bucket` layers as well (single-GPU default: 12, which is
-    # faster per launch but would hold back every bucket until a third of backward has passed)
-    F._wgrad_queue.group = min(F._wgrad_queue.group, layers_per_bucket)
+        if hasattr(m, "set_launch_structure") and hasattr(m, "kv_project_group"):
+            group = m.kv_project_group if m.kv_project_group > 0 else layers_per_bucket
+            undo.append((m, m.set_launch_structure(kv_project_group=group, wgrad_group=layers_per_bucket)))
+    return undo
 
 
 def _bucket_is_ours(owners, ids) -> bool:
@@ -77,16 +80,48 @@ class GradientAllReducer:
         self._sync = True
         fused = {id(p) for m in model.modules() if hasattr(m, "fused_params") for p in m.fused_params()}
         self._fused_ids = fused
+        self._names = dict(model.named_parameters())
         self.loose = [p for p in model.parameters() if p.requires_grad and id(p) not in fused]
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_param) for p in self.loose]
-        if self.active:
-            _split_kv_buckets(model)
+        self._undo = _bucket_launch_structure(model) if self.active else []
+        self._collect: Optional[list] = None      # graphs.PiecewiseGraphedTrainStep: buckets are recorded while a segment is captured ...
+        self.defer_loose = False                  # ... and un-fused parameters wait for finish() when backward runs in several segments
+        self.timeline: Optional[list] = None      # record_timeline(): (label, bytes, ready event, done event) per exchanged bucket
         F.add_grad_ready_callback(self._on_bucket)
 
     def close(self):
+        """Detach from the model: callbacks and hooks removed, the model's launch structure restored to what it was before."""
         F.remove_grad_ready_callback(self._on_bucket)
         for h in self._hooks:
             h.remove()
+        for m, prev in self._undo:
+            m.set_launch_structure(**prev)
+        self._undo = []
+
+    # -- piecewise capture: record instead of exchanging --
+    def begin_collect(self) -> None:
+        self._collect = []
+
+    def end_collect(self) -> list:
+        out, self._collect = self._collect or [], None
+        return out
+
+    def reduce_bucket(self, flat: torch.Tensor, owners) -> None:
+        """Exchange one recorded bucket now (its producers are already enqueued on the current stream)."""
+        if self.active:
+            self._early.update(id(p) for p, _, _ in owners)
+            self._reduce_async(flat, list(owners))
+
+    def record_timeline(self, on: bool = True) -> None:
+        """GPU only: keep (label, bytes, ready, done) event pairs of every bucket exchanged from now on - `timeline_ms()` after a
+        synchronised step says when each bucket became ready and how long its collective was in flight."""
+        self.timeline = [] if on else None
+
+    def timeline_ms(self, origin: "torch.cuda.Event"):
+        rows = []
+        for label, nbytes, ready, done in self.timeline or []:
+            rows.append(dict(bucket=label, mb=round(nbytes / 1e6, 1), ready_ms=round(origin.elapsed_time(ready), 3), done_ms=round(origin.elapsed_time(done), 3)))
+        return rows
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -101,7 +136,12 @@ class GradientAllReducer:
     def _on_param(self, p: torch.Tensor):
         """post-accumulate hook of an un-fused parameter: p.grad is final for this backward (accumulated or not)."""
         if self.active and self._sync:
-            self._reduce_async(p.grad, [])
+            if self._collect is not None:
+                self._collect.append((p.grad, []))
+            elif self.defer_loose:
+                self.late.append(p)
+            else:
+                self._reduce_async(p.grad, [])
 
     def _on_bucket(self, flat: torch.Tensor, owners=()):
         if not (self.active and self._sync) or not owners or not _bucket_is_ours(owners, self._fused_ids):
@@ -116,48 +156,49 @@ class GradientAllReducer:
                                        "the last micro-batch in GradientAllReducer.no_sync()")
                 self.late.append(p)
             return
+        if self._collect is not None:
+            self._collect.append((flat, list(owners)))
+            return
         self._early.update(id(p) for p, _, _ in owners)
         self._reduce_async(flat, list(owners))
 
+    def _mean_in_place(self, t: torch.Tensor) -> None:
+        """t <- mean over the ranks, on the current stream / thread, honouring reduce_dtype (the one place that decides how a gradient
+        tensor is exchanged; the early buckets and the accumulated-gradient path both end here)."""
+        widen = self.reduce_dtype is not None and t.dtype != self.reduce_dtype
+        x = t.to(self.reduce_dtype) if widen else t
+        if self.cuda:
+            dist.all_reduce(x, op=dist.ReduceOp.AVG, group=self.group)
+        else:            # gloo (CPU tests): no AVG
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+            x.div_(self.world)
+        if widen:
+            t.copy_(x)
+
     def _reduce_async(self, flat: torch.Tensor, owners):
-        widen = self.reduce_dtype is not None and flat.dtype != self.reduce_dtype
-        if widen and self.cuda:
-            ready = torch.cuda.Event()
-            ready.record()
-            if not torch.cuda.is_current_stream_capturing():
-                flat.record_stream(self.stream)
-            with torch.cuda.stream(self.stream):
-                self.stream.wait_event(ready)
-                wide = flat.to(self.reduce_dtype)
-                dist.all_reduce(wide, op=dist.ReduceOp.AVG, group=self.group)        # enqueued on the side stream, which then waits for it
-                flat.copy_(wide)
-                done = torch.cuda.Event()
-                done.record()
-            self.pending.append((flat, _StreamWork(done), False, owners))
-        elif widen:
-            wide = flat.to(self.reduce_dtype)
-            dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=self.group)
-            flat.copy_(wide.div_(self.world))
-            self.pending.append((flat, _StreamWork(None), False, owners))
-        elif self.cuda:
-            ready = torch.cuda.Event()
+        if self.cuda:
+            timed = self.timeline is not None and not torch.cuda.is_current_stream_capturing()
+            ready = torch.cuda.Event(enable_timing=timed)
             ready.record()                                   # after the kernels producing `flat` on the compute stream
             if not torch.cuda.is_current_stream_capturing():
                 flat.record_stream(self.stream)              # (inside a graph capture all memory is the graph's own static pool)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            self.pending.append((flat, work, False, owners))
-        else:  # gloo (CPU tests): no AVG, divide afterwards
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.pending.append((flat, work, True, owners))
+                self._mean_in_place(flat)                    # enqueued on the side stream
+                done = torch.cuda.Event(enable_timing=timed)
+                done.record()
+            if timed:
+                label = next((n for n, q in getattr(self, "_names", {}).items() if owners and q is owners[0][0]), None) or ("loose" if not owners else "bucket")
+                self.timeline.append((label, flat.numel() * flat.element_size(), ready, done))
+            self.pending.append((flat, _StreamWork(done), owners))
+        else:
+            self._mean_in_place(flat)                        # CPU ranks: synchronous
+            self.pending.append((flat, _StreamWork(None), owners))
 
     def finish(self):
         """Call after backward(), before optimizer.step(): the compute stream waits for the outstanding collectives."""
-        for flat, work, divide, owners in self.pending:
+        for flat, work, owners in self.pending:
             work.wait()
-            if divide:
-                flat.div_(self.world)
             for p, off, n in owners:     # the reduced slice must BE the parameter's gradient (see the module docstring)
                 if p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + off * flat.element_size():
                     p.grad.copy_(flat[off:off + n].view(p.shape))
@@ -167,11 +208,7 @@ class GradientAllReducer:
             if id(p) in seen or p.grad is None:
                 continue
             seen.add(id(p))
-            if self.cuda:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, group=self.group)
-            else:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
-                p.grad.div_(self.world)
+            self._mean_in_place(p.grad)
         self.late.clear()
         self._early.clear()
 
@@ -239,8 +276,7 @@ class ShardedAdamW(torch.optim.Optimizer):
                                      capturable=capturable) if update_fn is None else None
         self._loose_update_fn = update_fn
         self._loose_state = {}
-        if self.collectives:
-            _split_kv_buckets(model)
+        self._undo = _bucket_launch_structure(model) if self.collectives else []
         F.add_grad_ready_callback(self._on_bucket)
 
     @property
@@ -251,6 +287,9 @@ class ShardedAdamW(torch.optim.Optimizer):
         F.remove_grad_ready_callback(self._on_bucket)
         for h in self._hooks:
             h.remove()
+        for m, prev in self._undo:
+            m.set_launch_structure(**prev)
+        self._undo = []
 
     @contextlib.contextmanager
     def no_sync(self):

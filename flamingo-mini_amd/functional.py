@@ -64,7 +64,10 @@ class _WgradQueue:
     backward (forget_dead_passes).  A block whose parameters take part TWICE in one pass (module reuse, activation-checkpoint
     recompute) must not defer the second time: the engine sums the two contributions the moment the second one is returned, so the
     first is completed on the spot and the second runs the plain, non-deferred backward (seen_in_this_pass).
-    `enabled = False` (or FF_DEFER_WGRAD=0 in the environment at import) disables the deferral."""
+    Whether a block defers, and how many blocks a grouped launch batches, is the CALLER's choice (xattn_block(..., wgrad=(defer, group)):
+    GatedCrossAttentionBlock.defer_wgrad / .wgrad_group, set for a whole model through FlamingoBaseModel.set_launch_structure); `group`
+    below is only the default for callers that pass none, `enabled = False` switches the deferral off for everybody.  No environment
+    variable is read."""
 
     class _Pass:
         def __init__(self):
@@ -74,15 +77,14 @@ class _WgradQueue:
             self.summed_ids: set = set()     # ... that received a second contribution: autograd holds their SUM, nothing to repair
 
     def __init__(self):
-        import os
         # the per-pass bookkeeping needs the engine's graph-task id; a torch build without that (private) accessor runs the plain,
         # non-deferred backward instead of guessing which pass an entry belongs to
-        self.enabled = os.environ.get("FF_DEFER_WGRAD", "1") == "1" and hasattr(torch._C, "_current_graph_task_id")
+        self.enabled = hasattr(torch._C, "_current_graph_task_id")
         # Blocks per grouped launch.  At flamingo-mini's size a block contributes 400 tiles of 128 x 128 per product and the chip holds 512
         # workgroups at a time: 4 blocks = 3.1 rounds (the last one a quarter full), 12 blocks = 9.4 - measured 35.9 -> 35.5 ms per step
-        # (weight-gradient launches 704 -> 830 TFLOP/s).  Data-parallel reducers lower it to 4 so that gradient buckets keep becoming final
-        # - and their exchange keeps starting - every four layers of backward (data_parallel._split_kv_buckets).
-        self.group = max(1, min(ffi.WGRAD_GROUP_MAX, int(os.environ.get("FF_WGRAD_GROUP", "12"))))
+        # (weight-gradient launches 704 -> 830 TFLOP/s).  Data-parallel reducers set 4 ON THEIR MODEL so that gradient buckets keep becoming
+        # final - and their exchange keeps starting - every four layers of backward (data_parallel._bucket_launch_structure).
+        self.group = ffi.WGRAD_GROUP_MAX
         self._passes: dict = {}              # graph-task id -> _Pass
 
     @property
@@ -114,13 +116,13 @@ class _WgradQueue:
         st.pending.append(entry)
         st.deferred_ids.update(id(p) for p in entry["wparams"])
         same = [e for e in st.pending if e["key"] == entry["key"]]
-        if len(same) >= self.group:
+        if len(same) >= entry["group"]:
             self._run(st, same)
 
     def _flush_pending(self, st) -> None:
         while st.pending:
             key = st.pending[0]["key"]
-            self._run(st, [e for e in st.pending if e["key"] == key][: self.group])
+            self._run(st, [e for e in st.pending if e["key"] == key][: st.pending[0]["group"]])
 
     def flush(self, task) -> None:
         st = self._passes.get(task)
@@ -373,7 +375,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
         return desc, inner
 
     @staticmethod
-    def forward(ctx, y, kv, tt, cfg, n_visual, *params):
+    def forward(ctx, y, kv, tt, cfg, n_visual, wgrad, *params):
         lib = ffi.lib()
         _wgrad_queue.forget_dead_passes()
         y, kv = y.contiguous(), kv.contiguous()
@@ -387,6 +389,9 @@ class _XattnBlockKvFn(torch.autograd.Function):
                                          kv.data_ptr() + inner * kv.element_size(), out.data_ptr(), saved.data_ptr(), saved.numel(),
                                          scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_fwd(hoisted kv)")
         ctx.cfg, ctx.n_visual = cfg, n_visual
+        defer, group = wgrad if wgrad is not None else (True, None)
+        ctx.defer = bool(defer)
+        ctx.group = max(1, min(ffi.WGRAD_GROUP_MAX, int(group if group else _wgrad_queue.group)))
         ctx.save_for_backward(y, kv, tt, saved, *params)
         return out
 
@@ -403,7 +408,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
         dy, dkv = torch.empty_like(y), torch.empty_like(kv)
         scratch = _empty_bytes(lib.ff_xattn_scratch_bytes(desc), dev)
         aligned = all(t.data_ptr() % 16 == 0 for t in (y, dout, params[2], params[7]))     # the deferred entry point requires it
-        if _wgrad_queue.enabled and aligned and all(p.grad is None for p in own) and not _wgrad_queue.seen_in_this_pass(own):
+        if _wgrad_queue.enabled and ctx.defer and aligned and all(p.grad is None for p in own) and not _wgrad_queue.seen_in_this_pass(own):
             # data gradients now; d ffw.3 / d ffw.1 / d to_out / d to_q (and the final reductions of the LayerNorm / gate gradients)
             # later, grouped with the neighbouring layers' (see _WgradQueue)
             stash = _empty_bytes(lib.ff_xattn_wgrad_stash_bytes(desc), dev)
@@ -415,17 +420,17 @@ class _XattnBlockKvFn(torch.autograd.Function):
             offs, _ = _flat_offsets(own)
             deferred = tuple(i for i in range(len(params)) if i != _KV_PARAM)      # every gradient of the block is completed by the flush
             own_index = {i: (i if i < _KV_PARAM else i - 1) for i in deferred}
-            _wgrad_queue.push(dict(key=key, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, flat=flat, own=own,
+            _wgrad_queue.push(dict(key=key, group=ctx.group, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, flat=flat, own=own,
                                    grad_ptrs=[None if g is None else g.data_ptr() for g in grads],
                                    wparams=[params[i] for i in deferred],
                                    wslices=[(offs[own_index[i]], params[i].numel()) for i in deferred]))
-            return (dy, dkv, None, None, None, *grads)
+            return (dy, dkv, None, None, None, None, *grads)
         ffi.check(lib.ff_xattn_block_bwd_kv(desc, y.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * kv.element_size(), tt.data_ptr(),
                                             ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(), ffi.ptr_array(grads),
                                             dy.data_ptr(), dkv.data_ptr(), scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)),
                   "ff_xattn_block_bwd_kv")
         _announce(flat, own)
-        return (dy, dkv, None, None, None, *grads)
+        return (dy, dkv, None, None, None, None, *grads)
 
 
 def _kv_views(saved: torch.Tensor, y: torch.Tensor, n_kv: int, heads: int, dim_head: int):
@@ -438,15 +443,17 @@ def _kv_views(saved: torch.Tensor, y: torch.Tensor, n_kv: int, heads: int, dim_h
 
 def xattn_block(y: torch.Tensor, visual_features: Optional[torch.Tensor], tt: torch.Tensor, params: Sequence[torch.Tensor], cfg,
                 n_visual: int, previous_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, output_kv: bool = False,
-                hoisted_kv: Optional[torch.Tensor] = None):
+                hoisted_kv: Optional[torch.Tensor] = None, wgrad: Optional[Tuple[bool, Optional[int]]] = None):
     """GatedCrossAttentionBlock forward.  cfg = (heads, dim_head, ff_mult, act); tt = text_time int32 (b, L_total).
-    hoisted_kv: this layer's output of kv_project (then visual_features is not read).  Returns (y_out, (k, v) or None)."""
+    hoisted_kv: this layer's output of kv_project (then visual_features is not read).  wgrad = (defer, group): whether this block's weight
+    gradients are deferred into grouped launches and how many same-shaped blocks a launch batches (None: deferred, the queue's default).
+    Returns (y_out, (k, v) or None)."""
     ffi.require_cuda(y, tt, *params)
     _same_dtype(y, params, "GatedCrossAttentionBlock")
     heads, dim_head = cfg[0], cfg[1]
     if previous_kv is None and hoisted_kv is not None:
         ffi.require_cuda(hoisted_kv)
-        out = _XattnBlockKvFn.apply(y, hoisted_kv, tt, tuple(cfg), n_visual, *params)
+        out = _XattnBlockKvFn.apply(y, hoisted_kv, tt, tuple(cfg), n_visual, wgrad, *params)
         kv = None
         if output_kv:
             split = hoisted_kv.detach().view(hoisted_kv.shape[0], hoisted_kv.shape[1], 2, heads, dim_head)

@@ -46,6 +46,10 @@ class GatedCrossAttentionBlock(nn.Module):
         self.alpha_ffw = nn.Parameter(torch.tensor([0.]))
         self.cfg = (heads, dim_head, ff_mult, act)
         self.n_visual = n_visual
+        # launch structure of this block's backward (not part of the state_dict): weight gradients deferred into launches grouped with the
+        # neighbouring layers' (functional._WgradQueue), `wgrad_group` blocks per launch (None: the library default, 12)
+        self.defer_wgrad = True
+        self.wgrad_group: Optional[int] = None
 
     def fused_params(self):
         a = self.attn
@@ -65,7 +69,7 @@ class GatedCrossAttentionBlock(nn.Module):
         if previous_kv is None:
             assert text_time.shape == y.shape[:2]
         shape_before = y.shape
-        extra = {} if hoisted_kv is None else {"hoisted_kv": hoisted_kv}
+        extra = {} if hoisted_kv is None else {"hoisted_kv": hoisted_kv, "wgrad": (self.defer_wgrad, self.wgrad_group)}
         out, kv = F.xattn_block(y, visual_features, text_time, self.fused_params(), self.cfg, self.n_visual,
                                 previous_kv=previous_kv, output_kv=bool(output_kv), **extra)
         assert out.shape == shape_before
@@ -90,6 +94,7 @@ class ModifiedLMBlock(nn.Module):
         self.text_time = None
         self.hoisted_kv = None
         self.kv_output = None
+        self.autograd_cut = None     # graphs.AutogradCuts.cut when this layer starts a backward segment (FlamingoBaseModel.install_autograd_cuts)
 
     def condition(self, visual_features: torch.Tensor, media_locations: torch.Tensor, xattn_layer_past=None,
                   text_time: Optional[torch.Tensor] = None, hoisted_kv: Optional[torch.Tensor] = None) -> None:
@@ -112,6 +117,8 @@ class ModifiedLMBlock(nn.Module):
 
     def forward(self, hidden_states, *args, **kwargs):
         use_cache = self._use_cache_flag(args, kwargs)
+        if self.autograd_cut is not None:
+            hidden_states = self.autograd_cut(hidden_states)
         hidden_states, kv = self.xattn_block(
             y=hidden_states,
             visual_features=self.visual_features,

@@ -8,6 +8,10 @@ allocation, no host synchronisation), so forward + backward + optimizer can be c
     step = GraphedTrainStep(model, optimizer, example_batch)         # warms up, captures
     loss = step(batch)                                                # copies the batch into the static inputs, replays
 
+PiecewiseGraphedTrainStep is the variant that does not depend on collectives being capturable: the step is cut into sub-graphs
+(forward | one backward segment per few LM layers | resampler backward | optimizer) that are replayed one after the other, and the
+gradient collectives are issued EAGERLY between the replays, on the reducer's side stream, overlapping the next segment.
+
 Requirements: fixed shapes, an optimizer whose step is capture-safe (FusedAdamW(capturable=True) or
 torch.optim.AdamW(capturable=True)), and no data-dependent host control flow in the model (true for FlamingoModel's
 training forward).  With `reducer=` (data_parallel.GradientAllReducer) the gradient all-reduces are part of the capture: they are
@@ -96,4 +100,158 @@ class GraphedTrainStep:
         if self.optimizer is not None and hasattr(self.optimizer, "sync_device_hyperparams"):
             self.optimizer.sync_device_hyperparams()        # an LR scheduler may have changed group["lr"] since the capture
         self.graph.replay()
+        return self.loss
+
+
+class AutogradCuts:
+    """Cut points of the autograd graph.  `cut(t)` returns a detached copy-free twin of `t` that requires grad and remembers the pair;
+    `backward(loss)` then runs the backward pass segment by segment: from the loss down to the nearest cuts, then from each cut's attached
+    tensor (with the gradient its twin collected) down to the next ones, newest cut first.  Every segment is its own autograd call - its own
+    graph task, its own flush of the deferred weight gradients - so it can be captured into its own HIP graph, and whatever must happen
+    between segments (a collective, here) happens between two calls instead of inside one.  Valid because a cut created earlier in the
+    forward can only be consumed by work that flows into LATER cuts or the loss: by the time a pair is processed its twin's gradient is final."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def reset(self) -> None:
+        self.pairs = []
+
+    def cut(self, t: torch.Tensor) -> torch.Tensor:
+        if not (torch.is_grad_enabled() and t.requires_grad):
+            return t
+        twin = t.detach().requires_grad_(True)
+        self.pairs.append((t, twin))
+        return twin
+
+    def segments(self, loss: torch.Tensor):
+        """The backward pass as a list of thunks, one per segment, in execution order."""
+        def top():
+            loss.backward()
+
+        def below(pair):
+            attached, twin = pair
+            if twin.grad is not None:                       # (a twin nothing consumed - e.g. features unused under cached K / V - has no gradient)
+                torch.autograd.backward(attached, twin.grad)
+        return [top] + [lambda pair=pair: below(pair) for pair in reversed(self.pairs)]
+
+    def backward(self, loss: torch.Tensor) -> None:
+        for seg in self.segments(loss):
+            seg()
+
+
+class PiecewiseGraphedTrainStep:
+    """A training step replayed from SEVERAL HIP graphs with the gradient collectives issued eagerly between them.
+
+        forward | backward of the top `segment_layers` gated layers (+ head) | ... | backward of the bottom ones (+ embedding) |
+        resampler backward | optimizer
+
+    Each `|` is a graph boundary.  After a backward segment has been launched, the buckets that became final in it (recorded once, while
+    that segment was captured: the flat gradient buffers are static) are handed to the reducer, which all-reduces them on its side
+    stream while the next segment's graph runs; the optimizer graph is launched after reducer.finish().  Nothing here needs RCCL kernels to
+    be capturable, and a rank that cannot capture a piece can run that piece eagerly without changing the protocol between ranks.
+    `capture=False` runs the same segmented step with eager launches (CPU / gloo tests of the segmentation; a debugging aid on the GPU).
+
+    The model must offer `install_autograd_cuts(cuts, segment_layers)` (FlamingoModel / FlamingoBaseModel do: the visual features and the
+    hidden state in front of every `segment_layers`-th gated layer become cut points).  Segment boundaries should coincide with the bucket
+    structure the reducer sets (4 layers per weight-gradient group and per K / V projection call), which is the default."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
+                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, segment_layers: int = 4, capture: bool = True):
+        self.model, self.optimizer, self.reducer = model, optimizer, reducer
+        self.capture = bool(capture)
+        self._loss_fn = loss_fn or (lambda out: out.loss)
+        self.cuts = AutogradCuts()
+        if not hasattr(model, "install_autograd_cuts"):
+            raise TypeError("PiecewiseGraphedTrainStep: the model has no install_autograd_cuts(cuts, segment_layers)")
+        model.install_autograd_cuts(self.cuts, segment_layers)
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        self.graphs = []
+        self.segment_buckets = []
+        if not self.capture:
+            self.loss = None
+            return
+        if not torch.cuda.is_available():
+            raise RuntimeError("PiecewiseGraphedTrainStep(capture=True) needs a GPU")
+        _refuse_live_autograd_graphs(model)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        import torch.distributed as dist
+        mode = "thread_local" if reducer is not None or (dist.is_available() and dist.is_initialized()) else "global"
+        pool = torch.cuda.graph_pool_handle()
+
+        def piece(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                out = fn()
+            self.graphs.append(g)
+            return out
+
+        model.zero_grad(set_to_none=True)
+        self.cuts.reset()
+        loss = piece(lambda: self._loss_fn(self.model(**self.static)))
+        self.loss = loss.detach()
+        for seg in self.cuts.segments(loss):
+            if reducer is not None:
+                reducer.begin_collect()
+            piece(seg)
+            self.segment_buckets.append(reducer.end_collect() if reducer is not None else [])
+        if reducer is not None:        # an un-fused parameter (the tied token embedding) takes part in two segments: exchange it after the last one
+            seen = set()
+            for buckets in reversed(self.segment_buckets):
+                keep = [b for b in buckets if b[1] or b[0].data_ptr() not in seen]
+                seen.update(b[0].data_ptr() for b in buckets if not b[1])
+                buckets[:] = keep
+        self._opt_graph = None
+        if optimizer is not None:
+            piece(optimizer.step)
+            self._opt_graph = self.graphs.pop()
+        del loss
+        self.cuts.reset()               # the pairs' memory belongs to the graphs' pool; the Python references are not needed any more
+        torch.cuda.synchronize()
+
+    def _eager(self) -> torch.Tensor:
+        """The segmented step with eager launches (warm-up, capture=False): collectives are issued from inside backward as usual, except
+        that un-fused parameters, whose gradient is accumulated by two segments, are exchanged after the last one (reducer.finish())."""
+        self.model.zero_grad(set_to_none=True)
+        self.cuts.reset()
+        loss = self._loss_fn(self.model(**self.static))
+        if self.reducer is not None:
+            self.reducer.defer_loose = True
+        try:
+            self.cuts.backward(loss)
+        finally:
+            if self.reducer is not None:
+                self.reducer.defer_loose = False
+        self.cuts.reset()
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+        if batch is not None:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self.static[k].copy_(v, non_blocking=True)
+        if not self.capture:
+            self.loss = self._eager()
+            return self.loss
+        if self.optimizer is not None and hasattr(self.optimizer, "sync_device_hyperparams"):
+            self.optimizer.sync_device_hyperparams()
+        self.graphs[0].replay()
+        for g, buckets in zip(self.graphs[1:], self.segment_buckets):
+            g.replay()
+            for flat, owners in buckets:                    # eager collectives on the reducer's side stream, behind this segment
+                self.reducer.reduce_bucket(flat, owners)
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self._opt_graph is not None:
+            self._opt_graph.replay()
         return self.loss

@@ -68,14 +68,53 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
             dim=config.dim_visual, depth=config.resampler_depth, dim_head=config.resampler_dim_head,
             heads=config.resampler_heads, num_latents=config.resampler_num_latents,
             num_time_embeds=config.resampler_num_time_embeds, ff_mult=config.resampler_ff_mult, act=config.resampler_act)
+        # Launch structure of the fusion path - plain attributes of the model (no environment variable), see set_launch_structure():
         # keys / values of all cross-attention layers in grouped launches ahead of the LM (functional.kv_project): 41.5 -> 40.2 ms per
-        # step at the benchmark configuration; FF_HOIST_KV=0 (or .hoist_kv = False) restores the per-layer projection
-        self.hoist_kv = os.environ.get("FF_HOIST_KV", "1") == "1"
+        # step at the benchmark configuration; .hoist_kv = False restores the per-layer projection
+        self.hoist_kv = True
         # 0: ONE projection call (one autograd node, one gradient bucket) for all layers; n > 0: one call per n consecutive layers, so that
         # under data parallelism the to_kv gradients of the upper layers are final - and their all-reduce starts - while backward is still
         # working on the lower ones (the data-parallel reducers set 4 = one grouped launch per call; a single bucket of all 36 to_kv
         # weights, 75 MB at flamingo-mini's size, would only become ready at the very end of backward)
-        self.kv_project_group = int(os.environ.get("FF_KV_GROUP", "0"))      # (the environment variable: to trace the data-parallel launch structure on one GPU)
+        self.kv_project_group = 0
+
+    def set_launch_structure(self, *, hoist_kv: Optional[bool] = None, kv_project_group: Optional[int] = None,
+                             defer_wgrad: Optional[bool] = None, wgrad_group: "Optional[int] | str" = "keep") -> Dict[str, Any]:
+        """How the fusion path batches its launches (results are identical for every setting; only the launch / gradient-bucket structure
+        changes).  hoist_kv / kv_project_group: see __init__.  defer_wgrad / wgrad_group: the blocks' weight gradients run as launches
+        grouped over `wgrad_group` consecutive layers (None = the library default of 12; data-parallel reducers use 4 so that a gradient
+        bucket becomes final every four layers of backward).  Returns the PREVIOUS settings as a dict that can be passed back
+        (`model.set_launch_structure(**previous)`) - data_parallel.GradientAllReducer.close() does exactly that."""
+        blocks = [h.xattn_block for h in self.get_modified_layers()]
+        prev = dict(hoist_kv=self.hoist_kv, kv_project_group=self.kv_project_group,
+                    defer_wgrad=blocks[0].defer_wgrad if blocks else True, wgrad_group=blocks[0].wgrad_group if blocks else None)
+        if hoist_kv is not None:
+            self.hoist_kv = bool(hoist_kv)
+        if kv_project_group is not None:
+            self.kv_project_group = int(kv_project_group)
+        for b in blocks:
+            if defer_wgrad is not None:
+                b.defer_wgrad = bool(defer_wgrad)
+            if wgrad_group != "keep":
+                b.wgrad_group = None if wgrad_group is None else int(wgrad_group)
+        return prev
+
+    def install_autograd_cuts(self, cuts, segment_layers: int = 4) -> None:
+        """graphs.PiecewiseGraphedTrainStep: make the visual features and the hidden state in front of every `segment_layers`-th gated
+        layer cut points of the autograd graph (`cuts.cut`), so that backward runs - and is captured - segment by segment.  None removes them."""
+        self._autograd_cuts = cuts
+        seg = max(1, int(segment_layers))
+        if cuts is not None:
+            # a K / V projection call must not serve layers of two segments (its backward node would be entered by both): one call per
+            # segment, or per whole fraction of one
+            if not (self.kv_project_group > 0 and seg % self.kv_project_group == 0):
+                self._kv_group_before_cuts = self.kv_project_group
+                self.kv_project_group = seg
+        elif hasattr(self, "_kv_group_before_cuts"):
+            self.kv_project_group = self._kv_group_before_cuts
+            del self._kv_group_before_cuts
+        for i, hook in enumerate(self.get_modified_layers()):
+            hook.autograd_cut = cuts.cut if (cuts is not None and i > 0 and i % max(1, segment_layers) == 0) else None
 
     def _init_weights(self, module):  # backbones initialise themselves; fusion modules use torch defaults like the reference
         pass
@@ -150,6 +189,15 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
             else:  # cached K/V make the features irrelevant; only the shape is used
                 visual_features = torch.zeros((batch_size, 1, self.config.resampler_num_latents, self.config.dim_visual),
                                               dtype=self.resampler.latents.dtype, device=device)
+        if self.training and (getattr(self.lm, "gradient_checkpointing", False) or any(getattr(m, "gradient_checkpointing", False) for m in self.lm.modules())):
+            # The conditioning of the hooks (and the K / V projected up front for every layer) lives for ONE call and is dropped when the LM
+            # returns; a recomputation of LM blocks during backward would re-enter the hooks without it.
+            raise NotImplementedError("activation checkpointing of the language model is not supported by the fused cross-attention hooks: "
+                                      "their conditioning (visual features, hoisted K / V) is released when forward() returns. "
+                                      "Disable gradient checkpointing (the frozen LM keeps few activations: only the trainable blocks save theirs).")
+        cuts = getattr(self, "_autograd_cuts", None)
+        if cuts is not None and xattn_past is None:
+            visual_features = cuts.cut(visual_features)      # (PiecewiseGraphedTrainStep: the resampler's backward becomes its own segment)
         if text_time is None:
             if media_locations is None:
                 media_locations = torch.zeros((batch_size, seq_length), dtype=torch.int, device=device)
@@ -243,7 +291,9 @@ class FlamingoOPT(FlamingoBaseModel):
 
 
 # Decode sessions hold HIP graphs and raw parameter addresses: they live in a weak side table, not in the model's __dict__, so
-# copy.deepcopy(model) / pickling (EMA or evaluation copies) neither see nor try to copy them.
+# copy.deepcopy(model) / pickling (EMA or evaluation copies) neither see nor try to copy them.  The table is keyed by the model and a
+# session refers to its model only WEAKLY (a strong reference from the value would keep the key - and with it the model, its static KV
+# cache and the captured graph - alive for ever): `del model` frees all of it.
 import weakref
 _DECODE_SESSIONS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
@@ -259,7 +309,8 @@ class _DecodeSession:
 
     def __init__(self, model, b, max_length, device, ids_dtype, am_dtype, eos, pad, graph):
         from transformers.cache_utils import StaticCache
-        self.model, self.b, self.max_length, self.eos, self.graph_wanted = model, b, max_length, eos, graph
+        self._model_ref = weakref.ref(model)
+        self.b, self.max_length, self.eos, self.graph_wanted = b, max_length, eos, graph
         self.fill = pad if pad is not None else 0
         self.cache = StaticCache(config=model.flamingo.lm.config, max_cache_len=max_length)
         self.ids_buf = torch.empty((b, max_length), dtype=ids_dtype, device=device)
@@ -273,6 +324,13 @@ class _DecodeSession:
         self.replay = None
         self.capture_failed = False
         self.param_ptrs = self._param_ptrs()                                   # what a captured graph reads: checked before every reuse
+
+    @property
+    def model(self):
+        m = self._model_ref()
+        if m is None:
+            raise RuntimeError("decode session used after its model was deleted")
+        return m
 
     def _param_ptrs(self):
         return tuple(p.data_ptr() for p in self.model.parameters())
@@ -380,6 +438,12 @@ class FlamingoModel(PreTrainedModel):
 
     def parameters_trainable(self):
         return self.flamingo.parameters_trainable()
+
+    def install_autograd_cuts(self, cuts, segment_layers: int = 4) -> None:
+        self.flamingo.install_autograd_cuts(cuts, segment_layers)
+
+    def set_launch_structure(self, **kw):
+        return self.flamingo.set_launch_structure(**kw)
 
     def freeze_vm(self):
         self.flamingo.freeze_vm()

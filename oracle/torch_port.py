@@ -124,7 +124,7 @@ def install() -> None:
         keys = ["latents", "time_pos_emb", "norm.weight", "norm.bias"] + [f"layers.{i}.{k}" for i in range(depth) for k in RS_LAYER_KEYS]
         return resampler(x_f, dict(zip(keys, params)), heads=heads, dim_head=dim_head, act=act)
 
-    def xa(y, vf, tt, params, cfg, n_visual, previous_kv=None, output_kv=False, hoisted_kv=None):
+    def xa(y, vf, tt, params, cfg, n_visual, previous_kv=None, output_kv=False, hoisted_kv=None, wgrad=None):
         heads, dim_head, _, act = cfg
         ml = torch.diff(tt.to(torch.int64), dim=1, prepend=torch.zeros_like(tt[:, :1], dtype=torch.int64))
         out, kv = gated_xattn_block(y, vf, ml, dict(zip(XA_KEYS, params)), heads=heads, dim_head=dim_head, act=act, n_visual=n_visual,

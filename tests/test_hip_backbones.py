@@ -1,6 +1,6 @@
 """The op substitutions inside the frozen backbones (flamingo_mini_amd/backbones.py: ViT patch convolution evaluated as a matmul, CLIP's
 QuickGELU as one pass of the fusion library, HF's NewGELUActivation -> torch's fused tanh GELU) must leave the model's function alone:
-the substituted model against the UNTOUCHED Hugging Face modules (FLAMINGO_STOCK_BACKBONES=1) on the same weights and inputs - logits and
+the substituted model (FlamingoConfig(backbone_op_substitutions=True)) against the UNTOUCHED Hugging Face modules (the default) on the same weights and inputs - logits and
 loss, fp32 and bf16 - eagerly and when the training step is replayed from a captured HIP graph."""
 import os
 
@@ -15,21 +15,14 @@ pytestmark = pytest.mark.gpu
 
 def _build(stock: bool, dtype):
     from flamingo_mini_amd import FlamingoConfig, FlamingoModel
-    old = os.environ.get("FLAMINGO_STOCK_BACKBONES")
-    os.environ["FLAMINGO_STOCK_BACKBONES"] = "1" if stock else "0"
-    try:
-        # flamingo-tiny's architectures (BASELINE configs[0]) with fewer layers and no dropout inside the LM (dropout draws differ between
-        # an eager step and a replayed one by construction; everything else is deterministic)
-        cfg = FlamingoConfig(lm="gpt2", clip_model_type="openai/clip-vit-base-patch32", dim=768, dim_visual=768, random_init_backbones=True,
-                             backbone_overrides={"lm": dict(n_layer=4, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0),
-                                                 "clip": dict(num_hidden_layers=4)})
-        torch.manual_seed(7)
-        model = FlamingoModel(cfg)
-    finally:
-        if old is None:
-            os.environ.pop("FLAMINGO_STOCK_BACKBONES", None)
-        else:
-            os.environ["FLAMINGO_STOCK_BACKBONES"] = old
+    # flamingo-tiny's architectures (BASELINE configs[0]) with fewer layers and no dropout inside the LM (dropout draws differ between
+    # an eager step and a replayed one by construction; everything else is deterministic)
+    cfg = FlamingoConfig(lm="gpt2", clip_model_type="openai/clip-vit-base-patch32", dim=768, dim_visual=768, random_init_backbones=True,
+                         backbone_op_substitutions=not stock,
+                         backbone_overrides={"lm": dict(n_layer=4, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0),
+                                             "clip": dict(num_hidden_layers=4)})
+    torch.manual_seed(7)
+    model = FlamingoModel(cfg)
     with torch.no_grad():
         for hook in model.flamingo.get_modified_layers():
             hook.xattn_block.alpha_attn.fill_(0.5)

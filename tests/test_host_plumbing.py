@@ -98,6 +98,56 @@ def test_product_autograd_on_the_host_library_matches_the_oracle_model(clean_pat
         assert _close(v, 2.0 * want[k], 2e-4), k
 
 
+def _batch(z, rows, dtype):
+    ids = torch.from_numpy(z["ids"])[rows]
+    return dict(input_ids=ids, attention_mask=torch.ones_like(ids), media_locations=torch.from_numpy(z["ml"])[rows],
+                pixel_values=torch.from_numpy(z["px"])[rows].to(dtype), labels=ids)
+
+
+def test_segmented_backward_equals_one_backward_on_the_product_gradient_flow(clean_patches):
+    """graphs.PiecewiseGraphedTrainStep(capture=False): the visual features and the hidden state in front of every gated layer become cut
+    points, backward runs as one autograd call per segment (each with its own flush of the deferred weight gradients) - the gradients,
+    including the tied token embedding's, which two segments accumulate into, must be those of a single backward pass."""
+    from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
+    ref, z, _ = _model("oracle")
+    ref.zero_grad(set_to_none=True)
+    ref_loss = _loss(ref, z, [0, 1], torch.float64)
+    ref_loss.backward()
+    want = _grads(ref)
+    model, z, host = _model("host")
+    n_hooks = len(model.flamingo.get_modified_layers())
+    step = PiecewiseGraphedTrainStep(model, None, _batch(z, [0, 1], torch.float32), capture=False, segment_layers=1)
+    host.calls.clear()
+    loss = step()
+    assert abs(float(loss) - float(ref_loss)) < 1e-4
+    got = _grads(model)
+    assert set(got) == set(want)
+    for k in want:
+        assert np.isfinite(got[k]).all() and _close(got[k], want[k], 2e-4), k
+    # one segment per gated layer: every block's weight gradients were flushed by its own segment's end-of-pass callback
+    grouped = [int(c.split("[")[1][:-1]) for c in host.calls if c.startswith("ff_xattn_wgrad_grouped")]
+    assert grouped == [1] * n_hooks, grouped
+    assert host.calls.index("ff_resampler_bwd") > max(i for i, c in enumerate(host.calls) if c.startswith("ff_xattn_wgrad_grouped"))
+    model.install_autograd_cuts(None)
+    assert all(h.autograd_cut is None for h in model.flamingo.get_modified_layers())
+
+
+def test_reducers_restore_the_models_launch_structure_on_close(clean_patches):
+    """A reducer with collectives switches ITS model to the bucket-friendly launch structure (4 layers per weight-gradient group and per
+    K / V projection call) and close() puts back what was there - nothing process-wide is touched."""
+    from flamingo_mini_amd import functional as F
+    from flamingo_mini_amd.data_parallel import _bucket_launch_structure
+    model, z, _ = _model("host")
+    before = F._wgrad_queue.group
+    model.set_launch_structure(wgrad_group=7)
+    undo = _bucket_launch_structure(model)
+    blocks = [h.xattn_block for h in model.flamingo.get_modified_layers()]
+    assert model.flamingo.kv_project_group == 4 and all(b.wgrad_group == 4 for b in blocks) and F._wgrad_queue.group == before
+    for m, prev in undo:
+        m.set_launch_structure(**prev)
+    assert model.flamingo.kv_project_group == 0 and all(b.wgrad_group == 7 for b in blocks)
+
+
 def test_per_layer_projection_and_cached_decoding_on_the_host_library(clean_patches):
     """hoist_kv = False (the block projects K / V itself and returns views of the library's saved buffer) and the cached decode call with
     strided K / V and the tail of text_time - through the real functional.py; generation both with the growing cache and with the
@@ -158,6 +208,16 @@ def _worker(rank, world, port, out_dir, mode):
         reducer.finish()
         out.update({"acc." + k: v for k, v in _grads(model).items()})
         reducer.close()
+        assert model.flamingo.kv_project_group == 0        # close() restores what the constructor found (one projection call for all layers)
+    elif mode == "piecewise":
+        # the segmented step (graphs.PiecewiseGraphedTrainStep, eager launches on CPU ranks): bucket exchanges are issued from inside each
+        # segment's backward, the tied embedding - accumulated by two segments - is exchanged once, in finish()
+        from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
+        reducer = GradientAllReducer(model)
+        step = PiecewiseGraphedTrainStep(model, None, _batch(z, [rank], torch.float32), capture=False, segment_layers=1, reducer=reducer)
+        step()
+        out = {k: v for k, v in _grads(model).items()}
+        reducer.close()
     else:
         from test_data_parallel import HP, _torch_adamw
         opt = ShardedAdamW(model, update_fn=_torch_adamw, **HP)
@@ -172,13 +232,13 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["reduce", "sharded"])
+@pytest.mark.parametrize("mode", ["reduce", "sharded", "piecewise"])
 def test_two_gloo_ranks_on_the_product_gradient_flow(tmp_path, mode, clean_patches):
     port = _free_port()
     mp.start_processes(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True, start_method="spawn")
     r0, r1 = np.load(tmp_path / f"{mode}0.npz"), np.load(tmp_path / f"{mode}1.npz")
     ref, z, _ = _model("oracle")
-    if mode == "reduce":
+    if mode in ("reduce", "piecewise"):
         ref.zero_grad(set_to_none=True)
         ((_loss(ref, z, [0], torch.float64) + _loss(ref, z, [1], torch.float64)) / 2).backward()
         want = _grads(ref)

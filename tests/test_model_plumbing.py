@@ -216,6 +216,13 @@ def test_generation_strategies_cpu_with_oracle_checker(family):
             assert sess.stale()
             assert torch.equal(model.generate(ids, static_decode=True, **kw), greedy)
             assert next(iter(model._decode_sessions.values())) is not sess and len(model._decode_sessions) == 1
+            import gc
+            import weakref
+            alive = weakref.ref(twin)                                         # a session must not keep its model (KV cache, graph) alive
+            assert len(twin._decode_sessions) == 1
+            del twin
+            gc.collect()
+            assert alive() is None, "a decode session holds a strong reference to its model"
             for eos in {int(greedy[0, 5]), int(greedy[1, 7]), int(greedy[0, 8])}:     # early stop: same tokens, same trimmed length
                 want = model.generate(ids, eos_token_id=eos, pad_token_id=0, static_decode=False, **kw)
                 got = model.generate(ids, eos_token_id=eos, pad_token_id=0, static_decode=True, **kw)

@@ -12,9 +12,13 @@ Synthetic data (N(0,1) pixels, uniform token ids, media tag at position 0), rand
 architectures (no network), gates alpha = 0.5 (zero gates would make the fusion path an identity with zero gradients).
 The resampler / xattn blocks run in libflamingo_fusion (hand-written HIP); the run aborts if that library is missing.
 
-At N = 1 the step (forward + backward + optimizer) is captured once into a HIP graph and the timed region replays it
-(`--graph off`: eager launches, as at N > 1 where the RCCL all-reduce is not captured).  The stock CLIP / GPT-2 GEMMs use
-the pre-tuned hipBLASLt solutions in flamingo-mini_amd/tuning/ (`--stock-tuning off` for hipBLASLt's default heuristic).
+The step (forward + backward + gradient exchange + optimizer) is captured once into a HIP graph and the timed region replays it
+(`--graph off`: eager launches; `--graph piecewise`: one sub-graph per backward segment with the RCCL collectives issued eagerly
+between the replays - the path that does not depend on collectives being capturable).
+The headline `value` is the north star's configuration: the frozen CLIP / GPT-2 stay UNTOUCHED Hugging Face modules on stock
+PyTorch-ROCm with hipBLASLt's default heuristic.  `--backbone-tweaks on` enables three result-identical op substitutions inside them
+plus the pre-tuned hipBLASLt solution file for their GEMMs (flamingo-mini_amd/tuning/); the default run reports that configuration too,
+as the companion `with_backbone_op_substitutions`.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live: right after the timed region `--profile-steps` eager steps of
 the same workload run with every GEMM / attention launch of the fusion library bracketed by HIP events on its stream
@@ -78,28 +82,34 @@ def parse():
     ap.add_argument("--reduce-dtype", default="native", choices=["native", "f32"],
                     help="N > 1 with the all-reduce path: exchange gradient buckets in their own dtype (bf16, ReduceOp.AVG) or widened to fp32")
     ap.add_argument("--companions", default="auto", choices=["auto", "on", "off"],
-                    help="N=1 only: after the main measurement, re-run the same workload in child processes (a) with the untouched Hugging Face backbones "
-                         "and no tuning file, (b) with the fp32-master / fp32-moment optimizer, and add both to the JSON line (auto = on for the default config B run)")
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the step from a captured HIP graph (auto = on; at N > 1 the RCCL all-reduces are captured with it, and the "
-                         "step falls back to eager launches if that capture fails)")
+                    help="N=1 only: after the main measurement, re-run the same workload in child processes (a) with the op substitutions inside the "
+                         "backbones + the tuning file, (b) with the fp32-master / fp32-moment optimizer, and add both to the JSON line (auto = on for the default config B run)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off", "piecewise"],
+                    help="replay the step from a captured HIP graph (auto = on; at N > 1 the RCCL all-reduces are captured with it; if that capture "
+                         "fails on a rank the step falls back to `piecewise`, then to eager launches); piecewise = one sub-graph per backward segment "
+                         "of 4 gated layers, collectives issued eagerly between the replays")
+    ap.add_argument("--force-collectives", action="store_true", help="N=1: run the gradient exchange through a 1-rank RCCL group (what a single GPU can exercise of the N > 1 path)")
+    ap.add_argument("--bucket-timeline", action="store_true", help="after the timed region, one eager step with HIP events around every gradient "
+                                                                   "bucket's exchange: when it became ready, when its collective finished (rank 0, `bucket_timeline` in the JSON line)")
+    ap.add_argument("--wgrad-group", type=int, default=0, help="gated layers per grouped weight-gradient launch (0 = default: 12, or 4 with collectives)")
+    ap.add_argument("--kv-group", type=int, default=-1, help="gated layers per K / V projection call (-1 = default: all, or 4 with collectives)")
+    ap.add_argument("--lm-dropout", type=float, default=None, help="debugging aid: dropout probability inside the stock LM (default: the architecture's)")
     ap.add_argument("--profile-steps", type=int, default=3, help="instrumented eager steps after the timed region (roofline objects)")
-    ap.add_argument("--stock-tuning", default="on", choices=["on", "off"],
-                    help="load the pre-tuned hipBLASLt solution file for the stock CLIP / GPT-2 GEMMs (PyTorch TunableOp, tuning off)")
-    ap.add_argument("--backbone-tweaks", default="on", choices=["on", "off"],
-                    help="off = untouched Hugging Face CLIP / LM (no fused QuickGELU, no patch-conv-as-matmul, no GELU module swap) and no "
-                         "pre-tuned stock-GEMM file: isolates what the fusion path alone contributes")
+    ap.add_argument("--stock-tuning", default="auto", choices=["auto", "on", "off"],
+                    help="load the pre-tuned hipBLASLt solution file for the stock CLIP / GPT-2 GEMMs (PyTorch TunableOp, tuning off); auto = with --backbone-tweaks on")
+    ap.add_argument("--backbone-tweaks", default="off", choices=["on", "off"],
+                    help="off (default, the north star's configuration) = untouched Hugging Face CLIP / LM on stock PyTorch-ROCm; on = fused QuickGELU, "
+                         "patch-conv-as-matmul, fused tanh-GELU module inside them and the pre-tuned stock-GEMM file")
     ap.add_argument("--debug-phases", action="store_true", help="print host-side issue time of each phase of 5 eager steps and exit")
-    ap.add_argument("--hoist-kv", default="env", choices=["env", "on", "off"],
-                    help="project K / V of all cross-attention layers up front in grouped launches (env = FF_HOIST_KV, default on)")
+    ap.add_argument("--hoist-kv", default="on", choices=["on", "off"],
+                    help="project K / V of all cross-attention layers up front in grouped launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--child", action="store_true", help="internal: a companion run started by the main process (timed region only)")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
     args = ap.parse_args()
-    if args.backbone_tweaks == "off":
-        os.environ["FLAMINGO_STOCK_BACKBONES"] = "1"
-        args.stock_tuning = "off"
+    if args.stock_tuning == "auto":
+        args.stock_tuning = args.backbone_tweaks
     if args.child:
         args.no_cpu_baseline, args.caption_tokens, args.profile_steps, args.companions = True, 0, 0, "off"
     for k, v in CONFIGS[args.config].items():
@@ -113,8 +123,12 @@ def build_model(args, device, dtype):
     from flamingo_mini_amd import FlamingoConfig, FlamingoModel
     from flamingo_mini_amd.backbones import CLIP_VISION, GPT2, OPT
     dim = GPT2[args.lm][0] if args.lm in GPT2 else OPT[args.lm][0]
+    overrides = {}
+    if args.lm_dropout is not None:
+        d = float(args.lm_dropout)
+        overrides["lm"] = dict(attn_pdrop=d, resid_pdrop=d, embd_pdrop=d) if args.lm.startswith("gpt2") else dict(dropout=d, attention_dropout=d)
     cfg = FlamingoConfig(lm=args.lm, clip_model_type=args.clip, dim=dim, dim_visual=CLIP_VISION[args.clip][0], xattn_every=args.xattn_every,
-                         random_init_backbones=True)
+                         random_init_backbones=True, backbone_op_substitutions=args.backbone_tweaks == "on", backbone_overrides=overrides)
     torch.manual_seed(1234)                                   # same weights on every rank (DDP broadcasts; here: same seed)
     with torch.device(device):                                # random init straight on the GPU (opt-6.7b + 32 gated blocks are 11 G parameters)
         model = FlamingoModel(cfg)
@@ -206,8 +220,47 @@ def caption_leg(args, model, batch, device):
     lmkv_bytes = int(n_lm_layers * args.batch * 2 * avg_pos * cfg.dim * es)
     step_bytes = lm_bytes + blk_bytes + xkv_bytes + lmkv_bytes
     step_s = dt / new
+    # The library's own share of a token step, measured directly: the 36 cached gated-block calls of one decode step (the same calls on the
+    # same persistent K / V buffers, without the stock LM blocks between them) captured into a HIP graph and replayed.
+    library = None
+    try:
+        sess = sessions[0]
+        past, tt = sess.xattn_past, sess.tt_step
+        y0 = torch.randn((args.batch, 1, cfg.dim), device=device, dtype=next(model.parameters()).dtype)
+
+        def chain():
+            h = y0
+            for hook, kv in zip(blocks, past):
+                h, _ = hook.xattn_block(h, None, None, previous_kv=kv, output_kv=False, text_time=tt)
+            return h
+
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                chain(); chain()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                chain()
+            reps = 30
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g.replay(); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            lib_ms = e0.elapsed_time(e1) / reps
+        lib_bytes = blk_bytes + xkv_bytes
+        library = {"library_ms_per_decode_step": round(lib_ms, 3), "launch_mode": "HIP graph replay of the 36 cached gated-block calls alone",
+                   "library_roofline": {"bound": "hbm", "achieved": round(lib_bytes / (lib_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                        "frac": round(lib_bytes / (lib_ms * 1e-3) / 8e12, 4), "bytes": lib_bytes}}
+    except Exception as e:      # a reported extra, never a reason to lose the line
+        library = {"error": repr(e)[:200]}
     return {"value": round(args.batch * new / dt, 1), "unit": "caption tokens/sec", "batch": args.batch, "new_tokens_per_image": new,
-            "ms_per_decode_step": round(dt / new * 1e3, 2), "decode_step_hip_graph": graphed,
+            "ms_per_decode_step": round(dt / new * 1e3, 2), "decode_step_hip_graph": graphed, "library": library,
             "roofline": {"bound": "hbm", "achieved": round(step_bytes / step_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(step_bytes / step_s / 8e12, 4),
                          "bytes_per_decode_step": {"lm_weights": lm_bytes, "xattn_block_weights": blk_bytes, "xattn_kv_cache": xkv_bytes, "lm_kv_cache_avg": lmkv_bytes},
@@ -220,10 +273,9 @@ def run_companion(args, extra, timeout=420):
     """The same workload in a child process with other switches; returns the fields of its JSON line that matter next to the main one."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--child", "--config", args.config, "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--batch", str(args.batch), "--seq-len", str(args.seq_len), "--graph", args.graph] + extra
-    env = {k: v for k, v in os.environ.items() if k != "FLAMINGO_STOCK_BACKBONES"}
+           "--batch", str(args.batch), "--seq-len", str(args.seq_len), "--graph", args.graph, "--backbone-tweaks", args.backbone_tweaks] + extra
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return {"error": (r.stderr or r.stdout)[-300:]}
@@ -364,15 +416,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the fusion path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    collectives = world > 1 or args.force_collectives
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if os.environ.get("FF_BENCH_SDPA"):                          # debugging aid: restrict torch's SDPA backends inside the stock backbones
-        want = os.environ["FF_BENCH_SDPA"]
-        torch.backends.cuda.enable_flash_sdp(want == "flash")
-        torch.backends.cuda.enable_mem_efficient_sdp(want == "efficient")
-        torch.backends.cuda.enable_math_sdp(want == "math")
     memsnap = os.environ.get("FF_BENCH_MEMSNAP", "")            # debugging aid: allocator map (with allocation stacks) before the timed region
     if memsnap:
         torch.cuda.memory._record_memory_history(context="alloc", stacks="python", max_entries=400000)
@@ -387,15 +440,15 @@ def main():
         stock_tuned = load_stock_gemm_tuning()
     model, cfg = build_model(args, device, dtype)
     batch = synthetic_batch(args, cfg, device, dtype, rank)
-    if args.hoist_kv != "env":
-        model.flamingo.hoist_kv = args.hoist_kv == "on"
+    model.set_launch_structure(hoist_kv=args.hoist_kv == "on")
     params = [p for p in model.parameters_trainable()]
     n_trainable = sum(p.numel() for p in params)
     # Config E (4 x 1024 tokens) is launched eagerly under `auto`: replaying a captured step faults inside PyTorch-ROCm's memory-efficient
-    # SDPA kernels once the sequence reaches 1024 tokens and the stock LM has dropout active (tools/debug_e_bisect3.sh / 4.sh: the same
+    # SDPA kernels once the sequence reaches 1024 tokens and the stock LM has dropout active (bisected in round 2, DESIGN.md section 5: the same
     # fault with gpt2-large, with one gated block, without the optimizer; no fault with the math SDPA backend, with LM dropout 0, at 512
     # tokens, or when only this library's kernels are captured at the same shapes).  `--graph on` still forces the capture.
-    use_graph = args.graph == "on" or (args.graph == "auto" and args.config != "E")
+    use_graph = args.graph in ("on", "piecewise") or (args.graph == "auto" and args.config != "E")
+    graph_mode = "piecewise" if args.graph == "piecewise" else ("full" if use_graph else "off")
     master = dict(master_dtype=torch.float32) if args.optimizer.endswith("-master") and dtype == torch.bfloat16 else {}
 
     def make_optimizer(capturable):
@@ -412,7 +465,13 @@ def main():
     opt = make_optimizer(use_graph)
     sharded = args.optimizer.startswith("sharded") and opt is not None
     # ShardedAdamW does the exchange itself (reduce-scatter / all-gather per bucket); otherwise the buckets are all-reduced
-    reducer = None if sharded else GradientAllReducer(model, reduce_dtype=torch.float32 if args.reduce_dtype == "f32" else None)
+    reducer = None if sharded else GradientAllReducer(model, reduce_dtype=torch.float32 if args.reduce_dtype == "f32" else None,
+                                                      force_collectives=args.force_collectives)
+    # explicit launch structure (after the reducer chose its own): what tools/bucket_timeline.py traces on one GPU
+    if args.wgrad_group > 0:
+        model.set_launch_structure(wgrad_group=args.wgrad_group)
+    if args.kv_group >= 0:
+        model.set_launch_structure(kv_project_group=args.kv_group)
 
     def eager_step():
         for p in params:                 # == model.zero_grad(set_to_none=True) without walking the ~1000 frozen parameters (4 ms of host time)
@@ -450,33 +509,46 @@ def main():
         print("host ms/step: zero_grad %.2f forward %.2f backward %.2f optimizer %.2f drain %.2f" % tuple(acc), flush=True)
         return
     graph_note = ""
-    if use_graph:       # forward + backward (+ gradient all-reduces) + optimizer captured once, one graph launch per step (flamingo_mini_amd/graphs.py)
+    step = eager_step
+    if use_graph:
+        # full: forward + backward + gradient all-reduces + optimizer captured once, one graph launch per step; piecewise: one sub-graph per
+        # backward segment, collectives issued eagerly between the replays (flamingo_mini_amd/graphs.py).  A rank on which `full` cannot be
+        # captured (e.g. RCCL kernels refusing the capture) makes EVERY rank fall back to `piecewise`, then to eager launches: all ranks
+        # must take the same path - a rank replaying captured collectives while another launches them eagerly would deadlock.
         from flamingo_mini_amd import GraphedTrainStep
-        err = None
-        try:
-            graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=reducer if (world > 1 and reducer is not None) else None)
-        except Exception as e:      # e.g. a collective that cannot be captured on this software stack: run the same step eagerly
-            if world == 1 and args.graph == "on":
-                raise
-            err = e
-            torch.cuda.synchronize()
-        captured = err is None
-        if world > 1:               # every rank must take the same path: a rank replaying captured collectives while another launches them
-            flag = torch.tensor([1 if captured else 0], device=device, dtype=torch.int32)      # eagerly would deadlock
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            captured = bool(flag.item())
-        if captured:
-            step = graphed
-        else:
-            graph_note = "; graph capture failed on a rank" + (f" ({type(err).__name__}: {str(err)[:120]})" if err is not None else "") + ", eager launches instead"
+        from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
+        live_reducer = reducer if (collectives and reducer is not None) else None
+        attempts = ["piecewise"] if graph_mode == "piecewise" else (["full", "piecewise"] if (collectives and not sharded) else ["full"])
+        graph_mode = "off"
+        for mode in attempts:
+            err = None
+            try:
+                if mode == "full":
+                    graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer)
+                else:
+                    graphed = PiecewiseGraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer)
+            except Exception as e:
+                if world == 1 and not collectives and args.graph in ("on", "piecewise"):
+                    raise
+                err = e
+                torch.cuda.synchronize()
+                model.install_autograd_cuts(None)
+            captured = err is None
+            if world > 1:
+                flag = torch.tensor([1 if captured else 0], device=device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                captured = bool(flag.item())
+            if captured:
+                step, graph_mode = graphed, mode
+                break
+            graph_note += f"; {mode} graph capture failed on a rank" + (f" ({type(err).__name__}: {str(err)[:120]})" if err is not None else "")
+        if graph_mode == "off":
+            graph_note += ", eager launches instead"
             use_graph = False
             if opt is not None and args.optimizer != "torch":
                 if sharded:
                     opt.close()
                 opt = make_optimizer(False)
-            step = eager_step
-    else:
-        step = eager_step
 
     if memsnap:
         _dump_allocator_map(memsnap)
@@ -507,6 +579,32 @@ def main():
     prof_steps = max(args.profile_steps, 0)
     max_rec = 4096 * max(prof_steps, 1)
     eager_ms = None
+    model.install_autograd_cuts(None)       # (a piecewise step leaves its cut points installed: the eager steps below run one backward pass)
+    bucket_timeline = None
+    if collectives and reducer is not None and (args.bucket_timeline or world > 1):
+        # One eager step with HIP events around every bucket's exchange (rank 0 reports): when each bucket became final, when its collective
+        # finished, both relative to the start of backward - the table DESIGN.md section 6 predicts, line by line.
+        eager_step()
+        torch.cuda.synchronize()
+        for p in params:
+            p.grad = None
+        out = model(**batch)
+        t_b0, t_b1, t_fin = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        reducer.record_timeline(True)
+        t_b0.record()
+        out.loss.backward()
+        t_b1.record()
+        reducer.finish()
+        t_fin.record()
+        if opt is not None:
+            opt.step()
+        torch.cuda.synchronize()
+        rows = reducer.timeline_ms(t_b0)
+        reducer.record_timeline(False)
+        bwd_ms = t_b0.elapsed_time(t_b1)
+        bucket_timeline = {"backward_ms": round(bwd_ms, 3), "exchange_finished_ms": round(t_b0.elapsed_time(t_fin), 3),
+                           "exposed_communication_ms": round(max(0.0, t_b0.elapsed_time(t_fin) - bwd_ms), 3),
+                           "launch_mode": "eager (events cannot be recorded inside a replayed graph)", "buckets": rows}
     if prof_steps:
         if use_graph:
             loss = eager_step()         # the eager allocator pool is cold after the graph's private pool: one untimed step
@@ -539,8 +637,11 @@ def main():
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             tm, tn = (64, 128) if key[1] == 6412 else (key[1], key[1])
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
-            if key[1] == 128160:      # the 8-wave producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU>
-                name = f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 4, 1, 8>"      # ..., DMA waves>
+            if key[1] == 128160:      # the producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU, DMA waves>; split-K launches
+                # of this tile run the 8-wave workgroup with a 3-deep ring (ff_gemm.hip run_bf16_dma): name the instantiation most launches used
+                n_split = sum(v["launches"] for k, v in shapes.items() if k[6] == 128160 and k[4] == key[2] and k[5] == key[3] and k[7] > 1)
+                name = (f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 3, 1, 4>" if 2 * n_split > g["launches"]
+                        else f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 4, 1, 8>")
             elif key[1] == 64002:
                 name = f"ff::gemm_bf16_pc_kernel<64, 64, {key[2]}, {key[3]}, 3, 2, 4>"
             elif key[1] == 3264:
@@ -588,7 +689,9 @@ def main():
                                    + f" + {args.seq_len} tokens per sequence, xattn_every {args.xattn_every}, "
                                    f"per-GPU batch {args.batch}; step = fwd + bwd + grad all-reduce"
                                    + ("" if args.no_optimizer else f" + AdamW ({args.optimizer})")
-                                   + ("; step replayed from a captured HIP graph" + (" (RCCL all-reduces captured)" if world > 1 else "") if use_graph else "; eager launches")
+                                   + ({"full": "; step replayed from a captured HIP graph" + (" (RCCL all-reduces captured)" if collectives else ""),
+                                       "piecewise": "; step replayed from one HIP graph per backward segment, RCCL collectives issued eagerly between the replays",
+                                       "off": "; eager launches"}[graph_mode])
                                    + graph_note + "; random-init weights, gates alpha=0.5",
                        "global_batch": args.batch * world, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                        "trainable_params": n_trainable,
@@ -596,7 +699,8 @@ def main():
                        # ("the loss printed by the bench"); `loss` = after the instrumented eager steps that follow
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
-                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
+                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives),
+                       "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,
         }
@@ -606,21 +710,25 @@ def main():
                     "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 4), "launches": v["launches"],
                     "avg_launch_us": round(v["ms"] / v["launches"] * 1e3, 2), "avg_launch_mb": round(v["bytes"] / v["launches"] / 1e6, 2)}
                 for k, v in attn.items()}
+        if bucket_timeline is not None:
+            result["bucket_timeline"] = bucket_timeline
         if world == 1 and args.caption_tokens > 0:
             result["caption"] = caption_leg(args, model, batch, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
-        want_companions = args.companions == "on" or (args.companions == "auto" and args.config == "B" and args.backbone_tweaks == "on"
-                                                      and args.optimizer == "fused" and not args.no_optimizer)
+        want_companions = args.companions == "on" or (args.companions == "auto" and args.config == "B" and args.backbone_tweaks == "off"
+                                                      and args.optimizer == "fused" and not args.no_optimizer and not collectives)
         if world == 1 and want_companions:
             # free this process's model and graph pools first: the children build their own copies on the same GPU
             batch = model = opt = step = graphed = reducer = params = loss = loss_first = loss_last = None      # (closures keep the names alive)
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            result["stock_backbones"] = dict(run_companion(args, ["--backbone-tweaks", "off", "--optimizer", args.optimizer]),
-                                             what="same workload and fusion path, UNTOUCHED Hugging Face CLIP / LM modules and hipBLASLt's default heuristic "
-                                                  "(no op substitutions, no tuning file): the north star's 'backbones left on stock PyTorch-ROCm' figure")
+            result["with_backbone_op_substitutions"] = dict(
+                run_companion(args, ["--backbone-tweaks", "on", "--optimizer", args.optimizer]),
+                what="same workload and fusion path, plus three result-identical op substitutions INSIDE the frozen backbones (ViT patch convolution as a "
+                     "matmul, CLIP's QuickGELU in one pass, HF's 8-kernel NewGELU -> torch's fused tanh GELU; tests/test_hip_backbones.py) and the pre-tuned "
+                     "hipBLASLt solution file for their GEMMs - NOT the north star's configuration (backbones on stock PyTorch-ROCm), which is the headline")
             result["fp32_master_optimizer"] = dict(run_companion(args, ["--optimizer", "fused-master"]),
                                                    what="same as the headline run but AdamW keeps fp32 master weights and fp32 moments for the bf16 parameters "
                                                         "(ff_adamw_step_mixed) - the reference's --fp16 recipe, training/train.sh:24")

@@ -9,7 +9,6 @@ resampler and the gated cross-attention blocks hooked into the LM layer loop run
 from __future__ import annotations
 
 import contextlib
-import os
 import logging
 from abc import ABC, abstractmethod
 from typing import Any, Dict, List, Optional
@@ -409,6 +408,10 @@ class FlamingoModel(PreTrainedModel):
 
     config_class = FlamingoConfig
     _LANGUAGE_MODEL_VERSIONS = {"gpt2": FlamingoGPT2, "facebook/opt": FlamingoOPT}
+    # greedy decoding of a GPT-2-backed model on the GPU: fixed-shape decode steps (static_decode), replayed from a HIP graph (decode_graph);
+    # plain attributes, settable per model - no environment variable
+    static_decode = True
+    decode_graph = True
     _keys_to_ignore_on_load_missing = [r"flamingo.vision_encoder"]
 
     def __init__(self, config: FlamingoConfig, model_class: Optional[type] = None):
@@ -546,7 +549,7 @@ class FlamingoModel(PreTrainedModel):
                 raise ValueError("beam search with sampling is not implemented")
             return self._beam_search(ids, ml, am, pixel_values, visual_features, max_length, num_beams, eos_token_id, pad, early_stopping, length_penalty)
         if static_decode is None:       # greedy decoding of a GPT-2-backed model on the GPU: fixed-shape decode steps, replayed from a HIP graph
-            static_decode = ids.is_cuda and os.environ.get("FF_STATIC_DECODE", "1") == "1"
+            static_decode = ids.is_cuda and self.static_decode
         if static_decode and not do_sample and isinstance(self.flamingo, FlamingoGPT2) and ids.shape[1] + 1 < max_length:
             return self._static_greedy(ids, ml, am, pixel_values, visual_features, max_length, eos_token_id, pad)
         finished = torch.zeros(ids.shape[0], dtype=torch.bool, device=ids.device)
@@ -575,7 +578,7 @@ class FlamingoModel(PreTrainedModel):
         first caption batch of a shape pays for the capture.  a session whose model's parameters were re-allocated since (model.to(), ShardedAdamW) is rebuilt; reset_decode_sessions() drops them all."""
         b = ids.shape[0]
         if graph is None:
-            graph = ids.is_cuda and not self.training and os.environ.get("FF_DECODE_GRAPH", "1") == "1"
+            graph = ids.is_cuda and not self.training and self.decode_graph
         sessions = _DECODE_SESSIONS.setdefault(self, {})
         n_media = int(ml.sum(-1).max()) if visual_features is None and pixel_values is None else \
             (visual_features.shape[1] if visual_features is not None else (pixel_values.shape[1] if pixel_values.ndim >= 5 else pixel_values.shape[0]))

@@ -64,3 +64,34 @@ def xattn_params(dim, dim_visual, heads, dim_head, ff_mult, alpha_attn=0.5, alph
         "ffw.1.weight": det((ff_mult * dim, dim), tag + "1", (3.0 / dim) ** 0.5),
         "ffw.3.weight": det((dim, ff_mult * dim), tag + "3", (3.0 / (ff_mult * dim)) ** 0.5),
     }
+
+
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """float32 -> nearest bfloat16 (ties to even), returned as float32: values a bf16 kernel and a float64 reference both hold exactly."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+def det_state(name: str, shape, tag: str = "h64") -> np.ndarray:
+    """A whole model's state_dict by NAME (the drop-in keeps the reference's parameter names, so both sides can call this): closed-form,
+    bf16-representable values with magnitudes that keep activations O(1).  Used for the full-model fixture whose weights are not stored."""
+    shape = tuple(int(s) for s in shape)
+    leaf = name.split(".")[-1]
+    if "alpha_attn" in name:
+        return np.array([0.5 - 0.125 * (zlib.crc32(name.encode()) % 3)], np.float32)
+    if "alpha_ffw" in name:
+        return np.array([-0.375 + 0.25 * (zlib.crc32(name.encode()) % 3)], np.float32)
+    if len(shape) == 0:
+        return bf16_round(det((1,), tag + name, 0.5)).reshape(())
+    if len(shape) == 1:
+        norm_like = any(k in name for k in ("norm", "ln_", "layer_norm", "layrnorm")) or name.endswith("ffw.0.weight") or ".1.0." in name
+        if leaf == "weight" and norm_like:
+            return bf16_round(det(shape, tag + name, 0.2, 1.0))
+        return bf16_round(det(shape, tag + name, 0.1 if leaf != "class_embedding" else 0.5))
+    if leaf in ("latents", "time_pos_emb"):
+        return bf16_round(det(shape, tag + name, 0.5))
+    if "embed" in name or name.endswith(("wte.weight", "wpe.weight")):          # token / position embeddings (the token embedding is also the tied lm_head)
+        return bf16_round(det(shape, tag + name, 0.1))
+    fan = int(np.prod(shape[1:])) if len(shape) > 2 else max(shape)
+    return bf16_round(det(shape, tag + name, (3.0 / fan) ** 0.5))

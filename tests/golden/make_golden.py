@@ -60,6 +60,41 @@ def grads_of(module):
     return {k: p.grad.detach().numpy().copy() for k, p in module.named_parameters()}
 
 
+class GateProbe:
+    """Natural scale of the two scalar gate gradients of a GatedCrossAttentionBlock, d alpha = (1 - tanh^2 alpha) * sum(d branch_sum .* branch)
+    (gated_cross_attention.py:180,182): || d branch_sum .* branch ||_2 * (1 - tanh^2 alpha) - the noise floor of such a sum of rounded
+    products.  Stored next to the gradients as `gs.<parameter name>` so that the parity tests can hold a scalar gate gradient to
+    tol * (scale + |reference|) (tests/util.py: gate_grad_ok) instead of an absolute bound.  Reads the reference module's own tensors:
+    forward hooks keep the branch outputs (.attn, .ffw) and the two residual sums (the input of .ffw, the block's output) with their gradients."""
+
+    def __init__(self, named_blocks):
+        self.items = []
+        for prefix, blk in named_blocks:
+            rec = {"prefix": prefix, "blk": blk}
+            blk.attn.register_forward_hook(lambda mod, inp, out, rec=rec: rec.__setitem__("attn", out[0].detach()))
+            blk.ffw.register_forward_pre_hook(lambda mod, inp, rec=rec: self._keep(rec, "y1", inp[0]))      # y1 = y + tanh(alpha_attn) * attn_out
+            blk.ffw.register_forward_hook(lambda mod, inp, out, rec=rec: rec.__setitem__("ffw", out.detach()))
+            blk.register_forward_hook(lambda mod, inp, out, rec=rec: self._keep(rec, "y2", out[0]))          # y2 = y1 + tanh(alpha_ffw) * ffw_out
+            self.items.append(rec)
+
+    @staticmethod
+    def _keep(rec, key, t):
+        if t.requires_grad:
+            t.retain_grad()
+            rec[key] = t
+
+    def scales(self):
+        out = {}
+        for rec in self.items:
+            for branch, total, pname in (("attn", "y1", "alpha_attn"), ("ffw", "y2", "alpha_ffw")):
+                b, s = rec.get(branch), rec.get(total)
+                if b is None or s is None or s.grad is None:
+                    continue
+                th = float(torch.tanh(getattr(rec["blk"], pname).detach()))
+                out["gs." + rec["prefix"] + pname] = np.array(float((s.grad * b).norm()) * (1.0 - th * th))
+        return out
+
+
 def resampler_case(mods, name, *, dim, depth, heads, dim_head, q, nte, ff_mult, act, xshape, store_params):
     R = mods["perceiver_resampler"].PerceiverResampler
     m = R(dim=dim, depth=depth, dim_head=dim_head, heads=heads, num_latents=q, num_time_embeds=nte,
@@ -95,12 +130,14 @@ def xattn_case(mods, name, *, dim, dv, heads, dim_head, n_visual, ff_mult, act, 
     y = t64(det((b, L, dim), name + "y", 1.0)).requires_grad_(True)
     vf = t64(det((b, N, n_visual, dv), name + "vf", 1.0)).requires_grad_(True)
     mlt = torch.from_numpy(np.asarray(ml, dtype=np.int64))
+    probe = GateProbe([("", m)])
     out_y, kv = m(y, vf, mlt, previous_kv=None, output_kv=True)
     dy = t64(det((b, L, dim), name + "dy", 1.0))
     out_y.backward(dy)
     out = {"y_out": out_y.detach().numpy(), "k": kv[0].detach().numpy(), "v": kv[1].detach().numpy(),
            "dy_in": y.grad.numpy(), "dvf": vf.grad.numpy()}
     out.update({"g." + k: v for k, v in grads_of(m).items()})
+    out.update(probe.scales())
     # cached-decode path (gated_cross_attention.py:88-92,102-104): last token only, K/V reused
     with torch.no_grad():
         y_last = y[:, -1:].detach()
@@ -194,6 +231,7 @@ def full_model_case():
             hook.xattn_block.alpha_attn.fill_(0.5 - 0.2 * i)
             hook.xattn_block.alpha_ffw.fill_(-0.3 + 0.25 * i)
     model.train()
+    probe = GateProbe([(n + ".", m) for n, m in model.named_modules() if type(m).__name__ == "GatedCrossAttentionBlock"])
     b, L, N = 2, 10, 2
     px = t64(det((b, N, 3, 32, 32), "full-px"))
     ids = torch.from_numpy((np.abs(det((b, L), "full-ids")) * 96).astype(np.int64) % 96)
@@ -203,6 +241,7 @@ def full_model_case():
     out.loss.backward()
     sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
     grads = {k: p.grad.numpy() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    gate_scales = probe.scales()
     # cached two-step decode at the forward level: step 1 full prompt with use_cache, step 2 one more token
     model.eval()
     with torch.no_grad():
@@ -214,6 +253,7 @@ def full_model_case():
     save.update({"g." + k: v for k, v in grads.items()})
     save.update(px=px.numpy(), ids=ids.numpy(), ml=ml.numpy(), logits=out.logits.detach().numpy(), loss=np.array(out.loss.item()),
                 eval_logits=full.logits.numpy(), step2_logits=o2.logits.numpy())
+    save.update(gate_scales)
     np.savez_compressed(os.path.join(HERE, "full_opt_tiny.npz"), **save)
     print("full_opt_tiny: logits", tuple(out.logits.shape), "loss", out.loss.item(), "trainable grads", len(grads),
           "transformers", transformers.__version__)
@@ -272,6 +312,7 @@ def full_model_case_gpt2():
             hook.xattn_block.alpha_ffw.fill_(-0.375 + 0.25 * i)
     model = model.float().double()
     model.train()
+    probe = GateProbe([(n + ".", m) for n, m in model.named_modules() if type(m).__name__ == "GatedCrossAttentionBlock"])
     b, L, N = 2, 32, 1
     px = t64(det((b, N, 3, 112, 112), "gpt2-px"))
     ids = torch.from_numpy((np.abs(det((b, L), "gpt2-ids")) * 96).astype(np.int64) % 96)
@@ -283,6 +324,7 @@ def full_model_case_gpt2():
     for k, v in model.state_dict().items():
         assert np.array_equal(sd[k].astype(np.float64), v.detach().numpy()), k
     grads = {k: p.grad.numpy() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    gate_scales = probe.scales()
     model.eval()
     with torch.no_grad():
         o1 = model(input_ids=ids[:, :-1], attention_mask=am[:, :-1], media_locations=ml[:, :-1], pixel_values=px, use_cache=True)
@@ -308,10 +350,71 @@ def full_model_case_gpt2():
     save.update(ids=ids.numpy(), ml=ml.numpy(), ml4=ml4.numpy(), logits=out.logits.detach().numpy(), loss=np.array(out.loss.item()),
                 eval_logits=full.logits.numpy(), step2_logits=o2.logits.numpy(), vf=vf.numpy(), video_logits=vid.logits.numpy(),
                 vf4=vf4.numpy(), four_d_logits=four.logits.numpy())
+    save.update(gate_scales)
     np.savez_compressed(os.path.join(HERE, "full_gpt2_tiny.npz"), **save)
     n_rs = sum(p.numel() for p in model.flamingo.resampler.parameters())
     print("full_gpt2_tiny: logits", tuple(out.logits.shape), "loss", out.loss.item(), "trainable grads", len(grads),
           "resampler params", n_rs, "transformers", transformers.__version__)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Full model at the FUSED bf16 kernels' geometry: 64-wide heads in the gated blocks and the resampler, LM width 256,
+# 64 latents, one image + 32 tokens per sequence - small enough to store, large enough that the drop-in takes the resident fused kernels,
+# the hoisted K / V projection, the deferred grouped weight gradients and the fused loss / optimizer in bfloat16.  TWO training steps of the
+# reference (torch.optim.AdamW in float64): logits, loss and every trainable gradient of both.  No weights are stored: every parameter is
+# detgen.det_state(name, shape) - closed-form, bf16-representable - on both sides; so are the pixels.
+# ---------------------------------------------------------------------------------------------------
+H64 = dict(
+    lm_kw=dict(n_embd=256, n_layer=2, n_head=4, n_inner=256, vocab_size=96, n_positions=64, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0),
+    clip_kw=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64, patch_size=16, image_size=64),
+    flamingo_kw=dict(lm="gpt2-h64", clip_model_type="openai/clip-vit-h64", dim=256, dim_visual=64, xattn_every=1,
+                     xattn_dim_head=64, xattn_heads=2, xattn_ff_mult=1, xattn_act="gelu", resampler_depth=1,
+                     resampler_dim_head=64, resampler_heads=2, resampler_num_latents=64, resampler_num_time_embeds=4,
+                     resampler_ff_mult=2, resampler_act="gelu"),
+    # (eps at the scale of the gradients: with the default 1e-8 the first AdamW steps are sign updates, which no finite-precision gradient can
+    # reproduce element by element near zero; 1e-3 makes the update a smooth function of the gradient, so parameters can be compared)
+    adamw=dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-3, weight_decay=1e-2),
+)
+
+
+def full_model_case_h64():
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel, GPT2Config, GPT2LMHeadModel
+    from detgen import bf16_round, det_state
+    CLIPVisionModel.from_pretrained = classmethod(lambda cls, name, **kw: CLIPVisionModel(CLIPVisionConfig(**H64["clip_kw"])))
+    GPT2LMHeadModel.from_pretrained = classmethod(lambda cls, name, **kw: GPT2LMHeadModel(GPT2Config(**H64["lm_kw"])))
+    import flamingo_mini as ref        # (full_model_case_gpt2 ran before: the package is imported and ModifiedLMBlock.forward is the tolerant one)
+    cfg = ref.FlamingoConfig(**H64["flamingo_kw"])
+    model = ref.FlamingoModel(cfg).double()
+    assert type(model.flamingo).__name__ == "FlamingoGPT2"
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point and "lm_head" not in k:        # (lm_head.weight is the token embedding: tied)
+                v.copy_(t64(det_state(k, tuple(v.shape))))
+        assert model.flamingo.lm_head.weight.data_ptr() == model.flamingo.lm.wte.weight.data_ptr()
+    model.train()
+    probe = GateProbe([(n + ".", m) for n, m in model.named_modules() if type(m).__name__ == "GatedCrossAttentionBlock"])
+    b, L = 4, 32
+    px = t64(bf16_round(det((b, 1, 3, 64, 64), "h64-px")))
+    ids = torch.from_numpy((np.abs(det((b, L), "h64-ids")) * 96).astype(np.int64) % 96)
+    ml = torch.zeros(b, L, dtype=torch.long); ml[:, 0] = 1; ml[1, 0] = 0; ml[1, 5] = 1; ml[3, 20] = 1   # row 1: leading t = 0 tokens; row 3: a 2nd tag with 1 image (uniform rows)
+    am = torch.ones(b, L, dtype=torch.long)
+    opt = torch.optim.AdamW([p for p in model.parameters_trainable()], **H64["adamw"])
+    save = dict(ids=ids.numpy(), ml=ml.numpy())
+    for step in (1, 2):
+        opt.zero_grad(set_to_none=True)
+        out = model(input_ids=ids, attention_mask=am, media_locations=ml, pixel_values=px, labels=ids)
+        out.loss.backward()
+        grads = {k: p.grad.numpy() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+        save[f"logits{step}"] = out.logits.detach().numpy().astype(np.float32)
+        save[f"loss{step}"] = np.array(out.loss.item())
+        gdt = np.float32 if step == 1 else np.float16          # step 2 is compared in bfloat16 only (weights have left the bf16 grid by then)
+        save.update({f"g{step}." + k: v.astype(gdt) for k, v in grads.items()})
+        save.update({f"gs{step}." + k[3:]: v for k, v in probe.scales().items()})
+        opt.step()
+        print(f"full_gpt2_h64 step {step}: loss", out.loss.item(), "trainable grads", len(grads))
+    np.savez_compressed(os.path.join(HERE, "full_gpt2_h64.npz"), **save)
+    print("full_gpt2_h64: logits", tuple(out.logits.shape), "transformers", transformers.__version__)
 
 
 def param_count_pins():
@@ -326,4 +429,5 @@ def param_count_pins():
 
 if __name__ == "__main__" and os.environ.get("FLAMINGO_GOLDEN_FULL", "1") == "1":
     full_model_case_gpt2()
+    full_model_case_h64()
     param_count_pins()

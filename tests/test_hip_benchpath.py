@@ -79,7 +79,8 @@ def check_chain_against_oracle(blocks, hs, y, vf, ml_np, g, dtype, act="gelu", c
         for k, prm in m.named_parameters():
             assert prm.grad is not None and bool(torch.isfinite(prm.grad.float()).all()), (i, k)
             if g_r[k].size == 1:
-                # (|| a .* b ||_2: the noise floor of a sum of rounded products; |sum| itself: relative errors that are common to all terms)
+                # the rule of util.gate_grad_ok (|| a .* b ||_2: the noise floor of a sum of rounded products; |sum| itself: relative errors
+                # that are common to all terms), written as a ratio so that the worst case can be reported
                 note(f"block{i}.{k}", abs(float(prm.grad) - float(g_r[k])), t["grad"] * (gate_scale[k] + abs(float(g_r[k])) + 1e-30))
             else:
                 note(f"block{i}.{k}", rel(prm.grad, g_r[k]), t["grad"])

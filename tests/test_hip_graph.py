@@ -198,3 +198,51 @@ def test_capture_after_an_eager_forward_of_the_same_model(mode, expect):
     assert ("refused:" in res.stdout) == (expect == 3)
     if expect == 0:
         assert "captured; replays:" in res.stdout
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(one_rank_rccl, dtype):
+    """graphs.PiecewiseGraphedTrainStep on the full drop-in model (h64 fixture geometry: fused kernels, hoisted K / V, deferred weight
+    gradients) with the gradient exchange going through RCCL on a 1-rank group: forward | one backward sub-graph per gated layer |
+    resampler backward | optimizer, all-reduces issued eagerly between the replays.  Three arms from the same initial state - eager
+    launches, the whole step captured with its collectives, the piecewise replay - must produce the same losses and parameters."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_model_plumbing import H64, build_h64
+    from flamingo_mini_amd import FusedAdamW, GraphedTrainStep
+    from flamingo_mini_amd.data_parallel import GradientAllReducer
+    from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
+    base, z, batch = build_h64(dtype, "cuda")
+    arms = {"eager": base, "full": copy.deepcopy(base), "piecewise": copy.deepcopy(base)}
+    n_steps, losses, finals = 4, {}, {}
+    for name, model in arms.items():
+        params = [p for p in model.parameters_trainable()]
+        opt = FusedAdamW(params, capturable=name != "eager", **H64["adamw"])
+        reducer = GradientAllReducer(model, force_collectives=True)
+        assert reducer.active and all(h.xattn_block.wgrad_group == 4 for h in model.flamingo.get_modified_layers())
+        if name == "eager":
+            out = []
+            for _ in range(n_steps):
+                model.zero_grad(set_to_none=True)
+                loss = model(**batch).loss
+                loss.backward()
+                reducer.finish()
+                opt.step()
+                out.append(float(loss))
+        else:
+            cls = GraphedTrainStep if name == "full" else PiecewiseGraphedTrainStep
+            kw = {} if name == "full" else {"segment_layers": 1}
+            step = cls(model, opt, batch, warmup=1, reducer=reducer, **kw)        # (the constructor's warm-up is training step 1)
+            if name == "piecewise":
+                assert len(step.graphs) == 1 + 3 and sum(len(b) for b in step.segment_buckets) >= 4      # forward + 3 backward segments; blocks, to_kv, resampler, embedding
+            out = [None] + [float(step()) for _ in range(n_steps - 1)]
+        torch.cuda.synchronize()
+        reducer.close()
+        losses[name] = out
+        finals[name] = {k: p.detach().float().clone() for k, p in model.named_parameters() if p.requires_grad}
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    for name in ("full", "piecewise"):
+        for a, b in zip(losses["eager"][1:], losses[name][1:]):
+            assert abs(a - b) <= tol * max(1.0, abs(a)), (name, losses)
+        for k, v in finals["eager"].items():
+            assert rel(finals[name][k], v) < (1e-4 if dtype == torch.float32 else 3e-2), (name, k)

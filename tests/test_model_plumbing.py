@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import GOLDEN, rel
+from util import GOLDEN, gate_grad_ok, rel
 
 TINY = dict(
     lm_kw=dict(hidden_size=32, num_hidden_layers=3, num_attention_heads=2, ffn_dim=64, word_embed_proj_dim=32,
@@ -69,7 +69,7 @@ def run_checks(model, z, device, dtype, tol_out, tol_grad):
     for k in gkeys:
         ref = z["g." + k]
         if ref.size == 1:
-            assert abs(float(named[k].grad) - float(ref)) < tol_grad * max(1.0, abs(float(ref))) * 5, k
+            assert gate_grad_ok(named[k].grad.detach().double().cpu().numpy(), ref, tol_grad, z["gs." + k]), (k, float(named[k].grad), float(ref.reshape(-1)[0]))
         else:
             assert rel(named[k].grad, ref) < tol_grad, k
     assert {"flamingo." + k for k in model.state_dict_trainable()} == trainable   # keys are relative to .flamingo, as in the reference
@@ -142,7 +142,8 @@ def test_full_model_fp32_on_hip_matches_reference(hoist_kv, family):
 def test_full_gpt2_model_bf16_on_hip():
     """The benchmark dtype through the GPT-2 wrapper (the LM family of BASELINE configs A and B).  Everything - stock CLIP / GPT-2
     included - runs in bf16 here, so the tolerance is a bf16 one: 1.5e-2 relative L2 on logits (measured 8.9e-3; the reference's own
-    bf16-vs-fp32 drift is 0.3-0.7e-2 per module), 2.5e-2 on gradients (measured worst 1.5e-2), 25 % on the scalar gates."""
+    bf16-vs-fp32 drift is 0.3-0.7e-2 per module), 2.5e-2 on gradients (measured worst 1.5e-2), the scalar gates by
+    util.gate_grad_ok at the same 2.5e-2."""
     model, z = build(torch.bfloat16, "cuda", "gpt2")
     px = torch.from_numpy(z["px"]).to(device="cuda", dtype=torch.bfloat16)
     ids, ml = torch.from_numpy(z["ids"]).cuda(), torch.from_numpy(z["ml"]).cuda()
@@ -156,7 +157,7 @@ def test_full_gpt2_model_bf16_on_hip():
     for k in [k[2:] for k in z["files"] if k.startswith("g.")]:
         ref = z["g." + k]
         if ref.size == 1:
-            assert abs(float(named[k].grad) - float(ref)) < 0.25 * max(abs(float(ref)), 0.05), (k, float(named[k].grad), float(ref))
+            assert gate_grad_ok(named[k].grad.float().cpu().numpy(), ref, 2.5e-2, z["gs." + k]), (k, float(named[k].grad), float(ref.reshape(-1)[0]))
         else:
             worst[k] = rel(named[k].grad, ref)
     bad = {k: v for k, v in worst.items() if not v < 2.5e-2}      # measured worst 1.5e-2
@@ -294,3 +295,137 @@ def test_forward_leaves_no_conditioning_on_the_hooks():
         _refuse_live_autograd_graphs(model)                # nothing else holds on to the graph
     finally:
         oracle_backend.uninstall()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Full model at the fused bf16 kernels' geometry, two training steps (tests/golden/full_gpt2_h64.npz)
+# ---------------------------------------------------------------------------------------------------
+H64 = dict(
+    lm_kw=dict(n_embd=256, n_layer=2, n_head=4, n_inner=256, vocab_size=96, n_positions=64, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0),
+    clip_kw=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64, patch_size=16, image_size=64),
+    flamingo_kw=dict(lm="gpt2-h64", clip_model_type="openai/clip-vit-h64", dim=256, dim_visual=64, xattn_every=1,
+                     xattn_dim_head=64, xattn_heads=2, xattn_ff_mult=1, xattn_act="gelu", resampler_depth=1,
+                     resampler_dim_head=64, resampler_heads=2, resampler_num_latents=64, resampler_num_time_embeds=4,
+                     resampler_ff_mult=2, resampler_act="gelu"),
+    adamw=dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-3, weight_decay=1e-2),
+)
+
+
+def build_h64(dtype, device):
+    """The drop-in model of the h64 fixture: every parameter is detgen.det_state(name, shape) - the reference-side generator wrote the same
+    closed-form, bf16-representable values into the reference model by the same names - and the pixels are regenerated the same way."""
+    from flamingo_mini_amd import FlamingoConfig, FlamingoModel
+    from detgen import bf16_round, det, det_state
+    z = dict(np.load(os.path.join(GOLDEN, "full_gpt2_h64.npz")))
+    cfg = FlamingoConfig(**H64["flamingo_kw"], random_init_backbones=True, backbone_overrides={"lm": H64["lm_kw"], "clip": H64["clip_kw"]})
+    model = FlamingoModel(cfg).double()
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point and "lm_head" not in k:
+                v.copy_(torch.from_numpy(det_state(k, tuple(v.shape))).double())
+    assert model.flamingo.lm_head.weight.data_ptr() == model.flamingo.lm.wte.weight.data_ptr()
+    ids, ml = torch.from_numpy(z["ids"]), torch.from_numpy(z["ml"])
+    px = torch.from_numpy(bf16_round(det((ids.shape[0], 1, 3, 64, 64), "h64-px"))).double()
+    batch = dict(input_ids=ids.to(device), attention_mask=torch.ones_like(ids).to(device), media_locations=ml.to(device),
+                 pixel_values=px.to(device=device, dtype=dtype), labels=ids.to(device))
+    return model.to(device=device, dtype=dtype).train(), z, batch
+
+
+def _h64_grad_keys(z, step):
+    return [k[3:] for k in z if k.startswith(f"g{step}.")]
+
+
+def test_h64_two_training_steps_cpu_with_oracle_checker():
+    """The fixture against itself through the drop-in's plumbing on the host (fused entry points on the float64 oracle): both training
+    steps of the reference - logits, loss, all 39 trainable gradients, with torch.optim.AdamW in between."""
+    import oracle_backend
+    oracle_backend.install()
+    try:
+        model, z, batch = build_h64(torch.float64, "cpu")
+        named = dict(model.named_parameters())
+        assert set(_h64_grad_keys(z, 1)) == {k for k, p in named.items() if p.requires_grad}
+        opt = torch.optim.AdamW([p for p in model.parameters_trainable()], **H64["adamw"])
+        for step, tol in ((1, 2e-6), (2, 2e-3)):        # (gradients of step 1 are stored in float32, those of step 2 in float16)
+            opt.zero_grad(set_to_none=True)
+            out = model(**batch)
+            out.loss.backward()
+            assert rel(out.logits, z[f"logits{step}"]) < 2e-6 and abs(float(out.loss) - float(z[f"loss{step}"])) < 1e-9
+            for k in _h64_grad_keys(z, step):
+                ref = z[f"g{step}." + k].astype(np.float64)
+                if ref.size == 1:
+                    assert gate_grad_ok(named[k].grad.numpy(), ref, tol, z[f"gs{step}." + k]), (step, k)
+                else:
+                    assert rel(named[k].grad, ref) < tol, (step, k, rel(named[k].grad, ref))
+            opt.step()
+    finally:
+        oracle_backend.uninstall()
+
+
+def _np_adamw_step(p, g, m, v, step, lr, betas, eps, weight_decay):
+    """torch.optim.AdamW's rule in float64 numpy."""
+    b1, b2 = betas
+    p = p * (1.0 - lr * weight_decay)
+    m = b1 * m + (1.0 - b1) * g
+    v = b2 * v + (1.0 - b2) * g * g
+    denom = np.sqrt(v) / np.sqrt(1.0 - b2 ** step) + eps
+    return p - lr / (1.0 - b1 ** step) * m / denom, m, v
+
+
+@pytest.mark.gpu
+def test_h64_bf16_two_steps_through_graphed_train_step():
+    """End to end in the benchmark's own configuration: bfloat16, FlamingoBaseModel.forward with the hoisted K / V
+    projection, the resident fused LN -> q -> attention kernels (64-wide heads, 32 tokens, 64 keys per sample), deferred grouped weight
+    gradients, ff_shifted_ce, FusedAdamW with fp32 masters - captured by GraphedTrainStep and REPLAYED for two training steps, against the
+    reference's two steps: logits, loss and every trainable gradient of both (bf16 tolerances of tests/util.py; x2 in step 2, whose
+    weights have left the bf16 grid), and the fp32 master weights after step 1 against float64 AdamW on the REFERENCE's gradients."""
+    from util import TOL
+    from flamingo_mini_amd import FusedAdamW, GraphedTrainStep
+    dt = torch.bfloat16
+    model, z, batch = build_h64(dt, "cuda")
+    assert model.flamingo.hoist_kv
+    named = {k: p for k, p in model.named_parameters() if p.requires_grad}
+    assert set(_h64_grad_keys(z, 1)) == set(named)
+    params = list(named.values())
+    p0 = [p.detach().clone() for p in params]
+    opt = FusedAdamW(params, capturable=True, master_dtype=torch.float32, **H64["adamw"])
+    stash = {}
+    step = GraphedTrainStep(model, opt, batch, warmup=1, loss_fn=lambda out: (stash.__setitem__("logits", out.logits), out.loss)[1])
+    # the constructor ran one eager training step (and captured a second): rewind parameters, masters, moments and step counters
+    with torch.no_grad():
+        for p, q in zip(params, p0):
+            p.copy_(q)
+            st = opt.state[p]
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["master"].copy_(q.float())
+        for g in opt.param_groups:
+            for c in g["_step_dev"].values():
+                c.zero_()
+    t = TOL[dt]
+    m_state = {k: (np.zeros(p.shape), np.zeros(p.shape)) for k, p in named.items()}
+    report = {}
+    for s in (1, 2):
+        loss = float(step())
+        torch.cuda.synchronize()
+        mul = 1.0 if s == 1 else 2.0
+        report[f"logits{s}"] = rel(stash["logits"], z[f"logits{s}"])
+        assert report[f"logits{s}"] < 1.5e-2 * mul, report          # the whole model in bf16, stock CLIP / GPT-2 included (cf. test_full_gpt2_model_bf16_on_hip)
+        assert abs(loss - float(z[f"loss{s}"])) < 3e-2 * mul, (loss, float(z[f"loss{s}"]))
+        worst = {}
+        for k, p in named.items():
+            ref = z[f"g{s}." + k].astype(np.float64)
+            if ref.size == 1:
+                assert gate_grad_ok(p.grad.float().cpu().numpy(), ref, 2.5e-2 * mul, z[f"gs{s}." + k]), (s, k, float(p.grad), float(ref.reshape(-1)[0]))
+            else:
+                worst[k] = rel(p.grad, ref)
+        report[f"worst_grad{s}"] = max(worst.items(), key=lambda kv: kv[1])
+        bad = {k: v for k, v in worst.items() if not v < 2.5e-2 * mul}
+        assert not bad, (s, bad)
+        if s == 1:      # parameters after the step: the fp32 masters against float64 AdamW on the reference's gradients, measured on the UPDATE
+            wd = {}
+            for (k, p), q in zip(named.items(), p0):
+                want, m_, v_ = _np_adamw_step(q.double().cpu().numpy(), z["g1." + k].astype(np.float64).reshape(q.shape), *m_state[k], 1, **H64["adamw"])
+                got = opt.state[p]["master"].double().cpu().numpy()
+                wd[k] = float(np.linalg.norm((got - q.double().cpu().numpy()) - (want - q.double().cpu().numpy())) /
+                              max(np.linalg.norm(want - q.double().cpu().numpy()), 1e-30))
+            report["worst_update1"] = max(wd.items(), key=lambda kv: kv[1])
+            assert max(wd.values()) < 0.1, report             # the update is lr * g / (|g| + eps): a smooth function of the gradient at eps = 1e-3
+    print("h64 bf16 two-step report:", report)

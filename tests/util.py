@@ -16,6 +16,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = {torch.float32: dict(out=5e-6, grad=1e-5), torch.bfloat16: dict(out=8e-3, grad=1.2e-2)}
 
 
+def gate_grad_ok(got, ref, tol, scale) -> bool:
+    """THE rule for the scalar tanh-gate gradients (alpha_attn, alpha_ffw), used by every test that checks one:
+            |got - ref| <= tol * (scale + |ref|)
+    A gate gradient is a dot product over all b * L * dim elements, (1 - tanh^2 alpha) * sum(d branch_sum .* branch): `scale` is the
+    natural size of such a sum of rounded products, (1 - tanh^2 alpha) * || d branch_sum .* branch ||_2 (what it would be if the terms
+    did not cancel), |ref| covers relative errors common to all terms.  The golden fixtures carry the scale next to every gate gradient
+    (`gs.<name>`, tests/golden/make_golden.py: GateProbe); oracle-based tests compute it from the oracle's cache."""
+    return abs(float(np.asarray(got, np.float64).reshape(-1)[0]) - float(np.asarray(ref, np.float64).reshape(-1)[0])) <= \
+        tol * (float(np.asarray(scale).reshape(-1)[0]) + abs(float(np.asarray(ref, np.float64).reshape(-1)[0])))
+
+
 def rel(a, b) -> float:
     a = np.asarray(a.detach().double().cpu().numpy() if torch.is_tensor(a) else a, np.float64)
     b = np.asarray(b.detach().double().cpu().numpy() if torch.is_tensor(b) else b, np.float64)

@@ -3,7 +3,7 @@
 
 Input: the kernel trace of eager training steps run with the data-parallel launch structure (weight-gradient groups of 4 blocks, one
 K / V projection call per 4 layers):
-    cd /tmp && FF_WGRAD_GROUP=4 FF_KV_GROUP=4 rocprofv3 --kernel-trace --output-format csv -d <dir> -- \
+    cd /tmp && rocprofv3 --kernel-trace --output-format csv -d <dir> -- \
         python bench.py --graph off --steps 2 --warmup 2 --no-cpu-baseline --caption-tokens 0 --profile-steps 0 --companions off
     python tools/bucket_timeline.py <dir>/**/*kernel_trace.csv
 The last complete step of the trace is taken.  Bucket-final events: the end of every cluster of weight-gradient launches (both operands

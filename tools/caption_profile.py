@@ -1,24 +1,26 @@
 #!/usr/bin/env python
 """Only the caption leg of bench.py (cached greedy decoding of config B's model, batch 32, 32 new tokens), for rocprofv3:
     cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python tools/caption_profile.py [--eager]
-`--eager`: FF_DECODE_GRAPH=0 (every decode step launched kernel by kernel - what a kernel trace needs to see per-step launches)."""
+`--eager`: model.decode_graph = False (every decode step launched kernel by kernel - what a kernel trace needs to see per-step launches);
+`--tweaks`: with the op substitutions inside the backbones and the tuning file (bench.py --backbone-tweaks on)."""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-if "--eager" in sys.argv:
-    os.environ["FF_DECODE_GRAPH"] = "0"
+eager, tweaks = "--eager" in sys.argv, "--tweaks" in sys.argv
 import torch
 import bench
 
-sys.argv = ["bench.py"]
+sys.argv = ["bench.py"] + (["--backbone-tweaks", "on"] if tweaks else [])
 a = bench.parse()
 dev = torch.device("cuda", 0)
-from flamingo_mini_amd.backbones import load_stock_gemm_tuning
-load_stock_gemm_tuning()
+if tweaks:
+    from flamingo_mini_amd.backbones import load_stock_gemm_tuning
+    load_stock_gemm_tuning()
 model, cfg = bench.build_model(a, dev, torch.bfloat16)
+model.decode_graph = not eager
 batch = bench.synthetic_batch(a, cfg, dev, torch.bfloat16, 0)
 model.eval()
 ids, ml, am = batch["input_ids"][:, :4], batch["media_locations"][:, :4], batch["attention_mask"][:, :4]

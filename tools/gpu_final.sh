@@ -15,7 +15,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof --
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_write.err
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq -- $B --steps 1 --warmup 1 --graph off > /dev/null 2> $out/pmc_sq.err
-( export FF_WGRAD_GROUP=4 FF_KV_GROUP=4; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/bucket -- $B --steps 2 --warmup 2 --graph off > /dev/null 2> $out/bucket.err )
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/bucket -- $B --wgrad-group 4 --kv-group 4 --steps 2 --warmup 2 --graph off > /dev/null 2> $out/bucket.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/capprof -- python $R/tools/caption_profile.py --eager > $out/caption_profile.txt 2> $out/caption_profile.err
 cd $R
 python tools/bucket_timeline.py $(find $out/bucket -name "*kernel_trace.csv" | head -1) > $out/bucket_timeline.txt 2>&1; head -20 $out/bucket_timeline.txt

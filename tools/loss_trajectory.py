@@ -17,7 +17,7 @@ def child(args):
     sys.path.insert(0, ROOT)
     import torch
     import bench
-    sys.argv = ["bench.py", "--config", args.config, "--backbone-tweaks", args.tweaks]
+    sys.argv = ["bench.py", "--config", args.config, "--backbone-tweaks", args.tweaks] + ([] if args.lm_dropout is None else ["--lm-dropout", str(args.lm_dropout)])
     a = bench.parse()
     device = torch.device("cuda", 0)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -48,7 +48,7 @@ def child(args):
     else:
         for _ in range(args.steps):
             losses.append(round(float(eager()), 4))
-    print(json.dumps(dict(tweaks=args.tweaks, graph=args.graph, dropout=os.environ.get("FLAMINGO_LM_DROPOUT", "default"), optimizer=args.optimizer,
+    print(json.dumps(dict(tweaks=args.tweaks, graph=args.graph, dropout=args.lm_dropout if args.lm_dropout is not None else "default", optimizer=args.optimizer,
                           losses=losses)), flush=True)
 
 
@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--graph", default="on")
     ap.add_argument("--optimizer", default="bf16", choices=["bf16", "master"])
     ap.add_argument("--modes", default="on:on,on:off,off:on,off:off", help="comma-separated tweaks:graph pairs")
+    ap.add_argument("--lm-dropout", type=float, default=None)
     ap.add_argument("--dropouts", default="default,0", help="LM dropout settings to run every mode with (default = the HF config's 0.1)")
     args = ap.parse_args()
     if args.child:
@@ -68,11 +69,9 @@ def main():
     for drop in args.dropouts.split(","):
         for mode in args.modes.split(","):
             tw, gr = mode.split(":")
-            env = dict(os.environ)
-            if drop != "default":
-                env["FLAMINGO_LM_DROPOUT"] = drop
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--steps", str(args.steps), "--config", args.config,
-                                "--tweaks", tw, "--graph", gr, "--optimizer", args.optimizer], env=env, capture_output=True, text=True)
+                                "--tweaks", tw, "--graph", gr, "--optimizer", args.optimizer] + ([] if drop == "default" else ["--lm-dropout", drop]),
+                               capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             print(line[-1] if line else json.dumps(dict(tweaks=tw, graph=gr, dropout=drop, error=r.stderr[-400:])), flush=True)
 

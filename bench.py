@@ -732,8 +732,13 @@ def main():
             result["fp32_master_optimizer"] = dict(run_companion(args, ["--optimizer", "fused-master"]),
                                                    what="same as the headline run but AdamW keeps fp32 master weights and fp32 moments for the bf16 parameters "
                                                         "(ff_adamw_step_mixed) - the reference's --fp16 recipe, training/train.sh:24")
+        try:        # RCCL prints its version banner through C stdio, which is block-buffered when stdout is a file: flush it so that the JSON
+            import ctypes       # line below really is the LAST line of the output
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

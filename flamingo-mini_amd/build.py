@@ -16,7 +16,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion.so")
-SOURCES = ["ff_api.hip", "ff_gemm.hip", "ff_rowwise.hip", "ff_attention.hip", "ff_xattn_fused.hip", "ff_optim.hip", "ff_loss.hip", "ff_elementwise.hip"]
+SOURCES = ["ff_api.hip", "ff_gemm.hip", "ff_rowwise.hip", "ff_attention.hip", "ff_xattn_fused.hip", "ff_optim.hip", "ff_loss.hip", "ff_elementwise.hip", "ff_decode.hip"]
 HEADERS = ["ff_common.h", "ff_internal.h", "ff_gemm_tiles.h", "ff_attention_core.h", os.path.join("..", "..", "include", "flamingo_fusion.h")]
 ARCH = "gfx950"
 # kernarg preload: leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+); kernels fall back to loads on old firmware

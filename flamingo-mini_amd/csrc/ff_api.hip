@@ -411,6 +411,7 @@ static size_t xa_ws_bytes(const XaDims& s) {
     g(s.d, s.ffi, M); g(s.ffi, s.d, M); g(s.d, s.inner, M); g(s.inner, s.d, M); g(2 * s.inner, s.dv, Mk); g(Mk, s.dv, 2 * s.inner);
     w = std::max(w, layernorm_bwd_workspace(M, s.d));
     w = std::max(w, gate_grad_workspace(M, s.d));
+    if (decode_ffw_supported(s.dt, M, s.d, s.ffi)) w = std::max(w, decode_ffw_workspace_bytes(s.d, s.ffi));
     return align_up(w) + align_up((size_t)s.b * s.H * s.L * 4);
 }
 static size_t xa_scratch_layout(const XaDims& s, void* base, size_t cap, bool bwd, XaScratch& o) {
@@ -500,6 +501,9 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     // y = y + tanh(alpha_attn) * to_out(o) (:126, :180)
     FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(0, pI).c(pd).problem(S.O, P[6], S.y1, S.attn_out, nullptr, y, P[0]).run(W.ws, W.ws_bytes, st));
     // y = y + tanh(alpha_ffw) * ffw(y) (:182)
+    if (decode_ffw_supported(s.dt, M, s.d, s.ffi))      // <= 32 rows (the cached decode step): LayerNorm + up-projection and down-projection + gate + residual, two launches
+        return decode_ffw(M, s.d, s.ffi, s.act, 1e-5f, S.y1, P[7], P[8], P[9], P[10], P[1], S.xn_f, S.mean_f, S.rstd_f, S.Hpre, S.Aact, S.ffw_out, y_out,
+                          W.ws, W.ws_bytes, st);
     FF_TRY(layernorm_fwd(ln_args(s.dt, M, s.d, pd, pd, pd), S.y1, nullptr, P[7], P[8], S.xn_f, S.mean_f, S.rstd_f, st));
     FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(0, pd).c(pF).act(s.act).problem(S.xn_f, P[9], S.Aact, S.Hpre).run(W.ws, W.ws_bytes, st));
     return Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(0, pF).c(pd).problem(S.Aact, P[10], y_out, S.ffw_out, nullptr, S.y1, P[1]).run(W.ws, W.ws_bytes, st);

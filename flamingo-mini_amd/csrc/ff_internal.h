@@ -145,6 +145,13 @@ int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1,
                  const void* V, const int* tt, const void* O, const float* lse, void* dO, void* dQ, void* dK, void* dV, float* Dsum,
                  int* single_tile, hipStream_t st);
 
+// ---- decode-shaped feed-forward (ff_decode.hip): <= 32 rows, activations resident in LDS, weights streamed HBM -> VGPR -> MFMA ----
+bool decode_ffw_supported(int dtype, int M, int d, int ffi);
+size_t decode_ffw_workspace_bytes(int d, int ffi);
+int decode_ffw(int M, int d, int ffi, int act, float eps, const void* y1, const void* gamma, const void* beta, const void* W1, const void* W3,
+               const void* alpha, void* xn, float* mean, float* rstd, void* Hpre, void* Aact, void* ffw_out, void* y_out, void* ws, size_t ws_bytes,
+               hipStream_t st);
+
 // ---- bump allocator over a caller-provided buffer ----------------------------------------------
 struct Arena {
     unsigned char* base;

@@ -255,3 +255,51 @@ def test_resident_fused_kernels_bf16_vs_oracle(b, L, nv, dim):
         out_c, _ = m(yd[:, -1:].detach(), None, mlt, previous_kv=(kv[0].detach(), kv[1].detach()))
     want = outr[:, -1:] - as64(yd)[:, -1:]
     assert rel(out_c - yd[:, -1:].detach(), want) < t["out"]
+
+
+@pytest.mark.parametrize("b,L,dim,ffm,act", [(32, 1, 1280, 4, "gelu"), (4, 8, 1280, 4, "gelu"), (16, 2, 2048, 4, "relu"), (3, 5, 256, 1, "sqrelu"),
+                                             (2, 7, 768, 4, "gelu"), (8, 4, 1024, 2, "gelu")],
+                         ids=["gpt2-large-decode-b32", "gpt2-large-M32", "opt-1.3b-M32", "tiny-M15", "gpt2-M14", "dim1024-M32"])
+def test_decode_shaped_feedforward_bf16_vs_oracle(b, L, dim, ffm, act):
+    """At most 32 rows (the cached decode step's shape: one token per sequence, batch <= 32) the block's feed-forward half runs on the
+    weight-streaming kernels of csrc/ff_decode.hip: LayerNorm + up-projection + activation in one launch (rows resident in LDS, normalised in
+    place), the down-projection with its K split over workgroups and combined inside the launch (tickets, last arriver) + tanh gate + residual.
+    Forward AND backward against the oracle: the backward consumes what the decode kernels saved (statistics, normalised rows, H, act(H))."""
+    dtype = torch.bfloat16
+    dv, heads, dh, nv = 128, 8 if dim >= 512 else 2, 64, 16
+    p = xattn_params(dim, dv, heads, dh, ffm, tag=f"dec{dim}{ffm}")
+    m = build_block(p, dim, dv, heads, dh, nv, ffm, act, dtype)
+    ml = np.zeros((b, L), np.int64)
+    ml[:, 0] = 1
+    if b > 1 and L > 2:
+        ml[1, 0] = 0; ml[1, 2] = 1
+    yd = dev(det((b, L, dim), "dec-y"), dtype).requires_grad_(True)
+    vfd = dev(det((b, 1, nv, dv), "dec-vf"), dtype).requires_grad_(True)
+    dyd = dev(det((b, L, dim), "dec-dy"), dtype)
+    mlt = torch.as_tensor(ml).cuda()
+    out, kv = m(yd, vfd, mlt, output_kv=True)
+    out.backward(dyd)
+    p64 = {k: as64(v) for k, v in m.state_dict().items()}
+    outr, _, cache = O.gated_xattn_block_fwd(as64(yd), as64(vfd), ml, p64, n_visual=nv, act=act)
+    dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd), cache, p64, act=act)
+    t = TOL[dtype]
+    assert rel(out - yd, outr - as64(yd)) < t["out"]
+    assert rel(yd.grad, dyr) < t["grad"] and rel(vfd.grad, dvfr) < t["grad"]
+    for k, prm in m.named_parameters():
+        if gr[k].size > 1:
+            assert rel(prm.grad, gr[k]) < t["grad"], k
+    # the in-launch combine must not depend on which slice arrives last, on cache state or on what else the chip is doing: the same call
+    # again and again, next to an unrelated stream of work, gives the same bits
+    side = torch.cuda.Stream()
+    a_ = torch.randn(2048, 2048, device="cuda", dtype=dtype)
+    with torch.no_grad():
+        first = m(yd.detach(), vfd.detach(), mlt)[0].clone()
+        for i in range(24):
+            if i % 3 == 0:
+                with torch.cuda.stream(side):
+                    a_ = (a_ @ a_).clamp_(-1, 1)
+            again = m(yd.detach(), vfd.detach(), mlt)[0]
+            assert torch.equal(again, first), i
+        out_c, _ = m(yd[:, -1:].detach(), None, mlt, previous_kv=(kv[0].detach(), kv[1].detach()))      # the decode call proper
+    assert rel(out_c - yd[:, -1:].detach(), outr[:, -1:] - as64(yd)[:, -1:]) < t["out"]
+    torch.cuda.synchronize()

@@ -421,11 +421,19 @@ def test_h64_bf16_two_steps_through_graphed_train_step():
         assert not bad, (s, bad)
         if s == 1:      # parameters after the step: the fp32 masters against float64 AdamW on the reference's gradients, measured on the UPDATE
             wd = {}
+            hp = H64["adamw"]
             for (k, p), q in zip(named.items(), p0):
-                want, m_, v_ = _np_adamw_step(q.double().cpu().numpy(), z["g1." + k].astype(np.float64).reshape(q.shape), *m_state[k], 1, **H64["adamw"])
+                q64, g_ref = q.double().cpu().numpy(), z["g1." + k].astype(np.float64).reshape(q.shape)
+                want, m_, v_ = _np_adamw_step(q64, g_ref, *m_state[k], 1, **hp)
                 got = opt.state[p]["master"].double().cpu().numpy()
-                wd[k] = float(np.linalg.norm((got - q.double().cpu().numpy()) - (want - q.double().cpu().numpy())) /
-                              max(np.linalg.norm(want - q.double().cpu().numpy()), 1e-30))
+                if g_ref.size == 1:
+                    # a scalar gate: its gradient is held to util.gate_grad_ok's bound, and the first AdamW update lr * g / (|g| + eps) turns a
+                    # gradient error dg into lr * eps / (|g| + eps)^2 * dg
+                    dg = 2.5e-2 * (float(z["gs1." + k]) + abs(float(g_ref.reshape(-1)[0])))
+                    bound = hp["lr"] * hp["eps"] / (abs(float(g_ref.reshape(-1)[0])) + hp["eps"]) ** 2 * dg * 1.5 + 1e-7
+                    assert abs(float(got.reshape(-1)[0] - want.reshape(-1)[0])) <= bound, (k, float(got.reshape(-1)[0]), float(want.reshape(-1)[0]), bound)
+                    continue
+                wd[k] = float(np.linalg.norm((got - q64) - (want - q64)) / max(np.linalg.norm(want - q64), 1e-30))
             report["worst_update1"] = max(wd.items(), key=lambda kv: kv[1])
-            assert max(wd.values()) < 0.1, report             # the update is lr * g / (|g| + eps): a smooth function of the gradient at eps = 1e-3
+            assert max(wd.values()) < 0.05, report            # the update is lr * g / (|g| + eps): a smooth function of the gradient at eps = 1e-3 (measured <= 1.3e-2)
     print("h64 bf16 two-step report:", report)

@@ -51,6 +51,13 @@ struct DecodeArgs {
     int n_zero;
 };
 
+#ifdef FF_DEC_TIMELINE   // development probe (tools/experiments/decode_probe.hip): per-workgroup phase timestamps, 100 MHz constant clock
+__device__ unsigned long long g_dec_timeline[1024 * 8];
+#define FF_DTL(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_dec_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FF_DTL(i) do { } while (0)
+#endif
+
 FF_DEV void dec_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -95,37 +102,40 @@ FF_DEV void dec_epilogue4(const DecodeArgs& a, int m, int n, float (&v)[4], floa
 // NT: nontemporal weight loads (each weight byte is read once, by one CU).  LN: LayerNorm prologue on the resident rows (two instantiations
 // so that a kernel trace tells the up-projection launches from the down-projection ones).
 template <bool NT, bool LN>
-__global__ __launch_bounds__(kDecWaves * 64) void decode_rows32_kernel(const DecodeArgs a_in) {
+__global__ __launch_bounds__(kDecWaves * 64) void decode_rows32_kernel(const bf16* hA, const bf16* hB, const bf16* hG, const bf16* hBt, int hM, int hN,
+                                                                       int h_kslice, int h_kslices, int h_nb, int h_ld, const DecodeArgs a_in) {
+    // The leading scalars are everything the path to the last load instruction needs: plain kernel parameters, which the hardware preloads
+    // into SGPRs at wave launch (-amdgpu-kernarg-preload-count, build.py) - the struct behind them lives in HBM and costs a ~1 us scalar
+    // round trip, which now overlaps the loads in flight (probe: "loads issued" at 2.5 us after launch with everything in the struct).
+    // 14 dwords are preloaded (16 user SGPRs minus the kernarg pointer): four pointers and six integers; h_ld = leading dimension of BOTH
+    // operands (K-major rows of the full contraction length).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const DecodeArgs a = fetch_args(a_in);
+    FF_DTL(0);
     const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int n_groups = (a.N + a.nb - 1) / a.nb;
-    const int lin = xcd_remap(blockIdx.x, n_groups * a.kslices);      // the K slices of a column group are neighbours: same XCD (speed only)
-    const int cg = lin / a.kslices, ks = lin - cg * a.kslices;
-    const int n0 = cg * a.nb;
-    const int k0 = ks * a.kslice;
-    const int nk = a.kslice / kBK;                                      // 64-element LDS tiles of the slice
+    const int n_groups = (hN + h_nb - 1) / h_nb;
+    const int lin = xcd_remap(blockIdx.x, n_groups * h_kslices);      // the K slices of a column group are neighbours: same XCD (speed only)
+    const int cg = lin / h_kslices, ks = lin - cg * h_kslices;
+    const int n0 = cg * h_nb;
+    const int k0 = ks * h_kslice;
+    const int nk = h_kslice / kBK;                                      // 64-element LDS tiles of the slice
     bf16* sA = (bf16*)smem;                                             // [nk][32][64], 16-byte chunks XOR-swizzled by row
-    const int vec_elems = (a.kslice + 511) / 512 * 512;                 // gamma / beta padded to whole DMA instructions (out-of-range lanes write zeros)
+    const int vec_elems = (h_kslice + 511) / 512 * 512;                 // gamma / beta padded to whole DMA instructions (out-of-range lanes write zeros)
     bf16* s_g = sA + nk * (kDecRows * kBK);
     bf16* s_b = s_g + vec_elems;
     unsigned* s_flag = (unsigned*)(s_b + vec_elems);
 
-    if (a.zero_tickets && blockIdx.x == 0)                              // the next launch's tickets (visible at the kernel boundary)
-        for (int i = t; i < a.n_zero; i += kDecWaves * 64) a.zero_tickets[i] = 0u;
-
     // ---- the activation rows of this K slice: LDS-DMA, 8 rows x 128 bytes per wave instruction, four instructions per 64-element tile ----
     {
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)hA, 0, 0x7fffffff, 0x00020000);
         const int p = w & 3, row = p * 8 + (l >> 3), cp = l & 7;
-        const unsigned voff = row < a.M ? (unsigned)((long long)row * a.lda + k0 + ((cp ^ (row & 7)) << 3)) * 2u : kOobOffset;
+        const unsigned voff = row < hM ? (unsigned)((long long)row * h_ld + k0 + ((cp ^ (row & 7)) << 3)) * 2u : kOobOffset;
         for (int tile = w >> 2; tile < nk; tile += 2)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, FF_LDS_PTR(void, sA + tile * (kDecRows * kBK) + p * 8 * kBK), 16, voff, (unsigned)tile * (kBK * 2), 0, 0);
         if (LN) {       // gamma / beta of the slice, lane-linear
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gamma, 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rbt = __builtin_amdgcn_make_buffer_rsrc((void*)a.beta, 0, 0x7fffffff, 0x00020000);
-            const int nch = a.kslice / 8;
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)hG, 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rbt = __builtin_amdgcn_make_buffer_rsrc((void*)hBt, 0, 0x7fffffff, 0x00020000);
+            const int nch = h_kslice / 8;
             for (int i0 = w * 64; i0 < nch; i0 += kDecWaves * 64) {
                 const unsigned off = i0 + l < nch ? (unsigned)(k0 / 8 + i0 + l) * 16u : kOobOffset;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, FF_LDS_PTR(void, s_g + i0 * 8), 16, off, 0, 0, 0);
@@ -135,13 +145,13 @@ __global__ __launch_bounds__(kDecWaves * 64) void decode_rows32_kernel(const Dec
     }
     asm volatile("" ::: "memory");                                      // (the weight loads below stay behind the DMA pieces: the counted wait relies on it)
     // ---- ALL weight fragments of this wave: k-steps [s_begin, s_end) of the slice, rows n0 .. n0 + nb - 1 in two 16-row groups ----
-    const int steps = a.kslice / 32, spw = (steps + kDecWaves - 1) / kDecWaves;
+    const int steps = h_kslice / 32, spw = (steps + kDecWaves - 1) / kDecWaves;
     const int s_begin = w * spw, s_end = min(steps, s_begin + spw);
     bf16x8 fb0[kDecMaxSteps], fb1[kDecMaxSteps];
     {
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, 0x7fffffff, 0x00020000);
-        const unsigned b0_off = (c < a.nb && n0 + c < a.N) ? (unsigned)((long long)(n0 + c) * a.ldb + k0 + g * 8) * 2u : kOobOffset;
-        const unsigned b1_off = (16 + c < a.nb && n0 + 16 + c < a.N) ? (unsigned)((long long)(n0 + 16 + c) * a.ldb + k0 + g * 8) * 2u : kOobOffset;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)hB, 0, 0x7fffffff, 0x00020000);
+        const unsigned b0_off = (c < h_nb && n0 + c < hN) ? (unsigned)((long long)(n0 + c) * h_ld + k0 + g * 8) * 2u : kOobOffset;
+        const unsigned b1_off = (16 + c < h_nb && n0 + 16 + c < hN) ? (unsigned)((long long)(n0 + 16 + c) * h_ld + k0 + g * 8) * 2u : kOobOffset;
 #pragma unroll
         for (int i = 0; i < kDecMaxSteps; i++) {
             const bool in = s_begin + i < s_end;                        // wave-uniform
@@ -150,75 +160,70 @@ __global__ __launch_bounds__(kDecWaves * 64) void decode_rows32_kernel(const Dec
             fb1[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, in ? b1_off : kOobOffset, soff, NT ? 2 : 0));
         }
     }
+    FF_DTL(1);
+    const DecodeArgs a = fetch_args(a_in);                              // epilogue arguments: the scalar round trip overlaps the loads in flight
+    if (a.zero_tickets && blockIdx.x == 0)                              // the next launch's tickets (visible at the kernel boundary)
+        for (int i = t; i < a.n_zero; i += kDecWaves * 64) a.zero_tickets[i] = 0u;
     // the DMA pieces were issued before the 2 x kDecMaxSteps weight loads: they have landed once at most that many loads are outstanding
+    // (the ticket stores above are younger still: vmcnt counts them too, so the bound only gets safer)
     wait_vmcnt<2 * kDecMaxSteps>();
     dec_barrier();
+    FF_DTL(2);
 
-    // ---- LayerNorm of the resident rows, in place (16 threads per row, two-pass statistics; every pass re-reads LDS: registers belong to
-    //      the weight fragments in flight) ----
+    // ---- LayerNorm of the resident rows, in place: 16 threads per row.  One pass for the statistics - sums of (x - c) and (x - c)^2 around
+    //      the row's first element c, eight independent accumulators per thread (the first version's two serial passes of 80 dependent adds
+    //      per thread cost 6 us of a 12 us launch) - and one to normalise; every pass re-reads LDS, registers belong to the weights in flight ----
     if (LN) {
         const int r = t >> 4, s16 = t & 15;
         const int nch = nk * 8;
         auto piece = [&](int ci) { return sA + (ci >> 3) * (kDecRows * kBK) + r * kBK + (((ci & 7) ^ (r & 7)) << 3); };
-        constexpr int U = 4;                                            // pieces requested together (LDS latency paid once per batch)
-        float sum = 0.f;
-        for (int c0 = s16; c0 < nch; c0 += 16 * U) {
-            bf16x8 x[U];
+        // (the slice is a whole number of 128-element blocks - decode_ffw_supported - so every thread owns nch / 16 pieces, an even count:
+        // two pieces per iteration, no guards, no clamped duplicates)
+        const float shift = (float)sA[r * kBK + ((0 ^ (r & 7)) << 3)];  // x[r][0]
+        float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c0 = s16; c0 < nch; c0 += 32) {
+            const bf16x8 x0 = *(const bf16x8*)piece(c0), x1 = *(const bf16x8*)piece(c0 + 16);
 #pragma unroll
-            for (int u = 0; u < U; u++) x[u] = *(const bf16x8*)piece(min(c0 + 16 * u, nch - 1));
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (c0 + 16 * u < nch) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) sum += (float)x[u][e];
-                }
+            for (int e = 0; e < 8; e++) {
+                const float d0 = (float)x0[e] - shift, d1 = (float)x1[e] - shift;
+                s1[e] += d0 + d1;
+                s2[e] = fmaf(d1, d1, fmaf(d0, d0, s2[e]));
+            }
         }
+        float sum = ((s1[0] + s1[1]) + (s1[2] + s1[3])) + ((s1[4] + s1[5]) + (s1[6] + s1[7]));
+        float sq = ((s2[0] + s2[1]) + (s2[2] + s2[3])) + ((s2[4] + s2[5]) + (s2[6] + s2[7]));
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const float mu = sum / (float)a.kslice;
-        float sq = 0.f;
-        for (int c0 = s16; c0 < nch; c0 += 16 * U) {
-            bf16x8 x[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) x[u] = *(const bf16x8*)piece(min(c0 + 16 * u, nch - 1));
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (c0 + 16 * u < nch) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) sq += ((float)x[u][e] - mu) * ((float)x[u][e] - mu);
-                }
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-        const float rs = rsqrtf(sq / (float)a.kslice + a.eps);
-        const bool rok = r < a.M;
+        for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); sq += __shfl_xor(sq, o, 64); }
+        const float inv_n = 1.f / (float)h_kslice;
+        const float dm = sum * inv_n;                                   // mean - shift
+        const float mu = shift + dm;
+        const float rs = rsqrtf(fmaxf(sq * inv_n - dm * dm, 0.f) + a.eps);
+        const bool rok = r < hM;
         // by-products for backward, written once: row r by workgroup r % gridDim (every workgroup holds every row)
         const bool writer = rok && (int)(r % gridDim.x) == (int)blockIdx.x;
         if (writer && s16 == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
-        for (int c0 = s16; c0 < nch; c0 += 16 * U) {
-            bf16x8 x[U], gq[U], bq[U];
+        const float nmr = -mu * rs;
+        for (int c0 = s16; c0 < nch; c0 += 32) {
+            bf16x8 x[2], gq[2], bq[2];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int ci = min(c0 + 16 * u, nch - 1);
-                x[u] = *(const bf16x8*)piece(ci);
-                gq[u] = *(const bf16x8*)(s_g + ci * 8);
-                bq[u] = *(const bf16x8*)(s_b + ci * 8);
+            for (int u = 0; u < 2; u++) {
+                x[u] = *(const bf16x8*)piece(c0 + 16 * u);
+                gq[u] = *(const bf16x8*)(s_g + (c0 + 16 * u) * 8);
+                bq[u] = *(const bf16x8*)(s_b + (c0 + 16 * u) * 8);
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int ci = c0 + 16 * u;
-                if (ci < nch) {
-                    float v[8];
+            for (int u = 0; u < 2; u++) {
+                float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = ((float)x[u][e] - mu) * rs * (float)gq[u][e] + (float)bq[u][e];
-                    Vec<bf16>::store(piece(ci), v);
-                    if (writer && a.xn_out) Vec<bf16>::store(a.xn_out + (long long)r * a.ldxn + ci * 8, v);
-                }
+                for (int e = 0; e < 8; e++) v[e] = fmaf(fmaf((float)x[u][e], rs, nmr), (float)gq[u][e], (float)bq[u][e]);
+                Vec<bf16>::store(piece(c0 + 16 * u), v);
+                if (writer && a.xn_out) Vec<bf16>::store(a.xn_out + (long long)r * a.ldxn + (c0 + 16 * u) * 8, v);
             }
         }
         dec_barrier();
     }
 
+    FF_DTL(3);
     // ---- D[n][m] += W[n][k] . X[m][k] over this wave's k-steps: 2 row groups x 2 column groups ----
     f32x4 acc[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
     const bool two_cols = a.nb > 16;
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void decode_rows32_kernel(const Dec
     }
     // ---- the eight waves' partial tiles meet in LDS (the activation rows are dead) ----
     __syncthreads();
+    FF_DTL(4);
     f32x4* red = (f32x4*)smem;                                          // [wave][row group][column group][64 lanes]
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -264,27 +270,34 @@ __global__ __launch_bounds__(kDecWaves * 64) void decode_rows32_kernel(const Dec
     const float gate = a.gate ? tanhf((float)*a.gate) : 1.f;
     if (a.kslices == 1) {
         if (mine) dec_epilogue4(a, m, n, v, gate);
+        FF_DTL(5);
         return;
     }
-    // ---- K split over workgroups: publish the partial tile, the last arriver of the column group combines (MI355X guide, Guideline 16) ----
-    if (mine) *(f32x4*)(a.partial + ((long long)ks * kDecRows + m) * a.N + n) = f32x4{v[0], v[1], v[2], v[3]};      // (N % 4 == 0)
+    // ---- K split over workgroups: publish the partial tile, the last arriver of the column group combines.  The slab is 2.5 KB per workgroup:
+    //      written THROUGH (sc1 stores), drained, then one relaxed agent-scope ticket; the last arriver reads all slabs with sc1 loads.  No
+    //      release / acquire fences (MI355X guide, Guideline 16, the write-through form): the first version's plain stores + agent release
+    //      fence cost 4.6 us per launch - buffer_wbl2 writes back whatever is dirty in the XCD's L2, not just this tile. ----
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)a.partial, 0, 0x7fffffff, 0x00020000);
+    if (mine) {
+        const unsigned off = (unsigned)(((long long)ks * kDecRows + m) * a.N + n) * 4u;      // (N % 4 == 0: 16-byte aligned)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, f32x4{v[0], v[1], v[2], v[3]}), rp, off, 0, 16);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *s_flag = __hip_atomic_fetch_add(a.tickets + cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (t == 0) *s_flag = __hip_atomic_fetch_add(a.tickets + cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    FF_DTL(5);
     if (*s_flag != (unsigned)(a.kslices - 1)) return;
-    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
     if (mine) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < a.kslices; s++) sum += *(const f32x4*)(a.partial + ((long long)s * kDecRows + m) * a.N + n);
+        for (int s = 0; s < a.kslices; s++) {
+            const unsigned off = (unsigned)(((long long)s * kDecRows + m) * a.N + n) * 4u;
+            sum += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 16));
+        }
         float o[4] = {sum[0], sum[1], sum[2], sum[3]};
         dec_epilogue4(a, m, n, o, gate);
     }
+    FF_DTL(6);
 }
 
 int launch_decode(const DecodeArgs& a, hipStream_t st) {
@@ -304,10 +317,12 @@ int launch_decode(const DecodeArgs& a, hipStream_t st) {
         return FF_OK;
     };
     FF_CHECK(lds <= 160 * 1024, FF_ERR_UNSUPPORTED, "decode kernel: K slice %d does not fit LDS", a.kslice);
+    FF_CHECK(a.lda == a.ldb && a.lda == (long long)a.kslice * a.kslices, FF_ERR_SHAPE, "decode kernel: both operands K-major with leading dimension K");
 #define FF_DEC_LAUNCH(NT_, LN_)                                                                       \
     do {                                                                                              \
         FF_TRY(set_attr((const void*)decode_rows32_kernel<NT_, LN_>, (NT_ ? 2 : 0) + (LN_ ? 1 : 0))); \
-        decode_rows32_kernel<NT_, LN_><<<dim3(grid), dim3(kDecWaves * 64), lds, st>>>(a);             \
+        decode_rows32_kernel<NT_, LN_><<<dim3(grid), dim3(kDecWaves * 64), lds, st>>>(a.A, a.B, a.gamma, a.beta, a.M, a.N, a.kslice, a.kslices, a.nb, \
+                                                                                      (int)a.lda, a);                                               \
     } while (0)
     if (nt && a.ln) FF_DEC_LAUNCH(true, true);
     else if (nt) FF_DEC_LAUNCH(true, false);
@@ -333,7 +348,7 @@ int pick_kslices(int K) {       // fewest slices whose rows fit LDS (32 x 2048 b
 bool decode_ffw_supported(int dtype, int M, int d, int ffi) {
     static const int on = dbg_switch("FF_DECODE_FFW", 1);
     if (!on || dtype != FF_DTYPE_BF16 || M > kDecRows || M < 1) return false;
-    if (d % kBK != 0 || ffi % kBK != 0 || d > kDecMaxSteps * kDecWaves * 32 || d % 8 != 0 || ffi % 8 != 0) return false;
+    if (d % 128 != 0 || ffi % kBK != 0 || d > kDecMaxSteps * kDecWaves * 32) return false;      // (d % 128: the LayerNorm pass, two 64-element tiles per step)
     return pick_kslices(ffi) > 0;
 }
 size_t decode_ffw_workspace_bytes(int d, int ffi) {

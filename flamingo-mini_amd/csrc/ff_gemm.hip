@@ -429,13 +429,17 @@ template <int BN, int BL, int NW = 4> struct BStage {
 
 // WPC = workgroups per CU the register budget is sized for (2: <= 128 registers per lane, two 8-wave workgroups share a CU)
 // NPW = producer (DMA) waves: 4, or 8 (a 12-wave workgroup: one MFMA wave and two DMA waves per SIMD)
-template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4>
-__global__ __launch_bounds__(256 + NPW * 64, WPC) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
+// NCW = consumer (MFMA) waves: 4 (2 x 2 over the tile) or 8 (4 x 2: two MFMA waves per SIMD, each on a 32-row slice - one wave's fragment-read
+//       latency is covered by the other's MFMAs instead of being exposed twice per k-step; round 4, the 128 x 160 launches)
+template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4, int NCW = 4>
+__global__ __launch_bounds__((NCW + NPW) * 64, WPC) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
                                                            int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;
     constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
-    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
+    constexpr int CM = NCW / 2;                                 // consumer waves along M (x 2 along N)
+    constexpr int WM = BM / CM, WN = BN / 2, MT = WM / 16, NT = WN / 16;
+    static_assert((NCW == 4 || NCW == 8) && WM % 16 == 0, "consumer layout");
     typedef BStage<BN, BL, NPW> BS;
     constexpr int PER_TILE = BM / (NPW * 8) + BS::PER_WAVE;   // DMA instructions per producer wave per k-step
     static_assert(WN % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
@@ -454,9 +458,9 @@ __global__ __launch_bounds__(256 + NPW * 64, WPC) void gemm_bf16_pc_kernel(const
     const int k_end = min(hK, k_begin + h_kps);
     const int t = threadIdx.x, l = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const bool producer = w >= 4;
-    const int pw = producer ? w - 4 : w;           // index among the producers / the four consumers
-    const int wm = (w & 3) >> 1, wn = w & 1;
+    const bool producer = w >= NCW;
+    const int pw = producer ? w - NCW : w;         // index among the producers / the consumers
+    const int wm = (w & (NCW - 1)) >> 1, wn = w & 1;
     bf16* dummy = smem + NS * STAGE + (pw & 3) * 512;   // NPW = 8, 160-wide tile: scratch kilobyte of producers 4..7 (see BStage)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)opB, 0, 0x7fffffff, 0x00020000);
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256 + NPW * 64, WPC) void gemm_bf16_pc_kernel(const
         }
     }
     __syncthreads();
-    tile_epilogue_bf16<BM, BN, 256 + NPW * 64>(Q, pr, ct, m_base, n_base);      // all waves share the row loop
+    tile_epilogue_bf16<BM, BN, (NCW + NPW) * 64>(Q, pr, ct, m_base, n_base);      // all waves share the row loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -865,6 +869,7 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     const bool skinny_ok = a_layout == 0 && b_layout == 0;      // the 32 x 64 tile stages K-major operands only
     const bool rows_ok = skinny_ok && M <= 32 && nz == 1 && K % 32 == 0;      // the weight-streaming kernel (tile code 3216)
     if (ft == 3216 && rows_ok) return TilePlan{3216, 1};
+    if (ft == 128168) ft = 128160;      // the 8-consumer-wave launch of the same tile (run_bf16_dma looks at force_tile)
     if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
@@ -950,19 +955,19 @@ template <int BM, int BN, int NS> static int dispatch_bf16_dma(const GemmParams&
 template <int BM, int BN> static int run_bf16_dma_tile(const GemmParams& P, int ns, hipStream_t st) {
     return ns == 2 ? dispatch_bf16_dma<BM, BN, 2>(P, st) : ns == 4 ? dispatch_bf16_dma<BM, BN, 4>(P, st) : dispatch_bf16_dma<BM, BN, 3>(P, st);
 }
-template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
+template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4, int NCW = 4> static int launch_bf16_pc(const GemmParams& P, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * kBK * sizeof(bf16) + (NPW == 8 && BN == 160 ? 4096 : 0);
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC, NPW, NCW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm pc lds=%zu): %s", lds, hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
-    gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC, NPW><<<dim3(grid), dim3(256 + NPW * 64), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
+    gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC, NPW, NCW><<<dim3(grid), dim3((NCW + NPW) * 64), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
                                                                                  P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
                                                                                  (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_pc");
@@ -986,6 +991,13 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
         // (split-K launches - fp32 partial slabs, no epilogue for the extra waves to share - were ~1 us slower with the 12-wave workgroup: 24.5 -> 25.9 us)
         const int npw = P.split_k > 1 ? npw_split : npw_full;
         const int pns = P.force_stages > 0 ? P.force_stages : ns_env > 0 ? ns_env : npw == 8 ? 4 : 3;
+        // Round 4: eight MFMA waves (4 x 2) + four DMA waves, 4-deep ring - tile code 128168 or FF_GEMM_NCW=8 in the development build
+        static const int ncw_env = env_int("FF_GEMM_NCW", 4), ncw_split_env = env_int("FF_GEMM_NCW_SPLIT", 4);
+        const int ncw = P.force_tile == 128168 ? 8 : (P.split_k > 1 ? ncw_split_env : ncw_env);
+        if (ncw == 8) {
+            if (P.b_layout == 0) return pns == 3 ? launch_bf16_pc<128, 160, 0, 0, 3, 1, 4, 8>(P, st) : launch_bf16_pc<128, 160, 0, 0, 4, 1, 4, 8>(P, st);
+            return pns == 3 ? launch_bf16_pc<128, 160, 0, 1, 3, 1, 4, 8>(P, st) : launch_bf16_pc<128, 160, 0, 1, 4, 1, 4, 8>(P, st);
+        }
         if (npw == 8) {
             if (P.b_layout == 0) return pns == 4 ? launch_bf16_pc<128, 160, 0, 0, 4, 1, 8>(P, st) : launch_bf16_pc<128, 160, 0, 0, 3, 1, 8>(P, st);
             return pns == 4 ? launch_bf16_pc<128, 160, 0, 1, 4, 1, 8>(P, st) : launch_bf16_pc<128, 160, 0, 1, 3, 1, 8>(P, st);

@@ -747,13 +747,17 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
     } else wait_vmcnt<0>();
     res_barrier();                                                     // (raw barrier: the weight tiles stay in flight across it)
 
-    // ---- LayerNorm of the rows, from LDS and in place: 16 threads per row, two-pass statistics like torch ----
+    // ---- LayerNorm of the rows, from LDS and in place: 16 threads per row ----
     {
         constexpr int MAXC = 12;                                       // 16-byte pieces per thread: dim <= 1536
         const int r = t >> 4, s16 = t & 15;
         const int nch = nk * 8;
+        // statistics in ONE pass around the row's first element (sums of (x - c) and (x - c)^2), eight independent accumulators per thread:
+        // round 3's two passes were two serial chains of up to 96 dependent additions per thread (round 4: ff_decode.hip's probe put the same
+        // code at half of that kernel's time)
         uint4 raw[MAXC];
-        float sum = 0.f;
+        const float shift = (float)sA[r * kBK + ((r & 7) << 3)];        // x[r][0]: chunk 0 of row r sits in slot 0 ^ (r & 7)
+        float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < MAXC; u++) {
             const int ci = s16 + 16 * u;
@@ -762,25 +766,20 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
                 float v[8];
                 unpack16(raw[u], v, bf16());
 #pragma unroll
-                for (int e = 0; e < 8; e++) sum += v[e];
+                for (int e = 0; e < 8; e++) {
+                    const float d = v[e] - shift;
+                    s1[e] += d;
+                    s2[e] = fmaf(d, d, s2[e]);
+                }
             }
         }
+        float sum = ((s1[0] + s1[1]) + (s1[2] + s1[3])) + ((s1[4] + s1[5]) + (s1[6] + s1[7]));
+        float sq = ((s2[0] + s2[1]) + (s2[2] + s2[3])) + ((s2[4] + s2[5]) + (s2[6] + s2[7]));
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const float mu = sum / (float)a.dim;
-        float sq = 0.f;
-#pragma unroll
-        for (int u = 0; u < MAXC; u++) {
-            if (s16 + 16 * u < nch) {
-                float v[8];
-                unpack16(raw[u], v, bf16());
-#pragma unroll
-                for (int e = 0; e < 8; e++) sq += (v[e] - mu) * (v[e] - mu);
-            }
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-        const float rs = rsqrtf(sq / (float)a.dim + a.eps);
+        for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); sq += __shfl_xor(sq, o, 64); }
+        const float dm = sum / (float)a.dim;                            // mean - shift
+        const float mu = shift + dm;
+        const float rs = rsqrtf(fmaxf(sq / (float)a.dim - dm * dm, 0.f) + a.eps);
         const bool rok = r < n_rows;
         const long long grow = (long long)b * a.n_q + (rok ? r : 0);
         if (s16 == 0 && rok && h == 0) { mean[grow] = mu; rstd[grow] = rs; }

@@ -257,7 +257,7 @@ def test_resident_fused_kernels_bf16_vs_oracle(b, L, nv, dim):
     assert rel(out_c - yd[:, -1:].detach(), want) < t["out"]
 
 
-@pytest.mark.parametrize("b,L,dim,ffm,act", [(32, 1, 1280, 4, "gelu"), (4, 8, 1280, 4, "gelu"), (16, 2, 2048, 4, "relu"), (3, 5, 256, 1, "sqrelu"),
+@pytest.mark.parametrize("b,L,dim,ffm,act", [(32, 1, 1280, 4, "gelu"), (4, 8, 1280, 4, "gelu"), (16, 2, 2048, 4, "gelu"), (3, 5, 256, 1, "sqrelu"),
                                              (2, 7, 768, 4, "gelu"), (8, 4, 1024, 2, "gelu")],
                          ids=["gpt2-large-decode-b32", "gpt2-large-M32", "opt-1.3b-M32", "tiny-M15", "gpt2-M14", "dim1024-M32"])
 def test_decode_shaped_feedforward_bf16_vs_oracle(b, L, dim, ffm, act):
@@ -280,8 +280,8 @@ def test_decode_shaped_feedforward_bf16_vs_oracle(b, L, dim, ffm, act):
     out, kv = m(yd, vfd, mlt, output_kv=True)
     out.backward(dyd)
     p64 = {k: as64(v) for k, v in m.state_dict().items()}
-    outr, _, cache = O.gated_xattn_block_fwd(as64(yd), as64(vfd), ml, p64, n_visual=nv, act=act)
-    dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd), cache, p64, act=act)
+    outr, _, cache = O.gated_xattn_block_fwd(as64(yd), as64(vfd), ml, p64, heads=heads, dim_head=dh, n_visual=nv, act=act)
+    dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd), cache, p64, heads=heads, dim_head=dh, act=act)
     t = TOL[dtype]
     assert rel(out - yd, outr - as64(yd)) < t["out"]
     assert rel(yd.grad, dyr) < t["grad"] and rel(vfd.grad, dvfr) < t["grad"]

@@ -37,7 +37,8 @@ def test_gemm_every_instantiated_tile(al, bl):
     ref = (a if al == 0 else a.T) @ (b.T if bl == 0 else b)
     # 128002 / 128160: the 8-wave producer / consumer kernels (128 x 128 for every layout; 128 x 160 for a K-major A operand, B K-major or -
     # staged as a 128-column and a 32-column piece - N-contiguous)
-    for tile in (128, 6412, 64, 64002, 128002) + ((128160,) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
+    # 128168: the 128 x 160 tile with eight MFMA waves (4 x 2) + four DMA waves (round 4)
+    for tile in (128, 6412, 64, 64002, 128002) + ((128160, 128168) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
         for stages in (2, 3, 4):
             for split in (1, 2):
                 C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)
@@ -65,16 +66,17 @@ def test_gemm_balanced_producer_consumer_tile():
     for bl in (0, 1):        # B K-major, and N-contiguous (the data gradients dY . W: the 160-wide tile staged as 128 + 32 columns)
         B = dev(rnd((N, K) if bl == 0 else (K, N), 27, 0.05), dt)
         acc, r, h = as64(A) @ (as64(B).T if bl == 0 else as64(B)), as64(R), as64(H)
-        kw = dict(b_layout=bl, tile=128160)
-        for split_k in (1, 3):
-            for act in ("gelu", "sqrelu", "relu"):
-                C, aux = F().gemm(A, B, act=act, want_aux_out=True, split_k=split_k, **kw)
-                assert rel(aux, acc) < TOL[dt]["out"] and rel(C, O.act_fwd(acc, act)) < TOL[dt]["out"]
-                C = F().gemm(A, B, act_bwd=act, aux_in=H, gate=gate, split_k=split_k, **kw)
-                assert rel(C, acc * g * O.act_bwd(np.ones_like(h), h, act)) < TOL[dt]["out"]
-            C = F().gemm(A, B, residual=R, gate=gate, split_k=split_k, **kw)
-            assert rel(C, r + g * acc) < TOL[dt]["out"]
-            assert rel(F().gemm(A, B, scale=0.25, split_k=split_k, **kw), 0.25 * acc) < TOL[dt]["out"]
+        for tile_code in (128160, 128168):       # four / eight consumer waves
+            kw = dict(b_layout=bl, tile=tile_code)
+            for split_k in (1, 3):
+                for act in ("gelu", "sqrelu", "relu"):
+                    C, aux = F().gemm(A, B, act=act, want_aux_out=True, split_k=split_k, **kw)
+                    assert rel(aux, acc) < TOL[dt]["out"] and rel(C, O.act_fwd(acc, act)) < TOL[dt]["out"]
+                    C = F().gemm(A, B, act_bwd=act, aux_in=H, gate=gate, split_k=split_k, **kw)
+                    assert rel(C, acc * g * O.act_bwd(np.ones_like(h), h, act)) < TOL[dt]["out"]
+                C = F().gemm(A, B, residual=R, gate=gate, split_k=split_k, **kw)
+                assert rel(C, r + g * acc) < TOL[dt]["out"]
+                assert rel(F().gemm(A, B, scale=0.25, split_k=split_k, **kw), 0.25 * acc) < TOL[dt]["out"]
     # the data-gradient shapes the planner now hands to it: d H = d y2 . W3 (1024 x 5120 x 1280) and d xn = d H . W1 (1024 x 1280 x 5120, split-K)
     A, B = dev(rnd((1024, 1280), 31, 0.5), dt), dev(rnd((1280, 5120), 32, 0.05), dt)
     assert rel(F().gemm(A, B, b_layout=1), as64(A) @ as64(B)) < TOL[dt]["out"]

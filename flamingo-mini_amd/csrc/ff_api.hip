@@ -546,13 +546,19 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     if (!defer) FF_TRY(Gemm(s.dt, s.d, s.ffi, M).a(1, pd).b(1, pF).c(pF).problem(dy2, S.Aact, G[10], nullptr, nullptr, nullptr, P[1]).run(W.ws, gws, st));
     FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(1, pF).c(pF).act_bwd(s.act).problem(dy2, P[10], T.dH, nullptr, S.Hpre, nullptr, P[1]).run(W.ws, gws, st));
     if (!defer) FF_TRY(Gemm(s.dt, s.ffi, s.d, M).a(1, pF).b(1, pd).c(pd).problem(T.dH, S.xn_f, G[9]).run(W.ws, gws, st));
-    FF_TRY(Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(1, pd).c(pd).problem(T.dH, P[9], W.dxn).run(W.ws, gws, st));
+    // d LN(y1) = d H . W1: a split-K product at the benchmark's shape.  In the deferred mode its fp32 slabs are summed by the LayerNorm backward
+    // that consumes them (which keeps its partials in the stash, not in W.ws) instead of by a reduce launch of their own (round 4)
+    static const int fold_reduce = dbg_switch("FF_FOLD_SPLITK_LN", 1);
+    int dxn_splits = 1;
+    FF_TRY(Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(1, pd).c(pd).problem(T.dH, P[9], W.dxn).run(W.ws, gws, st, defer_ln && fold_reduce ? &dxn_splits : nullptr));
     {   // LN(y1) backward -> dy1, with both gate gradients folded in: d alpha_ffw = sum(dy2 . ffw_out), d alpha_attn = sum(dy1 . attn_out)
         LnDots dots;
         dots.a = S.ffw_out; dots.alpha_a = P[1]; dots.out_a = G[1];
         dots.b = S.attn_out; dots.alpha_b = P[0]; dots.out_b = G[0];
         if (defer_ln) {
-            FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, T.dy1, dy2, G[7], G[8], T.lnp_f,
+            LnArgs la = ln_args(s.dt, M, s.d, pd, pd, pd);
+            if (dxn_splits > 1) { la.dy_splits = dxn_splits; la.dy_slab = (long long)M * s.d; }
+            FF_TRY(layernorm_bwd(la, dxn_splits > 1 ? W.ws : W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, T.dy1, dy2, G[7], G[8], T.lnp_f,
                                  layernorm_bwd_partial_bytes(M, s.d), st, &dots, &pend_f));
             FF_CHECK(pend_f.partial, FF_ERR_SHAPE, "xattn_bwd: the one-pass LayerNorm backward did not apply in the deferred mode");
         } else FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dxn, S.y1, nullptr, P[7], S.mean_f, S.rstd_f, T.dy1, dy2, G[7], G[8], W.ws, gws, st, &dots));

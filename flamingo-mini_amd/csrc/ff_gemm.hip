@@ -1037,7 +1037,8 @@ size_t gemm_workspace_bytes(int dtype, int M, int N, int K, int nz, int split_k)
     return split_k > 1 ? (size_t)split_k * nz * M * N * sizeof(float) : 0;
 }
 
-int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipStream_t st) {
+int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipStream_t st, int* leave_partial) {
+    if (leave_partial) *leave_partial = 1;
     FF_CHECK(P.M > 0 && P.N > 0 && P.K > 0 && P.nz >= 1 && P.nz <= kGemmMaxZ, FF_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d nz=%d",
              P.M, P.N, P.K, P.nz);
     P.tile = kFBM;
@@ -1103,6 +1104,11 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
     }
     prof_end(prof_id, st);   // the record covers the MFMA main kernel only (what rocprofv3 lists under the same name)
     FF_TRY(rc);
+    if (P.split_k > 1 && leave_partial && P.nz == 1 && P.scale == 1.f && P.act < 0 && P.act_bwd < 0 && !P.p[0].aux_out && !P.p[0].gate &&
+        !P.p[0].residual) {
+        *leave_partial = P.split_k;         // the consumer sums the slabs (see ff_internal.h)
+        return FF_OK;
+    }
     if (P.split_k > 1) {
         const long long total = (long long)P.nz * P.M * ((P.N + 7) / 8);
         FF_CHECK(total < (1LL << 31), FF_ERR_UNSUPPORTED, "gemm split-K output too large (M=%d N=%d nz=%d)", P.M, P.N, P.nz);

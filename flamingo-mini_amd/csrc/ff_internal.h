@@ -35,7 +35,10 @@ struct GemmParams {
 };
 int gemm_pick_split(int dtype, int M, int N, int K, int nz);
 size_t gemm_workspace_bytes(int dtype, int M, int N, int K, int nz, int split_k);
-int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipStream_t st);
+// leave_partial != null: a split-K problem with a plain epilogue (no scale / aux / gate / activation / residual, one problem) skips its
+// reduce launch and leaves the fp32 slabs [split][M][N] at the start of `workspace` for the consumer to sum (layernorm_bwd: LnArgs.dy_splits);
+// *leave_partial = the number of slabs, or 1 when C was written as usual.
+int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipStream_t st, int* leave_partial = nullptr);
 
 // Convenience builder used by the module-level code.
 struct Gemm {
@@ -61,7 +64,7 @@ struct Gemm {
         return *this;
     }
     size_t workspace() const { return gemm_workspace_bytes(dtype, P.M, P.N, P.K, std::max(P.nz, 1), P.split_k); }
-    int run(void* ws, size_t ws_bytes, hipStream_t st) const { return gemm_launch(P, dtype, ws, ws_bytes, st); }
+    int run(void* ws, size_t ws_bytes, hipStream_t st, int* leave_partial = nullptr) const { return gemm_launch(P, dtype, ws, ws_bytes, st, leave_partial); }
 };
 
 // launch timing hooks (ff_gemm_profile_*): tile < 0 marks the attention kernels (-1 fwd, -2 dQ, -3 dK/dV; M = n_q, N = n_kv,
@@ -78,6 +81,10 @@ struct LnArgs {
     int add_rows_per_seg, add_div;
     float eps;
     int stats_given;
+    // backward only: dy_splits > 0 = `dy` points at that many fp32 slabs [rows][cols] (slab stride dy_slab elements) whose SUM is dy - the
+    // partial tiles of a split-K GEMM, combined on the way into the kernel instead of by a reduce launch of their own
+    int dy_splits = 0;
+    long long dy_slab = 0;
 };
 int layernorm_fwd(const LnArgs& a, const void* x, const void* add, const void* gamma, const void* beta, void* y,
                   float* mean, float* rstd, hipStream_t st);

@@ -247,9 +247,24 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
         for (int e = 0; e < VEC; e++) accg[i][e] = accb[i][e] = 0.f;
     float da = 0.f, db = 0.f;
     const int row_end = min(a.rows, (int)(blockIdx.x + 1) * rows_per_block);
+    // dy of a row chunk: one load, or - a.dy_splits > 0 - the sum of that many fp32 slabs a split-K GEMM left behind (plain [rows][cols] each)
+    auto load_dy = [&](int row, const T* dyr, int c, float (&d)[VEC]) {
+        if (a.dy_splits > 0) {
+            const float* pp = (const float*)dy + (long long)row * a.cols + c * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) d[e] = 0.f;
+            for (int sp = 0; sp < a.dy_splits; sp++) {
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) {
+                    const f32x4 q = *(const f32x4*)(pp + (long long)sp * a.dy_slab + e);
+                    d[e] += q[0]; d[e + 1] += q[1]; d[e + 2] += q[2]; d[e + 3] += q[3];
+                }
+            }
+        } else ld<T, VEC>(dyr + c * VEC, d);
+    };
     for (int row = blockIdx.x * rows_per_block + w; row < row_end; row += 4) {
         const T* xr = x + a.x_map.off(row);
-        const T* dyr = dy + a.y_map.off(row);
+        const T* dyr = a.dy_splits > 0 ? dy : dy + a.y_map.off(row);
         const T* ar = add ? add + (long long)((row % a.add_rows_per_seg) / a.add_div) * a.cols : nullptr;
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
 #pragma unroll
                     for (int e = 0; e < VEC; e++) v[e] += t[e];
                 }
-                ld<T, VEC>(dyr + c * VEC, d);
+                load_dy(row, dyr, c, d);
                 ld<T, VEC>(gamma + c * VEC, g);
                 if constexpr (HOIST) {
                     if (dx_res) rq[i] = *(const uint4*)(dx_res + doff + c * VEC);
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnArgs a_in, co
 #pragma unroll
                         for (int e = 0; e < VEC; e++) v[e] += t[e];
                     }
-                    ld<T, VEC>(dyr + c * VEC, d);
+                    load_dy(row, dyr, c, d);
 #pragma unroll
                     for (int e = 0; e < VEC; e++) xh[e] = (v[e] - mu) * rs;
                 }
@@ -712,6 +727,8 @@ int layernorm_bwd(const LnArgs& a, const void* dy, const void* x, const void* ad
     FF_CHECK(!dots.a || dx_residual, FF_ERR_SHAPE, "layernorm_bwd: dot_a is taken against dx_residual");
     FF_CHECK(!dots.b || dx, FF_ERR_SHAPE, "layernorm_bwd: dot_b is taken against dx");
     const bool v = vec_ok(a.dtype, a.cols, {a.x_map, a.y_map, a.dx_map}, {x, add, gamma, dy, dx, dx_residual, dots.a, dots.b});
+    FF_CHECK(a.dy_splits == 0 || (ln_fused_ok(a.dtype, a.cols, v) && (dgamma || dots.a || dots.b) && a.cols % 4 == 0), FF_ERR_UNSUPPORTED,
+             "layernorm_bwd: summing split-K slabs needs the one-pass kernel");
     if (ln_fused_ok(a.dtype, a.cols, v) && (dgamma || dots.a || dots.b)) {
         FF_CHECK(!dgamma == !dbeta, FF_ERR_SHAPE, "layernorm_bwd: dgamma and dbeta come together");
         int rpb;

@@ -210,8 +210,13 @@ def test_reused_block_and_accumulated_gradients_on_the_deferred_path(dtype):
     assert rel(out, h) < t["out"] * 3
     d, dvf = as64(g), np.zeros_like(vf64)
     grads = [dict(), dict()]
+    gscale = [dict(alpha_ffw=0.0, alpha_attn=0.0), dict(alpha_ffw=0.0, alpha_attn=0.0)]      # natural scale of the gate gradients (util.gate_grad_ok), summed over a block's uses
     for pos in reversed(range(len(order))):
         i = order[pos]
+        c = caches[pos]
+        d1 = d + O.feedforward_bwd(d * c[5], c[1], p64[i], "ffw.", "gelu", {})
+        gscale[i]["alpha_ffw"] += float(np.linalg.norm(d * c[3])) * float(1.0 - c[5][0] ** 2)
+        gscale[i]["alpha_attn"] += float(np.linalg.norm(d1 * c[2])) * float(1.0 - c[4][0] ** 2)
         d, dvf_i, g_r = O.gated_xattn_block_bwd(d, caches[pos], p64[i], act="gelu")
         dvf += dvf_i
         for k, v in g_r.items():
@@ -224,9 +229,8 @@ def test_reused_block_and_accumulated_gradients_on_the_deferred_path(dtype):
         for i, m in enumerate(blocks):
             for k, prm in m.named_parameters():
                 ref = scale * grads[i][k]
-                if ref.size == 1:       # gate gradients: a dot product over all elements, held on the scale of the larger of the two
-                    top = max(abs(float(v)) for gr in grads for kk, v in gr.items() if v.size == 1) * scale
-                    worst[f"{what}.block{i}.{k}"] = abs(float(prm.grad) - float(ref)) / (t["grad"] * 3 * top + 1e-30)
+                if ref.size == 1:       # gate gradients: the rule of util.gate_grad_ok, written as a ratio
+                    worst[f"{what}.block{i}.{k}"] = abs(float(prm.grad) - float(ref)) / (t["grad"] * 3 * (scale * gscale[i][k] + abs(float(ref))) + 1e-30)
                 else:
                     worst[f"{what}.block{i}.{k}"] = rel(prm.grad, ref) / (t["grad"] * 3)
 

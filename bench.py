@@ -85,9 +85,9 @@ def parse():
                     help="N=1 only: after the main measurement, re-run the same workload in child processes (a) with the op substitutions inside the "
                          "backbones + the tuning file, (b) with the fp32-master / fp32-moment optimizer, and add both to the JSON line (auto = on for the default config B run)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off", "piecewise"],
-                    help="replay the step from a captured HIP graph (auto = on; at N > 1 the RCCL all-reduces are captured with it; if that capture "
-                         "fails on a rank the step falls back to `piecewise`, then to eager launches); piecewise = one sub-graph per backward segment "
-                         "of 4 gated layers, collectives issued eagerly between the replays")
+                    help="replay the step from captured HIP graphs.  piecewise = one sub-graph per backward segment of 4 gated layers, the RCCL collectives "
+                         "issued eagerly between the replays; on = the whole step incl. its collectives in ONE graph; auto = on at N = 1, piecewise -> on -> "
+                         "eager launches at N > 1 (every rank takes the first mode that ALL ranks can capture)")
     ap.add_argument("--force-collectives", action="store_true", help="N=1: run the gradient exchange through a 1-rank RCCL group (what a single GPU can exercise of the N > 1 path)")
     ap.add_argument("--bucket-timeline", action="store_true", help="after the timed region, one eager step with HIP events around every gradient "
                                                                    "bucket's exchange: when it became ready, when its collective finished (rank 0, `bucket_timeline` in the JSON line)")
@@ -518,7 +518,15 @@ def main():
         from flamingo_mini_amd import GraphedTrainStep
         from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
         live_reducer = reducer if (collectives and reducer is not None) else None
-        attempts = ["piecewise"] if graph_mode == "piecewise" else (["full", "piecewise"] if (collectives and not sharded) else ["full"])
+        # With collectives `auto` tries the piecewise replay first: on one GPU with the exchange going through a 1-rank RCCL group it is the
+        # faster of the two (44.3 vs 47.6 ms per step, profiles/r04_launch_modes_one_rank_rccl.txt) and it does not depend on RCCL's kernels
+        # accepting a stream capture; `--graph on` asks for the whole-step capture first.
+        if graph_mode == "piecewise":
+            attempts = ["piecewise"]
+        elif collectives and not sharded:
+            attempts = ["full", "piecewise"] if args.graph == "on" else ["piecewise", "full"]
+        else:
+            attempts = ["full"]
         graph_mode = "off"
         for mode in attempts:
             err = None
@@ -637,19 +645,19 @@ def main():
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             tm, tn = (64, 128) if key[1] == 6412 else (key[1], key[1])
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
-            if key[1] == 128160:      # the producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU, DMA waves>; split-K launches
+            if key[1] == 128160:      # the producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU, DMA waves, MFMA waves>; split-K launches
                 # of this tile run the 8-wave workgroup with a 3-deep ring (ff_gemm.hip run_bf16_dma): name the instantiation most launches used
                 n_split = sum(v["launches"] for k, v in shapes.items() if k[6] == 128160 and k[4] == key[2] and k[5] == key[3] and k[7] > 1)
-                name = (f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 3, 1, 4>" if 2 * n_split > g["launches"]
-                        else f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 4, 1, 8>")
+                name = (f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 3, 1, 4, 4>" if 2 * n_split > g["launches"]
+                        else f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 4, 1, 8, 4>")
             elif key[1] == 64002:
-                name = f"ff::gemm_bf16_pc_kernel<64, 64, {key[2]}, {key[3]}, 3, 2, 4>"
+                name = f"ff::gemm_bf16_pc_kernel<64, 64, {key[2]}, {key[3]}, 3, 2, 4, 4>"
             elif key[1] == 3264:
-                name = "ff::gemm_bf16_pc_kernel<32, 64, 0, 0, 4, 2, 4>"
+                name = "ff::gemm_bf16_pc_kernel<32, 64, 0, 0, 4, 2, 4, 4>"
             elif key[1] == 3216:
                 name = "ff::gemm_bf16_rows32_kernel"
             elif key[1] == 128002:
-                name = f"ff::gemm_bf16_pc_kernel<128, 128, {key[2]}, {key[3]}, 2, 2, 4>"
+                name = f"ff::gemm_bf16_pc_kernel<128, 128, {key[2]}, {key[3]}, 2, 2, 4, 4>"
             tot_ms = sum(v["ms"] for v in groups.values())
             tot_fl = sum(v["flops"] for v in groups.values())
             # HBM bytes per launch of this kernel: PMC counters cannot be read from inside this process (rocprofv3 wraps the command), so the

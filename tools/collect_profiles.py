@@ -43,6 +43,50 @@ def pmc(sub):
     return acc
 
 fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
+
+
+# ---- the same counters PER SHAPE: a kernel instantiation serves several GEMM shapes, which differ in their grid; the algorithmic bytes of a
+# shape can only be compared with the counter traffic of ITS launches (175 MB vs 108 MB was a comparison across shapes) ----
+def pmc_by_grid(sub, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    with open(find(sub, "*counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if is_ours(r["Kernel_Name"]) and r["Counter_Name"] == counter:
+                a = acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))]
+                a[0] += 1; a[1] += float(r["Counter_Value"])
+    return acc
+
+
+def gemm_kernel_of(tile, al, bl, split):
+    """(kernel name as rocprofv3 prints it, block tile, threads per workgroup) of a row of the bench's GEMM table (ff_gemm.hip: run_bf16_dma)"""
+    if tile == 128002: return f"ff::gemm_bf16_pc_kernel<128, 128, {al}, {bl}, 2, 2, 4, 4>", 128, 128, 512
+    if tile == 128160 and split > 1: return f"ff::gemm_bf16_pc_kernel<128, 160, {al}, {bl}, 3, 1, 4, 4>", 128, 160, 512
+    if tile == 128160: return f"ff::gemm_bf16_pc_kernel<128, 160, {al}, {bl}, 4, 1, 8, 4>", 128, 160, 768
+    if tile == 64002: return f"ff::gemm_bf16_pc_kernel<64, 64, {al}, {bl}, 3, 2, 4, 4>", 64, 64, 512
+    if tile == 3264: return "ff::gemm_bf16_pc_kernel<32, 64, 0, 0, 4, 2, 4, 4>", 32, 64, 512
+    return None, 0, 0, 0
+
+
+if os.path.exists(os.path.join(src, "gemm_table.txt")):
+    fetch_g, write_g = pmc_by_grid("pmc_fetch", "FETCH_SIZE"), pmc_by_grid("pmc_write", "WRITE_SIZE")
+    lines = ["M N K nz aL bL tile splitK launches/step us/launch algorithmic_MB counter_MB counter/algorithmic   "
+             "(counter = (2 FETCH_SIZE + WRITE_SIZE) KiB per launch of THIS shape; algorithmic = operands read once + output written once, fp32 slabs for split-K)"]
+    for row in open(os.path.join(src, "gemm_table.txt")).read().strip().splitlines()[1:]:
+        M, N, K, nz, al, bl, tile, sk = (int(v) for v in row.split()[:8])
+        per_step, us = row.split()[8], row.split()[9]
+        name, bm, bn, threads = gemm_kernel_of(tile, al, bl, sk)
+        if name is None:
+            continue
+        grid = -(-M // bm) * -(-N // bn) * sk * nz * threads
+        f_ = next((v for (k, g), v in fetch_g.items() if g == grid and k.replace(" ", "") == name.replace(" ", "")), None)
+        w_ = next((v for (k, g), v in write_g.items() if g == grid and k.replace(" ", "") == name.replace(" ", "")), None)
+        alg = nz * ((M * K + N * K) * 2 + (M * N * 4 * sk if sk > 1 else M * N * 2)) / 1e6
+        if f_ is None or w_ is None:
+            lines.append(f"{M} {N} {K} {nz} {al} {bl} {tile} {sk} {per_step} {us} {alg:.1f} n/a n/a")
+            continue
+        cnt = (2 * f_[1] / f_[0] + w_[1] / w_[0]) * 1024 / 1e6
+        lines.append(f"{M} {N} {K} {nz} {al} {bl} {tile} {sk} {per_step} {us} {alg:.1f} {cnt:.1f} {cnt / alg:.2f}")
+    open(os.path.join(P, f"{rnd}_gemm_traffic.txt"), "w").write("\n".join(lines) + "\n")
 traffic = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over one eager step of the default bench; counter values are KB; "
                     "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 "
                     "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated; memory-side counters include Infinity-Cache hits.", "kernels": {}}
@@ -72,14 +116,15 @@ for k in sorted(sq, key=lambda k: -sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1]):
 json.dump(busy, open(os.path.join(P, f"{rnd}_sq_mfma_busy.json"), "w"), indent=1)
 
 # the bench line: take `traffic` of its dominant kernel from the PMC file of the SAME session
-line = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+line = next(json.loads(l) for l in reversed(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()) if l.startswith("{"))
 k = line["roofline"]["kernel"]
 line["roofline"]["traffic"] = traffic["kernels"].get(k, {}).get("hbm_bytes_per_launch")
 json.dump(line, open(os.path.join(P, f"{rnd}_bench_default.json"), "w"), indent=1)
 if os.path.exists(os.path.join(src, "bench_stock_backbones.json")):      # (round 3 on: the default line carries it as `stock_backbones`)
     stock = json.loads(open(os.path.join(src, "bench_stock_backbones.json")).read().strip().splitlines()[-1])
     json.dump(stock, open(os.path.join(P, f"{rnd}_bench_stock_backbones.json"), "w"), indent=1)
-for extra in ("gemm_table.txt", "bucket_timeline.txt", "caption_decode_kernels.txt", "smoke.txt"):
+for extra in ("gemm_table.txt", "bucket_timeline.txt", "caption_decode_kernels.txt", "smoke.txt", "gemm_yardstick.txt", "decode_probe.txt", "decode_chain.txt",
+              "launch_modes_one_rank_rccl.txt", "gemm_ncw8_ab.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(P, f"{rnd}_{extra}"))
 print("dominant kernel", k, "traffic", line["roofline"]["traffic"], "frac", line["roofline"]["frac"], "value", line["value"])

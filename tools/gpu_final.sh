@@ -4,7 +4,7 @@ ulimit -c 0   # no core files: a GPU fault must not fill the scratch disk
 # trace of the same command, the two PMC traffic passes and the SQ MFMA-busy pass (separate runs, --kernel-trace only), the bucket timeline of
 # the data-parallel launch structure, the kernel statistics of the caption leg.
 #   tools/gpu_final.sh <tag> <round>      results under gpurun_out/<tag>/ ; tools/collect_profiles.py turns them into profiles/<round>_*
-tag=$1; rnd=${2:-r03}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
+tag=$1; rnd=${2:-r04}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/pytest.txt 2>&1; echo "pytest rc=$?"; tail -n 3 $out/pytest.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; echo "smoke rc=$?"; tail -n 2 $out/smoke.txt
@@ -18,6 +18,30 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_C
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/bucket -- $B --wgrad-group 4 --kv-group 4 --steps 2 --warmup 2 --graph off > /dev/null 2> $out/bucket.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/capprof -- python $R/tools/caption_profile.py --eager > $out/caption_profile.txt 2> $out/caption_profile.err
 cd $R
+# round 4: hipBLASLt beside every GEMM shape of the step (same method for both), the decode kernels in isolation (probe with phase timestamps, the 36-block
+# chain), the three launch modes of the step with the gradient exchange going through a 1-rank RCCL group + the bucket timeline, the 128 x 160 tile with 4 / 8 MFMA waves
+timeout 400 python tools/gemm_yardstick.py $out/gemm_table.txt > $out/gemm_yardstick.txt 2> $out/gemm_yardstick.err; head -5 $out/gemm_yardstick.txt
+P=tools/experiments/_bin/decode_probe
+if [ -x $P ]; then for a in "32 5120 1280 20 1 1" "32 5120 1280 20 1 0" "32 1280 5120 20 4 0" "32 8192 2048 32 1 1" "32 2048 8192 32 4 0"; do echo "== decode_probe $a"; timeout 60 $P $a 2>&1 | tail -4; done > $out/decode_probe.txt 2>&1; fi
+( python tools/decode_chain_bench.py 2>&1 | tail -1; for v in "FF_DECODE_FFW=0" "FF_DECODE_FFW=1"; do ( export FLAMINGO_FUSION_LIB=debug $v; echo "[development build, $v] $(python tools/decode_chain_bench.py 2>&1 | tail -1)" ); done ) > $out/decode_chain.txt
+cat $out/decode_chain.txt
+B2="python bench.py --no-cpu-baseline --caption-tokens 0 --profile-steps 0 --companions off --steps 12 --warmup 3"
+( for g in on piecewise off; do timeout 300 $B2 --graph $g --force-collectives --bucket-timeline 2> /dev/null | python -c "
+import sys, json
+d = next(json.loads(l) for l in reversed(sys.stdin.read().strip().splitlines()) if l.startswith('{'))
+bt = d.get('bucket_timeline') or {}
+print('graph=$g, gradient exchange through a 1-rank RCCL group:', d['value'], 'images/s', d['ms_per_step'], 'ms/step, mode', d['config']['graph_mode'], '| eager timeline step: backward', bt.get('backward_ms'), 'ms, exchange finished', bt.get('exchange_finished_ms'), 'ms, exposed', bt.get('exposed_communication_ms'), 'ms,', len(bt.get('buckets', [])), 'buckets')
+if '$g' == 'piecewise':
+    for r in bt.get('buckets', []): print('   ', r)
+"; done
+  timeout 300 $B2 --graph on 2> /dev/null | python -c "
+import sys, json
+d = next(json.loads(l) for l in reversed(sys.stdin.read().strip().splitlines()) if l.startswith('{'))
+print('graph=on, no collectives (the single-GPU default):', d['value'], 'images/s', d['ms_per_step'], 'ms/step')" ) > $out/launch_modes_one_rank_rccl.txt
+head -4 $out/launch_modes_one_rank_rccl.txt
+( for t in 128160 128168 128160 128168; do python tools/gemm_graph_bench.py 1024 5120 1280 0 0 $t 2>/dev/null | tail -1; done
+  for t in 128160 128168; do EPI=act python tools/gemm_graph_bench.py 1024 5120 1280 0 0 $t 2>/dev/null | tail -1; done
+  for t in 128160 128168; do EPI=act_bwd python tools/gemm_graph_bench.py 1024 5120 1280 0 1 $t 2>/dev/null | tail -1; done ) > $out/gemm_ncw8_ab.txt
 python tools/bucket_timeline.py $(find $out/bucket -name "*kernel_trace.csv" | head -1) > $out/bucket_timeline.txt 2>&1; head -20 $out/bucket_timeline.txt
 python - > $out/caption_decode_kernels.txt <<P
 import csv, glob

@@ -13,6 +13,7 @@ def category(name):
     if "normal_and_transform" in name or "rocsolver" in name or "potf2" in name: return INIT
     if "ff::gemm_bf16" in name or "ff16gemm" in name or "gemm_f32" in name: return "fusion: GEMM main kernels (hand-written MFMA)"
     if "gemm_splitk" in name: return "fusion: split-K reduce + epilogue"
+    if "decode_rows32" in name: return "fusion: decode-shaped feed-forward (weight streaming, <= 32 rows)"
     if "xa_qattn" in name or "xa_dattn" in name: return "fusion: LayerNorm + projection + attention of the gated blocks (one launch each way)"
     if "attn_fwd_kernel" in name or "attn_bwd" in name: return "fusion: attention core of the resampler (fwd, dQ, dK/dV)"
     if "adamw_kernel" in name: return "fusion: multi-tensor AdamW (ff_adamw_step)"

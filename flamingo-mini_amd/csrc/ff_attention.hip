@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const ff_attn_desc d_in, 
 
     const T* Kb = K + b * d.k.sb + h * d.k.sh;
     const T* Vb = V + b * d.v.sb + h * d.v.sh;
-    attn_fwd_loop<T, DH>(d, fq, rr, blo, bhi, Kb, Vb, sK, sV, acc, m, lsum);
+    attn_fwd_loop<T, DH, PrefetchStage<T, DH>>(d, fq, rr, blo, bhi, Kb, Vb, sK, sV, acc, m, lsum);
     lsum = group_sum(lsum);
     if (q < d.n_q) {
         const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const ff_attn_desc d_i
     for (int dt = 0; dt < DH / 16; dt++) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* Kb = K + b * d.k.sb + h * d.k.sh;
     const T* Vb = V + b * d.v.sb + h * d.v.sh;
-    attn_dq_loop<T, DH>(d, fq, fdo, rr, L, Dq, blo, bhi, Kb, Vb, sK, sV, acc);
+    attn_dq_loop<T, DH, PrefetchStage<T, DH>>(d, fq, fdo, rr, L, Dq, blo, bhi, Kb, Vb, sK, sV, acc);
     if (qok) store_acc_row<T, DH>(dQ + b * d.dq.sb + (long long)q * d.dq.sr + h * d.dq.sh, acc, 1.f, g);
 }
 
@@ -126,21 +126,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const ff_attn_desc d_
 
     const T* Qb = Q + b * d.q.sb + h * d.q.sh;
     const T* dOb = dO + b * d.dout.sb + h * d.dout.sh;
-    for (int q0 = 0; q0 < d.n_q; q0 += kTile) {
-        __syncthreads();
-        stage_tile<T, DH>(sQ, Qb, d.q.sr, q0, d.n_q);
-        stage_tile<T, DH>(sDO, dOb, d.dout.sr, q0, d.n_q);
+    // query tile t + 1 (Q, dO and the per-query statistics) is requested into registers as soon as tile t is published: its latency runs under
+    // tile t's MFMAs (round 4; before, every tile's loads sat in front of its products)
+    TileRegs<T, DH> rq, rdo;
+    RowRange rr_n = {0, 0, 0, 0};
+    float lse_n = kPosBig, D_n = 0.f;
+    auto issue = [&](int q0) {
+        stage_issue<T, DH>(rq, Qb, d.q.sr, q0, d.n_q);
+        stage_issue<T, DH>(rdo, dOb, d.dout.sr, q0, d.n_q);
         if (threadIdx.x < kTile) {
             const int q = q0 + threadIdx.x;
-            const RowRange rr = row_range(d, tt, b, q);
-            s_lo[threadIdx.x] = rr.lo;
-            s_hi[threadIdx.x] = rr.hi;
-            s_flag[threadIdx.x] = rr.softmax | (rr.uniform << 1);
+            rr_n = row_range(d, tt, b, q);
             const long long sidx = ((long long)b * d.heads + h) * d.n_q + q;
-            s_lse[threadIdx.x] = q < d.n_q ? lse[sidx] : kPosBig;
-            s_D[threadIdx.x] = q < d.n_q ? Dsum[sidx] : 0.f;
+            lse_n = q < d.n_q ? lse[sidx] : kPosBig;
+            D_n = q < d.n_q ? Dsum[sidx] : 0.f;
+        }
+    };
+    issue(0);
+    for (int q0 = 0; q0 < d.n_q; q0 += kTile) {
+        __syncthreads();
+        stage_commit<T, DH>(rq, sQ);
+        stage_commit<T, DH>(rdo, sDO);
+        if (threadIdx.x < kTile) {
+            s_lo[threadIdx.x] = rr_n.lo;
+            s_hi[threadIdx.x] = rr_n.hi;
+            s_flag[threadIdx.x] = rr_n.softmax | (rr_n.uniform << 1);
+            s_lse[threadIdx.x] = lse_n;
+            s_D[threadIdx.x] = D_n;
         }
         __syncthreads();
+        if (q0 + kTile < d.n_q) issue(q0 + kTile);
         attn_dkv_step<T, DH>(key, fk, fv, sQ, sDO, s_lo, s_hi, s_flag, s_lse, s_D, acc_k, acc_v);
     }
     if (kok) {

@@ -1,6 +1,7 @@
 // Device-side building blocks of the attention kernels (ff_attention.hip) and of the fused projection + attention kernels
 // (ff_xattn_fused.hip): own-row fragments, LDS tile staging, the two transposed MFMA products, per-row key ranges.
 #pragma once
+#include <type_traits>
 #include "ff_common.h"
 
 namespace ff {
@@ -87,6 +88,33 @@ FF_DEV void stage_tile(T* lds, const T* base, long long row_stride, int row0, in
         uint4 v = {0, 0, 0, 0};
         if (row0 + r < n_rows) v = *(const uint4*)(base + (long long)(row0 + r) * row_stride + ch * VN);
         *(uint4*)(lds + r * LD + ch * VN) = v;
+    }
+}
+
+// The same staging split in two (round 4): `stage_issue` requests a tile's 16-byte pieces into registers, `stage_commit` writes them to LDS.
+// The stand-alone kernels issue tile t + 1 right after tile t has been published, so its global-memory latency runs under tile t's MFMAs
+// instead of in front of them (one workgroup per CU at the resampler's shape: nothing else was hiding it - 20 us for 25 MB).
+template <typename T, int DH> struct TileRegs {
+    static constexpr int N = (kTile * (DH / Vec<T>::N) + 255) / 256;
+    uint4 v[N];
+};
+template <typename T, int DH>
+FF_DEV void stage_issue(TileRegs<T, DH>& r, const T* base, long long row_stride, int row0, int n_rows) {
+    constexpr int VN = Vec<T>::N, CH = DH / VN;
+#pragma unroll
+    for (int i = 0; i < TileRegs<T, DH>::N; i++) {
+        const int idx = threadIdx.x + i * 256, rr = idx / CH, ch = idx - rr * CH;
+        r.v[i] = uint4{0, 0, 0, 0};
+        if (idx < kTile * CH && row0 + rr < n_rows) r.v[i] = *(const uint4*)(base + (long long)(row0 + rr) * row_stride + ch * VN);
+    }
+}
+template <typename T, int DH> FF_DEV void stage_commit(const TileRegs<T, DH>& r, T* lds) {
+    constexpr int LD = DH + AttnCfg<T>::pad;
+    constexpr int VN = Vec<T>::N, CH = DH / VN;
+#pragma unroll
+    for (int i = 0; i < TileRegs<T, DH>::N; i++) {
+        const int idx = threadIdx.x + i * 256, rr = idx / CH, ch = idx - rr * CH;
+        if (idx < kTile * CH) *(uint4*)(lds + rr * LD + ch * VN) = r.v[i];
     }
 }
 
@@ -205,18 +233,49 @@ template <typename T, int DH> struct SyncStage {
         stage_tile<T, DH>(s1, b1, sr1, row0, n_rows);
     }
 };
+// ... and the register-prefetched form of it (the stand-alone kernels): issue2 early, commit2 behind the barrier
+template <typename T, int DH> struct PrefetchStage : SyncStage<T, DH> {
+    struct Regs { TileRegs<T, DH> a, b; };
+    static FF_DEV void issue2(Regs& r, const T* b0, long long sr0, const T* b1, long long sr1, int row0, int n_rows) {
+        stage_issue<T, DH>(r.a, b0, sr0, row0, n_rows);
+        stage_issue<T, DH>(r.b, b1, sr1, row0, n_rows);
+    }
+    static FF_DEV void commit2(const Regs& r, T* s0, T* s1) {
+        stage_commit<T, DH>(r.a, s0);
+        stage_commit<T, DH>(r.b, s1);
+    }
+};
+// register sets kept in flight.  One: the next tile's latency runs under the current tile's products (resampler forward 19.7 -> 15.2 us, dQ
+// 26.8 -> 17.1 us).  Three were measured too (r4s7b): no further gain - after the first overlap the loop is bound by its two barriers and the
+// LDS round trip per tile, not by memory latency - so the ring stays one deep.
+template <typename T, int DH> struct PrefetchDepth { static constexpr int value = 1; };
+template <typename St> struct StageSplit { static constexpr bool value = false; };
+template <typename T, int DH> struct StageSplit<PrefetchStage<T, DH>> { static constexpr bool value = true; };
 
 template <typename T, int DH, typename St = SyncStage<T, DH>>
 FF_DEV void attn_fwd_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const RowRange& rr, int blo, int bhi, const T* Kb, const T* Vb,
                           T* sK, T* sV, f32x4 (&acc)[DH / 16], float& m, float& lsum, int staged_k0 = -1) {
     typedef typename St::L L;
     const int g = (threadIdx.x & 63) >> 4;
-    for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
+    const int k_first = (blo / kTile) * kTile;
+    constexpr bool SPLIT = StageSplit<St>::value;
+    constexpr int D = SPLIT ? PrefetchDepth<T, DH>::value : 1;           // key tiles requested ahead (statically indexed register sets)
+    static_assert(D == 1, "deeper rings were measured without gain and are not covered by the parity suite");
+    [[maybe_unused]] typename std::conditional<SPLIT, typename PrefetchStage<T, DH>::Regs, int>::type rg[D];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < D; j++)
+            if (k_first + j * kTile < bhi && k_first + j * kTile != staged_k0) St::issue2(rg[j], Kb, d.k.sr, Vb, d.v.sr, k_first + j * kTile, d.n_kv);
+    }
+    auto tile = [&](int k0, auto& regs) {
         if (k0 != staged_k0) {
             __syncthreads();
-            St::stage2(sK, Kb, d.k.sr, sV, Vb, d.v.sr, k0, d.n_kv);
+            if constexpr (SPLIT) St::commit2(regs, sK, sV);
+            else St::stage2(sK, Kb, d.k.sr, sV, Vb, d.v.sr, k0, d.n_kv);
             __syncthreads();
         }
+        if constexpr (SPLIT)
+            if (k0 + D * kTile < bhi) St::issue2(regs, Kb, d.k.sr, Vb, d.v.sr, k0 + D * kTile, d.n_kv);      // in flight under the next D tiles' MFMAs
         f32x4 z[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) z[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -251,6 +310,11 @@ FF_DEV void attn_fwd_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[dt][r] *= alpha;
         mma_t<DH, L>(acc, sV, z);
+    };
+    for (int k0 = k_first; k0 < bhi; k0 += D * kTile) {
+#pragma unroll
+        for (int j = 0; j < D; j++)
+            if (k0 + j * kTile < bhi) tile(k0 + j * kTile, rg[j]);
     }
 }
 
@@ -260,12 +324,25 @@ FF_DEV void attn_dq_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const 
                          int blo, int bhi, const T* Kb, const T* Vb, T* sK, T* sV, f32x4 (&acc)[DH / 16], int staged_k0 = -1) {
     typedef typename St::L LY;
     const int g = (threadIdx.x & 63) >> 4;
-    for (int k0 = (blo / kTile) * kTile; k0 < bhi; k0 += kTile) {
+    const int k_first = (blo / kTile) * kTile;
+    constexpr bool SPLIT = StageSplit<St>::value;
+    constexpr int D = SPLIT ? PrefetchDepth<T, DH>::value : 1;
+    static_assert(D == 1, "deeper rings were measured without gain and are not covered by the parity suite");
+    [[maybe_unused]] typename std::conditional<SPLIT, typename PrefetchStage<T, DH>::Regs, int>::type rg[D];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < D; j++)
+            if (k_first + j * kTile < bhi && k_first + j * kTile != staged_k0) St::issue2(rg[j], Kb, d.k.sr, Vb, d.v.sr, k_first + j * kTile, d.n_kv);
+    }
+    auto tile = [&](int k0, auto& regs) {
         if (k0 != staged_k0) {
             __syncthreads();
-            St::stage2(sK, Kb, d.k.sr, sV, Vb, d.v.sr, k0, d.n_kv);
+            if constexpr (SPLIT) St::commit2(regs, sK, sV);
+            else St::stage2(sK, Kb, d.k.sr, sV, Vb, d.v.sr, k0, d.n_kv);
             __syncthreads();
         }
+        if constexpr (SPLIT)
+            if (k0 + D * kTile < bhi) St::issue2(regs, Kb, d.k.sr, Vb, d.v.sr, k0 + D * kTile, d.n_kv);
         f32x4 z[4], dp[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) { z[s] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -281,6 +358,11 @@ FF_DEV void attn_dq_loop(const ff_attn_desc& d, const OwnFrag<T, DH>& fq, const 
                 z[s][r] = p * (dp[s][r] - Dq);  // dS^T
             }
         mma_t<DH, LY>(acc, sK, z);    // dQ^T += K^T dS^T
+    };
+    for (int k0 = k_first; k0 < bhi; k0 += D * kTile) {
+#pragma unroll
+        for (int j = 0; j < D; j++)
+            if (k0 + j * kTile < bhi) tile(k0 + j * kTile, rg[j]);
     }
 }
 

@@ -70,3 +70,44 @@ def test_roofline_table_is_regenerable_from_the_committed_profiles():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), rnd], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-800:]
     assert out.stdout.strip() == open(path).read().strip()
+
+
+def test_counter_traffic_is_compared_shape_by_shape():
+    """profiles/rNN_gemm_traffic.txt (round 4 on): the FETCH_SIZE / WRITE_SIZE passes grouped by kernel instantiation AND grid, one row per GEMM shape of the
+    step, next to that shape's algorithmic bytes - so a traffic ratio never mixes shapes.  The listed figures must follow from the row's own shape, the
+    ratio from the two columns, every shape of the bench's GEMM table must be there, and the bench line's per-instantiation average must lie inside the
+    range of the rows that instantiation serves."""
+    path = os.path.join(P, f"{RND}_gemm_traffic.txt")
+    if not os.path.exists(path):
+        pytest.skip("no per-shape traffic table for this round")
+    rows = [l.split() for l in open(path).read().strip().splitlines()[1:]]
+    table = [l.split()[:8] for l in open(os.path.join(P, f"{RND}_gemm_table.txt")).read().strip().splitlines()[1:]]
+    assert sorted(r[:8] for r in rows) == sorted(t for t in table if int(t[6]) in (128002, 128160, 64002, 3264))
+    measured = 0
+    for r in rows:
+        M, N, K, nz, al, bl, tile, sk = (int(v) for v in r[:8])
+        alg = nz * ((M * K + N * K) * 2 + (M * N * 4 * sk if sk > 1 else M * N * 2)) / 1e6
+        assert abs(alg - float(r[10])) <= 0.06, r
+        if r[11] == "n/a":
+            continue
+        measured += 1
+        assert abs(float(r[11]) / float(r[10]) - float(r[12])) <= 0.03 * float(r[12]) + 0.01 and 0.5 < float(r[12]) < 4.0, r
+    assert measured >= len(rows) - 2
+    line = _bench()["roofline"]
+    m = re.match(r"ff::gemm_bf16_pc_kernel<(\d+), (\d+), (\d), (\d),", line["kernel"])
+    if m and line["traffic"]:
+        bm, bn, al, bl = (int(v) for v in m.groups())
+        code = {(128, 128): 128002, (128, 160): 128160, (64, 64): 64002}[(bm, bn)]
+        mine = [float(r[11]) for r in rows if int(r[6]) == code and int(r[4]) == al and int(r[5]) == bl and r[11] != "n/a"]
+        assert mine and min(mine) * 0.95 <= line["traffic"] / 1e6 <= max(mine) * 1.05, (line["traffic"], mine)
+
+
+def test_hipblaslt_yardstick_covers_every_gemm_shape():
+    path = os.path.join(P, f"{RND}_gemm_yardstick.txt")
+    if not os.path.exists(path):
+        pytest.skip("no yardstick table for this round")
+    rows = [l.split() for l in open(path).read().strip().splitlines()[1:]]
+    table = [l.split()[:8] for l in open(os.path.join(P, f"{RND}_gemm_table.txt")).read().strip().splitlines()[1:]]
+    assert sorted(r[:8] for r in rows) == sorted(table)
+    for r in rows:
+        assert float(r[10]) > 0 and float(r[11]) > 0 and abs(float(r[10]) / float(r[11]) - float(r[12])) <= 0.011, r

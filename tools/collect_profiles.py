@@ -70,7 +70,7 @@ def gemm_kernel_of(tile, al, bl, split):
 if os.path.exists(os.path.join(src, "gemm_table.txt")):
     fetch_g, write_g = pmc_by_grid("pmc_fetch", "FETCH_SIZE"), pmc_by_grid("pmc_write", "WRITE_SIZE")
     lines = ["M N K nz aL bL tile splitK launches/step us/launch algorithmic_MB counter_MB counter/algorithmic   "
-             "(counter = (2 FETCH_SIZE + WRITE_SIZE) KiB per launch of THIS shape; algorithmic = operands read once + output written once, fp32 slabs for split-K)"]
+             "(counter = (2 FETCH_SIZE + WRITE_SIZE) KiB per launch of THIS shape; algorithmic = operands read once + output written once, fp32 slabs for split-K; NOT in the algorithmic column: the epilogue's second tensor (pre-activation saved / read back, residual: +M*N*2 bytes on the M x 5120 rows and the gated outputs), and the per-XCD copies - FETCH_SIZE counts what the eight private L2s request from the fabric, so an operand shared by workgroups on all XCDs is counted up to eight times although the 256 MiB Infinity Cache, not HBM, serves the repeats: for 1024x5120x1280 the cheapest 8-way split is A x 8 + B = 34 MB of reads, which is what the counter shows)"]
     for row in open(os.path.join(src, "gemm_table.txt")).read().strip().splitlines()[1:]:
         M, N, K, nz, al, bl, tile, sk = (int(v) for v in row.split()[:8])
         per_step, us = row.split()[8], row.split()[9]

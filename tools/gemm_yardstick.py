@@ -43,7 +43,7 @@ def main():
     path = sys.argv[1]
     dt = torch.bfloat16
     rows = [l.split() for l in open(path).read().strip().splitlines()[1:]]
-    print("M N K nz aL bL tile splitK launches/step in-model_us ff_isolated_us hipblaslt_us ff/hipblaslt")
+    print("M N K nz aL bL tile splitK launches/step in-model_us ff_isolated_us hipblaslt_us ff/hipblaslt   (isolated columns: plain products on cold weights, no epilogue; rows with nz>1 time the nz products as nz separate launches on BOTH sides and report their sum, while in-model_us is the model's ONE grouped launch)")
     for r in rows:
         M, N, K, nz, al, bl, tile, sk = (int(v) for v in r[:8])
         per_step, in_model_us = r[8], r[9]

@@ -3,7 +3,7 @@ ulimit -c 0   # no core files: a GPU fault must not fill the scratch disk
 # bench.py on every BASELINE.json config: tools/gpu_configs.sh <tag> [configs...]
 tag=$1; shift; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 for c in "$@"; do
-  timeout 600 python bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline --caption-tokens 0 --profile-steps 2 --gemm-table $out/gemm_$c.txt > $out/bench_$c.json 2> $out/bench_$c.err; echo "config $c rc=$?"
+  timeout 600 python bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline --caption-tokens 0 --companions off --profile-steps 2 --gemm-table $out/gemm_$c.txt > $out/bench_$c.json 2> $out/bench_$c.err; echo "config $c rc=$?"
   python - <<P
 import json
 try:

@@ -56,10 +56,14 @@ def build(force: bool = False, verbose: bool = False, debug: bool = False) -> st
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + flags + ["-c", s, "-o", o]
+        cmd = [hipcc] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-4000:]}")
+        # the compiler's register / scratch / occupancy remarks of every kernel of the unit: tools/kernel_resources.py prints them and
+        # tests/test_cabi.py holds the kernels whose co-residency the launch plans assume to their budgets
+        with open(o.replace(".o", ".resources.txt"), "w") as f:
+            f.write("\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" in l) + "\n")
         if verbose:
             print("compiled", os.path.basename(s))
         return o

@@ -446,12 +446,15 @@ template <int BN, int BL, int NW = 4> struct BStage {
     }
 };
 
-// WPC = workgroups per CU the register budget is sized for (2: <= 128 registers per lane, two 8-wave workgroups share a CU)
+// WPC = workgroups per CU the register budget is sized for (2: <= 128 registers per lane, two 8-wave workgroups share a CU).  The second
+//       __launch_bounds__ argument of HIP is WAVES PER SIMD, not workgroups: WPC * waves / 4.  (Until round 4 it said WPC, the <128,128,1,1>
+//       instantiation happened to need 124 registers, and an unrelated edit of tile_coord moved it to 140: one workgroup per CU, the 12-block
+//       weight-gradient launches 189 -> 289 us.  tests/test_cabi.py now reads the compiler's resource remarks.)
 // NPW = producer (DMA) waves: 4, or 8 (a 12-wave workgroup: one MFMA wave and two DMA waves per SIMD)
 // NCW = consumer (MFMA) waves: 4 (2 x 2 over the tile) or 8 (4 x 2: two MFMA waves per SIMD, each on a 32-row slice - one wave's fragment-read
 //       latency is covered by the other's MFMAs instead of being exposed twice per k-step; round 4, the 128 x 160 launches)
 template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4, int NCW = 4>
-__global__ __launch_bounds__((NCW + NPW) * 64, WPC) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
+__global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_bf16_pc_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
                                                            int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;

@@ -217,14 +217,10 @@ FF_DEV int fast_div(int a, int b) {
 // 1024x5120x1280: 103 MB with one row panel per XCD - every L2 pulled the whole weight matrix - vs 15.7 MB algorithmic).
 // The map is a bijection for any grid size: positions are the concatenation of the sub-grids, XCD x takes a contiguous chunk
 // of positions.  Everything here is on the critical path of a ~20 us kernel: shifts and one reciprocal, no integer division.
-// Grouped launches (nz > 1: the weight gradients of up to 12 blocks) take the `walk` order instead: an XCD's chunk of the list is 1-2 whole problems,
-// which it crosses 32-64 tiles at a time, and what decides its L2 traffic is the ORDER inside a problem.  walk = 1 | b_resident << 1 | R << 2: the
-// smaller operand's panels are visited in super-panels of R tiles that stay in the 4 MiB L2 (inner index) while the other operand and the
-// output stream past once per super-panel (outer index).  12-block 1280x5120x1024 launches, 2 x FETCH_SIZE per launch (157 MB of operands): sub-grid
-// order 420 MB (every 10 x 5 sub-grid pulls the 2.6 MB operand again: 50 tiles move 5.5 MB through the L2 between two visits), 1.5 MB budget 316 MB,
-// 3 MB (the whole smaller operand resident) 236 MB; launch time unchanged within +-3 % - the Infinity Cache was serving the repeats.
-FF_DEV TileCoord tile_coord(int nz, int split_k, int xcd, int tiles_m, int tiles_n) {
-    const int ms = xcd & 255, ns = (xcd >> 8) & 255, walk = xcd >> 16;
+// Grouped launches (an XCD's chunk = one or two whole problems) keep this order too: walking a problem with the smaller operand's panels
+// as the inner index (tools/experiments/r4_grouped_resident_panel_walk.patch) cut 2 x FETCH_SIZE of a 12-block weight-gradient launch
+// 416 -> 368 MB but cost 9 % of its time (190 -> 208 us) with two workgroups per CU in flight - profiles/r04_wgrad_walk_ab.txt.
+FF_DEV TileCoord tile_coord(int nz, int split_k, int ms, int ns, int tiles_m, int tiles_n) {
     const int per_z = tiles_m * tiles_n;
     int bid = xcd_remap(blockIdx.x, per_z * split_k * nz);   // == gridDim.x, without the hidden-argument load
     TileCoord c;
@@ -232,18 +228,6 @@ FF_DEV TileCoord tile_coord(int nz, int split_k, int xcd, int tiles_m, int tiles
     if (nz > 1) { c.z = fast_div(bid, per_z * split_k); bid -= c.z * per_z * split_k; }
     if (split_k > 1) { c.split = fast_div(bid, per_z); bid -= c.split * per_z; }
     int p = bid;
-    if (walk) {
-        const int R = walk >> 2;
-        const bool b_res = walk & 2;
-        const int inner = b_res ? tiles_n : tiles_m, outer = b_res ? tiles_m : tiles_n;
-        const int s = fast_div(p, R * outer);
-        p -= s * R * outer;
-        const int rows = min(R, inner - s * R);
-        const int o = fast_div(p, rows), i = s * R + p - o * rows;
-        c.tm = b_res ? o : i;
-        c.tn = b_res ? i : o;
-        return c;
-    }
     const int lm = __builtin_ctz(ms), ln = __builtin_ctz(ns);
     c.tm = 0; c.tn = 0;
     for (int sgrid = 0; sgrid < ms * ns; sgrid++) {
@@ -291,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const void* hA, cons
     const void* opA = hA;
     const void* opB = hB;
     const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
-    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd, tiles_m, tiles_n);
+    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd & 255, h_xcd >> 8, tiles_m, tiles_n);
     if (tc.z > 0) { opA = P.p[tc.z].A; opB = P.p[tc.z].B; }   // grouped launches only: one kernarg round trip
     const int m_base = tc.tm * BM, n_base = tc.tn * BN;
     const int k_begin = tc.split * h_kps;
@@ -448,8 +432,8 @@ template <int BN, int BL, int NW = 4> struct BStage {
 
 // WPC = workgroups per CU the register budget is sized for (2: <= 128 registers per lane, two 8-wave workgroups share a CU).  The second
 //       __launch_bounds__ argument of HIP is WAVES PER SIMD, not workgroups: WPC * waves / 4.  (Until round 4 it said WPC, the <128,128,1,1>
-//       instantiation happened to need 124 registers, and an unrelated edit of tile_coord moved it to 140: one workgroup per CU, the 12-block
-//       weight-gradient launches 189 -> 289 us.  tests/test_cabi.py now reads the compiler's resource remarks.)
+//       instantiation happened to need 124 registers, and an experiment in tile_coord moved it to 140: one workgroup per CU, the 12-block
+//       weight-gradient launches 189 -> 289 us.  tests/test_kernel_resources.py now reads the compiler's resource remarks.)
 // NPW = producer (DMA) waves: 4, or 8 (a 12-wave workgroup: one MFMA wave and two DMA waves per SIMD)
 // NCW = consumer (MFMA) waves: 4 (2 x 2 over the tile) or 8 (4 x 2: two MFMA waves per SIMD, each on a 32-row slice - one wave's fragment-read
 //       latency is covered by the other's MFMAs instead of being exposed twice per k-step; round 4, the 128 x 160 launches)
@@ -473,7 +457,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_
     const void* opA = hA;
     const void* opB = hB;
     const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
-    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd, tiles_m, tiles_n);
+    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd & 255, h_xcd >> 8, tiles_m, tiles_n);
     if (tc.z > 0) { opA = P.p[tc.z].A; opB = P.p[tc.z].B; }
     const int m_base = tc.tm * BM, n_base = tc.tn * BN;
     const int k_begin = tc.split * h_kps;
@@ -715,7 +699,7 @@ template <int AL, int BL> __global__ __launch_bounds__(256) void gemm_f32_kernel
     __shared__ __attribute__((aligned(16))) float sA[kFBK * kFLd];
     __shared__ __attribute__((aligned(16))) float sB[kFBK * kFLd];
     const int tiles_m = (P.M + kFBM - 1) / kFBM, tiles_n = (P.N + kFBM - 1) / kFBM;
-    const TileCoord tc = tile_coord(P.nz, P.split_k, P.xcd_ms | (P.xcd_ns << 8) | (P.xcd_walk << 16), tiles_m, tiles_n);
+    const TileCoord tc = tile_coord(P.nz, P.split_k, P.xcd_ms, P.xcd_ns, tiles_m, tiles_n);
     const GemmProblem& pr = P.p[tc.z];
     const int m_base = tc.tm * kFBM, n_base = tc.tn * kFBM;
     const int k_begin = tc.split * P.k_per_split;
@@ -965,7 +949,7 @@ template <int BM, int BN, int AL, int BL, int NS> static int launch_bf16_dma(con
     const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
     gemm_bf16_dma_kernel<BM, BN, AL, BL, NS><<<dim3(grid), dim3(256), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split, P.nz,
-                                                                           P.xcd_ms | (P.xcd_ns << 8) | (P.xcd_walk << 16), (int)P.a_map.ld, (int)P.b_map.ld, seg, P);
+                                                                           P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld, (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_dma");
 }
 template <int BM, int BN, int NS> static int dispatch_bf16_dma(const GemmParams& P, hipStream_t st) {
@@ -990,7 +974,7 @@ template <int BM, int BN, int AL, int BL, int NS, int WPC, int NPW = 4, int NCW 
     const int grid = cdiv(P.M, BM) * cdiv(P.N, BN) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
     gemm_bf16_pc_kernel<BM, BN, AL, BL, NS, WPC, NPW, NCW><<<dim3(grid), dim3((NCW + NPW) * 64), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split,
-                                                                                 P.nz, P.xcd_ms | (P.xcd_ns << 8) | (P.xcd_walk << 16), (int)P.a_map.ld,
+                                                                                 P.nz, P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld,
                                                                                  (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_pc");
 }
@@ -1093,16 +1077,6 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         }
         static const int disable = env_int("FF_GEMM_XCD2D", 1) == 0;
         if (disable) { P.xcd_ms = 1; P.xcd_ns = 1; }
-        P.xcd_walk = 0;
-        static const int walk_kb = env_int("FF_GEMM_WALK_KB", 3072);       // resident super-panel budget (the A/B switch exists in development builds only; 0 = off)
-        if (P.nz > 1 && walk_kb > 0 && dtype == FF_DTYPE_BF16 && tiles_m * tiles_n >= 64) {
-            const bool b_res = P.N < P.M;
-            const int inner = b_res ? tiles_n : tiles_m;
-            const long long panel = (long long)(b_res ? tn_edge : tm_edge) * P.K * 2;
-            int R = (int)std::max(1LL, std::min<long long>(inner, walk_kb * 1024LL / panel));
-            R = cdiv(inner, cdiv(inner, R));                                 // equal super-panels
-            P.xcd_walk = 1 | (b_res ? 2 : 0) | (R << 2);
-        }
     }
     const int vec = dtype == FF_DTYPE_BF16 ? 8 : 4;
     auto map_ok = [&](const RowMap& m) { return m.ld % vec == 0 && (m.rows_per_seg <= 0 || m.seg_stride % vec == 0); };

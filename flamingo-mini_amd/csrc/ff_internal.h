@@ -27,7 +27,6 @@ struct GemmParams {
     int tile;   // block tile chosen by the host (bf16: 128 = 128x128, 64 = 64x64, 6412 = 64x128, 128002 / 128160 = producer / consumer kernels)
     int force_tile, force_stages;   // explicit plan override from the descriptor (0 = automatic)
     int xcd_ms, xcd_ns;   // XCD partition of the tile grid (ms * ns sub-grids, one per XCD)
-    int xcd_walk;         // grouped launches: resident-panel order inside a problem (tile_coord), 0 = the sub-grid order
     float* partial;
     int a_vec_ok, b_vec_ok;
     int c_vec8;   // bf16 epilogue may use 16-byte accesses on C / aux / residual

@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--companions", default="auto", choices=["auto", "on", "off"],
                     help="N=1 only: after the main measurement, re-run the same workload in child processes (a) with the op substitutions inside the "
                          "backbones + the tuning file, (b) with the fp32-master / fp32-moment optimizer, and add both to the JSON line (auto = on for the default config B run)")
+    ap.add_argument("--pace", default="host", choices=["host", "stream"],
+                    help="piecewise replay: host = the host waits for a backward segment and then issues its collectives (default; no barrier packet waits in a "
+                         "hardware queue beside the compute queue), stream = collectives enqueued right behind the segment's graph, ordered by an event wait")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off", "piecewise"],
                     help="replay the step from captured HIP graphs.  piecewise = one sub-graph per backward segment of 4 gated layers, the RCCL collectives "
                          "issued eagerly between the replays; on = the whole step incl. its collectives in ONE graph; auto = on at N = 1, piecewise -> on -> "
@@ -534,7 +537,7 @@ def main():
                 if mode == "full":
                     graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer)
                 else:
-                    graphed = PiecewiseGraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer)
+                    graphed = PiecewiseGraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer, pace=args.pace)
             except Exception as e:
                 if world == 1 and not collectives and args.graph in ("on", "piecewise"):
                     raise
@@ -573,10 +576,22 @@ def main():
         if i == 0:
             loss_first = loss.detach().clone()      # (the replayed graph overwrites its static loss tensor every step)
     loss_last = loss.detach().clone()
-    torch.cuda.synchronize()
+    host_issue_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)      # how long the host needed to ISSUE a step (a replayed step that is
+    torch.cuda.synchronize()                                                    # as long as its GPU time is launch-bound)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    piecewise_host = None
+    if graph_mode == "piecewise" and hasattr(step, "host_timing"):      # host seconds by kind of call over 5 more steps (launch-bound or not, and by what)
+        step.host_timing = {}
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        n = max(step.host_timing.pop("steps", 1), 1)
+        piecewise_host = {k: round(v * 1e3 / n, 3) for k, v in step.host_timing.items()}
+        piecewise_host["sub_graphs"] = len(step.graphs) + (1 if step._opt_graph is not None else 0)
+        piecewise_host["collectives_issued"] = sum(len(b) for b in step.segment_buckets)
+        step.host_timing = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -707,7 +722,7 @@ def main():
                        # ("the loss printed by the bench"); `loss` = after the instrumented eager steps that follow
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
-                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives),
+                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
                        "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,

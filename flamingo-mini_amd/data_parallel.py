@@ -108,9 +108,42 @@ class GradientAllReducer:
 
     def reduce_bucket(self, flat: torch.Tensor, owners) -> None:
         """Exchange one recorded bucket now (its producers are already enqueued on the current stream)."""
-        if self.active:
+        self.reduce_buckets([(flat, owners)])
+
+    def reduce_buckets(self, buckets, producers_done: bool = False) -> None:
+        """Exchange the recorded buckets of one backward segment, all of whose producers are already enqueued on the current stream: ONE
+        ready / done event pair for the segment (the piecewise step used to pay a pair per bucket: 94 events and as many cross-stream waits
+        per step), the collectives back to back on the side stream.
+        producers_done=True: the caller has SEEN the producers finish (it synchronised with an event behind them), so the side stream needs
+        no wait - see PiecewiseGraphedTrainStep(pace="host") for why that is worth a host round trip."""
+        if not self.active or not buckets:
+            return
+        for _, owners in buckets:
             self._early.update(id(p) for p, _, _ in owners)
-            self._reduce_async(flat, list(owners))
+        if not self.cuda:
+            for flat, owners in buckets:
+                self._reduce_async(flat, list(owners))
+            return
+        timed = self.timeline is not None
+        ready = torch.cuda.Event(enable_timing=timed)
+        if not producers_done:
+            ready.record()
+        with torch.cuda.stream(self.stream):
+            if producers_done:
+                ready.record()                               # (timeline only: when the exchange was issued)
+            else:
+                self.stream.wait_event(ready)
+            for flat, _ in buckets:
+                flat.record_stream(self.stream)
+                self._mean_in_place(flat)
+            done = torch.cuda.Event(enable_timing=timed)
+            done.record()
+        work = _StreamWork(done)
+        for i, (flat, owners) in enumerate(buckets):
+            if timed:
+                label = next((n for n, q in self._names.items() if owners and q is owners[0][0]), None) or ("loose" if not owners else "bucket")
+                self.timeline.append((label, flat.numel() * flat.element_size(), ready, done))
+            self.pending.append((flat, work if i == 0 else _StreamWork(None), list(owners)))
 
     def record_timeline(self, on: bool = True) -> None:
         """GPU only: keep (label, bytes, ready, done) event pairs of every bucket exchanged from now on - `timeline_ms()` after a

@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Optional
 
+import time
+
 import torch
 
 
@@ -150,6 +152,15 @@ class PiecewiseGraphedTrainStep:
     that segment was captured: the flat gradient buffers are static) are handed to the reducer, which all-reduces them on its side
     stream while the next segment's graph runs; the optimizer graph is launched after reducer.finish().  Nothing here needs RCCL kernels to
     be capturable, and a rank that cannot capture a piece can run that piece eagerly without changing the protocol between ranks.
+
+    pace="host" (default): ALL sub-graphs of the step are enqueued first; then the host waits for segment k's event and only then issues
+    segment k's collectives (the last segment's stay stream-ordered, so that finish() and the optimizer graph are enqueued without waiting
+    for the GPU).  pace="stream" issues every segment's collectives right behind its graph launch, ordered by a cross-stream event wait.
+    The stream-ordered form looks free and is not: a barrier packet that sits unsatisfied in the side queue for the length of a segment slows
+    the dispatch of the compute queue's thousands of short kernels - measured on one MI355X with the exchange going through a 1-rank RCCL
+    group (tools/sessions/r4/rccl_variants.py): a wait alone, nothing behind it, 41.2 -> 42.9 ms per step, independent of how many
+    segments wait; host-paced 41.4.  The price is that __call__ returns when the GPU is in the last backward segment instead of
+    immediately; the next step's forward graph is enqueued while the last segment and the optimizer run.
     `capture=False` runs the same segmented step with eager launches (CPU / gloo tests of the segmentation; a debugging aid on the GPU).
 
     The model must offer `install_autograd_cuts(cuts, segment_layers)` (FlamingoModel / FlamingoBaseModel do: the visual features and the
@@ -157,8 +168,12 @@ class PiecewiseGraphedTrainStep:
     structure the reducer sets (4 layers per weight-gradient group and per K / V projection call), which is the default."""
 
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
-                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, segment_layers: int = 4, capture: bool = True):
+                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, segment_layers: int = 4, capture: bool = True,
+                 pace: str = "host"):
+        if pace not in ("host", "stream"):
+            raise ValueError("pace must be 'host' or 'stream'")
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
+        self.pace = pace
         self.capture = bool(capture)
         self._loss_fn = loss_fn or (lambda out: out.loss)
         self.cuts = AutogradCuts()
@@ -168,6 +183,7 @@ class PiecewiseGraphedTrainStep:
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self.graphs = []
         self.segment_buckets = []
+        self.host_timing: Optional[dict] = None
         if not self.capture:
             self.loss = None
             return
@@ -245,13 +261,46 @@ class PiecewiseGraphedTrainStep:
             return self.loss
         if self.optimizer is not None and hasattr(self.optimizer, "sync_device_hyperparams"):
             self.optimizer.sync_device_hyperparams()
+        ht = self.host_timing                               # None, or a dict that accumulates the HOST seconds of each kind of call
+        t0 = time.perf_counter() if ht is not None else 0.0
         self.graphs[0].replay()
-        for g, buckets in zip(self.graphs[1:], self.segment_buckets):
-            g.replay()
-            for flat, owners in buckets:                    # eager collectives on the reducer's side stream, behind this segment
-                self.reducer.reduce_bucket(flat, owners)
+        host_paced = self.pace == "host" and self.reducer is not None and getattr(self.reducer, "cuda", False) and getattr(self.reducer, "active", False)
+        if host_paced:
+            events = []
+            for g in self.graphs[1:]:
+                g.replay()
+                e = torch.cuda.Event()
+                e.record()
+                events.append(e)
+            if ht is not None:
+                t1 = time.perf_counter(); ht["graph_launches"] = ht.get("graph_launches", 0.0) + t1 - t0; t0 = t1
+            with_buckets = [i for i, b in enumerate(self.segment_buckets) if b]
+            for i in with_buckets:
+                if i != with_buckets[-1]:
+                    events[i].synchronize()                 # the host sees segment i finish; nothing waits inside a hardware queue
+                    if ht is not None:
+                        t1 = time.perf_counter(); ht["host_waits"] = ht.get("host_waits", 0.0) + t1 - t0; t0 = t1
+                    self.reducer.reduce_buckets(self.segment_buckets[i], producers_done=True)
+                else:
+                    self.reducer.reduce_buckets(self.segment_buckets[i])
+                if ht is not None:
+                    t1 = time.perf_counter(); ht["collectives"] = ht.get("collectives", 0.0) + t1 - t0; t0 = t1
+        else:
+            for g, buckets in zip(self.graphs[1:], self.segment_buckets):
+                g.replay()
+                if ht is not None:
+                    t1 = time.perf_counter(); ht["graph_launches"] = ht.get("graph_launches", 0.0) + t1 - t0; t0 = t1
+                if buckets:                                     # eager collectives on the reducer's side stream, behind this segment
+                    self.reducer.reduce_buckets(buckets)
+                if ht is not None:
+                    t1 = time.perf_counter(); ht["collectives"] = ht.get("collectives", 0.0) + t1 - t0; t0 = t1
         if self.reducer is not None:
             self.reducer.finish()
+        if ht is not None:
+            t1 = time.perf_counter(); ht["finish"] = ht.get("finish", 0.0) + t1 - t0; t0 = t1
         if self._opt_graph is not None:
             self._opt_graph.replay()
+        if ht is not None:
+            ht["graph_launches"] = ht.get("graph_launches", 0.0) + time.perf_counter() - t0
+            ht["steps"] = ht.get("steps", 0) + 1
         return self.loss

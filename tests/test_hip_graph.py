@@ -204,8 +204,9 @@ def test_capture_after_an_eager_forward_of_the_same_model(mode, expect):
 def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(one_rank_rccl, dtype):
     """graphs.PiecewiseGraphedTrainStep on the full drop-in model (h64 fixture geometry: fused kernels, hoisted K / V, deferred weight
     gradients) with the gradient exchange going through RCCL on a 1-rank group: forward | one backward sub-graph per gated layer |
-    resampler backward | optimizer, all-reduces issued eagerly between the replays.  Three arms from the same initial state - eager
-    launches, the whole step captured with its collectives, the piecewise replay - must produce the same losses and parameters."""
+    resampler backward | optimizer, all-reduces issued eagerly between the replays.  Four arms from the same initial state - eager
+    launches, the whole step captured with its collectives, the piecewise replay with host-paced and with stream-ordered collectives -
+    must produce the same losses and parameters."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_model_plumbing import H64, build_h64
@@ -213,7 +214,7 @@ def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(on
     from flamingo_mini_amd.data_parallel import GradientAllReducer
     from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
     base, z, batch = build_h64(dtype, "cuda")
-    arms = {"eager": base, "full": copy.deepcopy(base), "piecewise": copy.deepcopy(base)}
+    arms = {"eager": base, "full": copy.deepcopy(base), "piecewise": copy.deepcopy(base), "piecewise_stream_paced": copy.deepcopy(base)}
     n_steps, losses, finals = 4, {}, {}
     for name, model in arms.items():
         params = [p for p in model.parameters_trainable()]
@@ -231,9 +232,9 @@ def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(on
                 out.append(float(loss))
         else:
             cls = GraphedTrainStep if name == "full" else PiecewiseGraphedTrainStep
-            kw = {} if name == "full" else {"segment_layers": 1}
+            kw = {} if name == "full" else {"segment_layers": 1, "pace": "stream" if name.endswith("stream_paced") else "host"}
             step = cls(model, opt, batch, warmup=1, reducer=reducer, **kw)        # (the constructor's warm-up is training step 1)
-            if name == "piecewise":
+            if name.startswith("piecewise"):
                 assert len(step.graphs) == 1 + 3 and sum(len(b) for b in step.segment_buckets) >= 4      # forward + 3 backward segments; blocks, to_kv, resampler, embedding
             out = [None] + [float(step()) for _ in range(n_steps - 1)]
         torch.cuda.synchronize()
@@ -241,7 +242,7 @@ def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(on
         losses[name] = out
         finals[name] = {k: p.detach().float().clone() for k, p in model.named_parameters() if p.requires_grad}
     tol = 2e-5 if dtype == torch.float32 else 3e-2
-    for name in ("full", "piecewise"):
+    for name in ("full", "piecewise", "piecewise_stream_paced"):
         for a, b in zip(losses["eager"][1:], losses[name][1:]):
             assert abs(a - b) <= tol * max(1.0, abs(a)), (name, losses)
         for k, v in finals["eager"].items():

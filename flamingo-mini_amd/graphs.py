@@ -163,17 +163,32 @@ class PiecewiseGraphedTrainStep:
     immediately; the next step's forward graph is enqueued while the last segment and the optimizer run.
     `capture=False` runs the same segmented step with eager launches (CPU / gloo tests of the segmentation; a debugging aid on the GPU).
 
+    overlap_optimizer=True (host pacing only; the optimizer must accept `step(only=ids, advance=bool)`, FusedAdamW with capturable=True does):
+    the optimizer is captured as one sub-graph per backward segment - the parameters whose gradient became FINAL in that segment (the tied
+    token embedding, which two segments accumulate into, belongs to the later one) - and segment k's update is launched on the side stream,
+    behind segment k's collectives, as soon as the host has seen segment k finish: the HBM-bound AdamW sweep runs beside the latency-bound
+    backward of the layers below instead of after it.  Nothing that still runs in the step reads those weights (a backward segment reads
+    the weights of its own layers only; the K / V projection of a layer group has its backward inside that group's segment).  The last
+    segment's update stays on the calling stream, and the calling stream waits for the side stream at the end of the call, so the usual
+    stream semantics hold for whoever reads the parameters next.
+
     The model must offer `install_autograd_cuts(cuts, segment_layers)` (FlamingoModel / FlamingoBaseModel do: the visual features and the
     hidden state in front of every `segment_layers`-th gated layer become cut points).  Segment boundaries should coincide with the bucket
     structure the reducer sets (4 layers per weight-gradient group and per K / V projection call), which is the default."""
 
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
                  warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, segment_layers: int = 4, capture: bool = True,
-                 pace: str = "host"):
+                 pace: str = "host", overlap_optimizer: bool = False):
         if pace not in ("host", "stream"):
             raise ValueError("pace must be 'host' or 'stream'")
+        if overlap_optimizer and (pace != "host" or not capture):
+            raise ValueError("overlap_optimizer needs pace='host' and capture=True")
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
         self.pace = pace
+        self.overlap_optimizer = bool(overlap_optimizer) and optimizer is not None
+        self._opt_pieces = []          # overlap_optimizer: one optimizer sub-graph per backward segment (None where nothing became final)
+        self._side = None
+        self._side_done = None
         self.capture = bool(capture)
         self._loss_fn = loss_fn or (lambda out: out.loss)
         self.cuts = AutogradCuts()
@@ -212,11 +227,19 @@ class PiecewiseGraphedTrainStep:
         self.cuts.reset()
         loss = piece(lambda: self._loss_fn(self.model(**self.static)))
         self.loss = loss.detach()
-        for seg in self.cuts.segments(loss):
+        trainable = [p for p in model.parameters() if p.requires_grad]
+        last_touched, seen = {}, {}
+        for k, seg in enumerate(self.cuts.segments(loss)):
             if reducer is not None:
                 reducer.begin_collect()
             piece(seg)
             self.segment_buckets.append(reducer.end_collect() if reducer is not None else [])
+            for p in trainable:                 # which segment wrote (or accumulated into) which gradient
+                if p.grad is not None:
+                    mark = (p.grad.data_ptr(), p.grad._version)
+                    if seen.get(id(p)) != mark:
+                        seen[id(p)] = mark
+                        last_touched[id(p)] = k
         if reducer is not None:        # an un-fused parameter (the tied token embedding) takes part in two segments: exchange it after the last one
             seen = set()
             for buckets in reversed(self.segment_buckets):
@@ -224,7 +247,19 @@ class PiecewiseGraphedTrainStep:
                 seen.update(b[0].data_ptr() for b in buckets if not b[1])
                 buckets[:] = keep
         self._opt_graph = None
-        if optimizer is not None:
+        if self.overlap_optimizer:
+            n_seg = len(self.segment_buckets)
+            final_in = [frozenset(i for i, k in last_touched.items() if k == seg) for seg in range(n_seg)]
+            first = True
+            for ids in final_in:
+                if not ids:
+                    self._opt_pieces.append(None)
+                    continue
+                piece(lambda ids=ids, first=first: optimizer.step(only=ids, advance=first))
+                self._opt_pieces.append(self.graphs.pop())
+                first = False
+            self._side = reducer.stream if (reducer is not None and getattr(reducer, "cuda", False)) else torch.cuda.Stream()
+        elif optimizer is not None:
             piece(optimizer.step)
             self._opt_graph = self.graphs.pop()
         del loss
@@ -263,6 +298,8 @@ class PiecewiseGraphedTrainStep:
             self.optimizer.sync_device_hyperparams()
         ht = self.host_timing                               # None, or a dict that accumulates the HOST seconds of each kind of call
         t0 = time.perf_counter() if ht is not None else 0.0
+        if self.overlap_optimizer:
+            return self._replay_overlapped(ht, t0)
         self.graphs[0].replay()
         host_paced = self.pace == "host" and self.reducer is not None and getattr(self.reducer, "cuda", False) and getattr(self.reducer, "active", False)
         if host_paced:
@@ -302,5 +339,51 @@ class PiecewiseGraphedTrainStep:
             self._opt_graph.replay()
         if ht is not None:
             ht["graph_launches"] = ht.get("graph_launches", 0.0) + time.perf_counter() - t0
+            ht["steps"] = ht.get("steps", 0) + 1
+        return self.loss
+
+    def _replay_overlapped(self, ht, t0) -> torch.Tensor:
+        """overlap_optimizer=True: forward | all backward segments enqueued | per segment, once the host has seen it finish: its collectives,
+        then its optimizer sub-graph, on the side stream | last segment: collectives, finish(), update on the calling stream."""
+        red = self.reducer if (self.reducer is not None and getattr(self.reducer, "cuda", False) and getattr(self.reducer, "active", False)) else None
+        main = torch.cuda.current_stream()
+        self.graphs[0].replay()                              # (the previous call ended with this stream waiting for the side stream)
+        events = []
+        for g in self.graphs[1:]:
+            g.replay()
+            e = torch.cuda.Event()
+            e.record()
+            events.append(e)
+        if ht is not None:
+            t1 = time.perf_counter(); ht["graph_launches"] = ht.get("graph_launches", 0.0) + t1 - t0; t0 = t1
+        work = [i for i in range(len(events)) if self._opt_pieces[i] is not None or (red is not None and self.segment_buckets[i])]
+        progress = None
+        for i in work[:-1]:
+            events[i].synchronize()                         # the host sees segment i finish; nothing waits inside a hardware queue
+            if ht is not None:
+                t1 = time.perf_counter(); ht["host_waits"] = ht.get("host_waits", 0.0) + t1 - t0; t0 = t1
+            if red is not None and self.segment_buckets[i]:
+                red.reduce_buckets(self.segment_buckets[i], producers_done=True)
+            if self._opt_pieces[i] is not None:
+                with torch.cuda.stream(self._side):         # behind segment i's collectives: same stream
+                    self._opt_pieces[i].replay()
+                    progress = torch.cuda.Event()
+                    progress.record()
+            if ht is not None:
+                t1 = time.perf_counter(); ht["collectives"] = ht.get("collectives", 0.0) + t1 - t0; t0 = t1
+        if work:
+            i = work[-1]
+            if red is not None and self.segment_buckets[i]:
+                red.reduce_buckets(self.segment_buckets[i])
+            if red is not None:
+                red.finish()
+            if progress is not None:
+                main.wait_event(progress)                    # the first partial update advanced the step counters; and: end-of-call stream semantics
+            if self._opt_pieces[i] is not None:
+                self._opt_pieces[i].replay()
+        elif red is not None:
+            red.finish()
+        if ht is not None:
+            ht["finish"] = ht.get("finish", 0.0) + time.perf_counter() - t0
             ht["steps"] = ht.get("steps", 0) + 1
         return self.loss

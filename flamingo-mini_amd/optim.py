@@ -34,17 +34,25 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale, capturable=capturable))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, *, only=None, advance: bool = True):
+        """only / advance (capturable mode): update just the parameters whose id() is in `only` - one of several calls that together cover every
+        parameter with a gradient exactly once per training step (graphs.PiecewiseGraphedTrainStep(overlap_optimizer=True) updates the
+        parameters of a backward segment while the next segments still run).  The FIRST partial call of a training step passes advance=True
+        (the device step counters count training steps, not calls) and must execute before the others."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = ffi.lib()
+        if only is not None:
+            only = frozenset(only)
+            if not all(g.get("capturable", False) for g in self.param_groups):
+                raise ValueError("FusedAdamW.step(only=...) needs capturable=True (step counts live in device scalars shared by the partial calls)")
         for gi, group in enumerate(self.param_groups):
             capturable = group.get("capturable", False)
-            if capturable:
+            if capturable and advance:
                 self._advance_device_steps(group)
-            for bucket in self._buckets(gi, group):
+            for bucket in self._buckets(gi, group, only):
                 params, grad_ptrs, n = bucket["params"], bucket["grad_ptrs"], len(bucket["params"])
                 for i, p in enumerate(params):           # only the gradient addresses change from step to step
                     g = p.grad
@@ -73,13 +81,14 @@ class FusedAdamW(torch.optim.Optimizer):
                     t.fill_(float(group["lr"]))
                     group.setdefault("_lr_on_dev", {})[dev] = group["lr"]
 
-    def _buckets(self, gi, group):
+    def _buckets(self, gi, group, only=None):
         """Parameters with a gradient, grouped by (dtype, device, step count); the pointer tables of everything that does not
         change between steps (parameters, moments, sizes) are built once and reused while the same parameters have gradients."""
-        active = [p for p in group["params"] if p.grad is not None]
+        active = [p for p in group["params"] if p.grad is not None and (only is None or id(p) in only)]
         cache = self.__dict__.setdefault("_bucket_cache", {})
         key = tuple(id(p) for p in active)
-        hit = cache.get(gi)
+        slot = gi if only is None else (gi, only)
+        hit = cache.get(slot)
         if hit is not None and hit[0] == key and all(b["param_ptrs"][0] == b["params"][0].data_ptr() for b in hit[1]):
             return hit[1]
         self._sync_host_steps()
@@ -108,7 +117,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                 m_ptrs=ffi.ptr_array([self.state[p]["exp_avg"] for p in params]),
                                 v_ptrs=ffi.ptr_array([self.state[p]["exp_avg_sq"] for p in params]),
                                 numels=(C.c_longlong * n)(*[p.numel() for p in params])))
-        cache[gi] = (key, buckets)
+        cache[slot] = (key, buckets)
         return buckets
 
     # ------------------------------------------------------------------ capturable mode

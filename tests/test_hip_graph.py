@@ -204,9 +204,10 @@ def test_capture_after_an_eager_forward_of_the_same_model(mode, expect):
 def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(one_rank_rccl, dtype):
     """graphs.PiecewiseGraphedTrainStep on the full drop-in model (h64 fixture geometry: fused kernels, hoisted K / V, deferred weight
     gradients) with the gradient exchange going through RCCL on a 1-rank group: forward | one backward sub-graph per gated layer |
-    resampler backward | optimizer, all-reduces issued eagerly between the replays.  Four arms from the same initial state - eager
-    launches, the whole step captured with its collectives, the piecewise replay with host-paced and with stream-ordered collectives -
-    must produce the same losses and parameters."""
+    resampler backward | optimizer, all-reduces issued eagerly between the replays.  Five arms from the same initial state - eager
+    launches, the whole step captured with its collectives, the piecewise replay with host-paced and with stream-ordered collectives, and
+    with the optimizer split into per-segment sub-graphs that run beside the backward of the layers below - must produce the same losses
+    and parameters."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_model_plumbing import H64, build_h64
@@ -214,7 +215,8 @@ def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(on
     from flamingo_mini_amd.data_parallel import GradientAllReducer
     from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
     base, z, batch = build_h64(dtype, "cuda")
-    arms = {"eager": base, "full": copy.deepcopy(base), "piecewise": copy.deepcopy(base), "piecewise_stream_paced": copy.deepcopy(base)}
+    arms = {"eager": base, "full": copy.deepcopy(base), "piecewise": copy.deepcopy(base), "piecewise_stream_paced": copy.deepcopy(base),
+            "piecewise_overlapped_optimizer": copy.deepcopy(base)}
     n_steps, losses, finals = 4, {}, {}
     for name, model in arms.items():
         params = [p for p in model.parameters_trainable()]
@@ -232,8 +234,11 @@ def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(on
                 out.append(float(loss))
         else:
             cls = GraphedTrainStep if name == "full" else PiecewiseGraphedTrainStep
-            kw = {} if name == "full" else {"segment_layers": 1, "pace": "stream" if name.endswith("stream_paced") else "host"}
+            kw = {} if name == "full" else {"segment_layers": 1, "pace": "stream" if name.endswith("stream_paced") else "host",
+                                            "overlap_optimizer": name.endswith("overlapped_optimizer")}
             step = cls(model, opt, batch, warmup=1, reducer=reducer, **kw)        # (the constructor's warm-up is training step 1)
+            if name.endswith("overlapped_optimizer"):      # one optimizer sub-graph per segment in which a gradient became final
+                assert sum(g is not None for g in step._opt_pieces) >= 3 and step._opt_graph is None
             if name.startswith("piecewise"):
                 assert len(step.graphs) == 1 + 3 and sum(len(b) for b in step.segment_buckets) >= 4      # forward + 3 backward segments; blocks, to_kv, resampler, embedding
             out = [None] + [float(step()) for _ in range(n_steps - 1)]
@@ -242,8 +247,47 @@ def test_piecewise_graphs_with_eager_collectives_equal_eager_and_full_capture(on
         losses[name] = out
         finals[name] = {k: p.detach().float().clone() for k, p in model.named_parameters() if p.requires_grad}
     tol = 2e-5 if dtype == torch.float32 else 3e-2
-    for name in ("full", "piecewise", "piecewise_stream_paced"):
+    for name in ("full", "piecewise", "piecewise_stream_paced", "piecewise_overlapped_optimizer"):
         for a, b in zip(losses["eager"][1:], losses[name][1:]):
             assert abs(a - b) <= tol * max(1.0, abs(a)), (name, losses)
         for k, v in finals["eager"].items():
             assert rel(finals[name][k], v) < (1e-4 if dtype == torch.float32 else 3e-2), (name, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_piecewise_overlapped_optimizer_without_a_reducer_equals_eager_steps(dtype):
+    """The single-GPU form of PiecewiseGraphedTrainStep(overlap_optimizer=True): no reducer, the per-segment AdamW sub-graphs run on a side
+    stream beside the backward segments below them.  Same losses and parameters as eager steps; the tied token embedding (gradient from the
+    head in the top segment AND from the lookup in the bottom one) must be updated once, after the later of the two."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_model_plumbing import H64, build_h64
+    from flamingo_mini_amd import FusedAdamW
+    from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
+    base, z, batch = build_h64(dtype, "cuda")
+    arms = {"eager": base, "overlapped": copy.deepcopy(base)}
+    n_steps, losses, finals = 5, {}, {}
+    for name, model in arms.items():
+        opt = FusedAdamW([p for p in model.parameters_trainable()], capturable=name != "eager", **H64["adamw"])
+        if name == "eager":
+            out = []
+            for _ in range(n_steps):
+                model.zero_grad(set_to_none=True)
+                loss = model(**batch).loss
+                loss.backward()
+                opt.step()
+                out.append(float(loss))
+        else:
+            step = PiecewiseGraphedTrainStep(model, opt, batch, warmup=1, segment_layers=1, overlap_optimizer=True)
+            pieces = [g for g in step._opt_pieces if g is not None]
+            assert len(pieces) >= 3
+            out = [None] + [float(step()) for _ in range(n_steps - 1)]
+            torch.cuda.current_stream().synchronize()       # (stream semantics: the calling stream has waited for the side stream)
+        torch.cuda.synchronize()
+        losses[name] = out
+        finals[name] = {k: p.detach().float().clone() for k, p in model.named_parameters() if p.requires_grad}
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    for a, b in zip(losses["eager"][1:], losses["overlapped"][1:]):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), losses
+    for k, v in finals["eager"].items():
+        assert rel(finals["overlapped"][k], v) < (1e-4 if dtype == torch.float32 else 3e-2), k

@@ -80,6 +80,53 @@ def test_fused_adamw_capturable_and_graph_replay():
     assert "_step_dev" not in o_graph.state_dict()["param_groups"][0]
 
 
+def test_fused_adamw_partial_steps_cover_a_step():
+    """step(only=ids, advance=...) (capturable mode): three partial calls that together cover the parameters once - the first one advancing the
+    device step counter - equal one whole step, eagerly and as three captured sub-graphs replayed in order (what
+    graphs.PiecewiseGraphedTrainStep(overlap_optimizer=True) launches per backward segment); host-step mode refuses partial calls."""
+    from flamingo_mini_amd import FusedAdamW
+    shapes = [(129,), (64, 40), (8191,), (1,), (513, 7)]
+
+    def make():
+        ps = [torch.nn.Parameter(dev(rnd(s, 10 + i))) for i, s in enumerate(shapes)]
+        for i, p in enumerate(ps):
+            p.grad = dev(rnd(shapes[i], 20 + i, 0.1))
+        return ps
+
+    whole, parts, graphed = make(), make(), make()
+    o_w = FusedAdamW(whole, lr=1e-2, weight_decay=0.1, capturable=True)
+    o_p = FusedAdamW(parts, lr=1e-2, weight_decay=0.1, capturable=True)
+    o_g = FusedAdamW(graphed, lr=1e-2, weight_decay=0.1, capturable=True)
+    split = lambda ps: [frozenset(id(p) for p in ps[:2]), frozenset(id(p) for p in ps[2:3]), frozenset(id(p) for p in ps[3:])]
+    for _ in range(3):
+        o_w.step()
+        for k, ids in enumerate(split(parts)):
+            o_p.step(only=ids, advance=k == 0)
+    for a, b in zip(whole, parts):
+        assert torch.equal(a, b)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        o_g.step()                                    # step 1 eagerly (allocates the state and the device counters)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    pieces = []
+    for k, ids in enumerate(split(graphed)):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            o_g.step(only=ids, advance=k == 0)
+        pieces.append(g)
+    for _ in range(2):
+        for g in pieces:
+            g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(whole, graphed):
+        assert rel(a, b) < 1e-6
+    assert {float(st["step"]) for st in o_g.state_dict()["state"].values()} == {3.0}
+    with pytest.raises(ValueError):
+        FusedAdamW(make(), lr=1e-2).step(only=frozenset(), advance=True)
+
+
 def test_fused_adamw_fp32_master_weights_keep_small_updates():
     """master_dtype=fp32 (what the reference's `--fp16` autocast training keeps, training/train.sh:24): the fp32 master copy follows the
     float64 AdamW rule and the bf16 parameter is its rounding; with bf16-only storage the same small steps (lr 1e-4 on weights ~1) are

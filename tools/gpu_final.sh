@@ -26,12 +26,12 @@ if [ -x $P ]; then for a in "32 5120 1280 20 1 1" "32 5120 1280 20 1 0" "32 1280
 ( python tools/decode_chain_bench.py 2>&1 | tail -1; for v in "FF_DECODE_FFW=0" "FF_DECODE_FFW=1"; do ( export FLAMINGO_FUSION_LIB=debug $v; echo "[development build, $v] $(python tools/decode_chain_bench.py 2>&1 | tail -1)" ); done ) > $out/decode_chain.txt
 cat $out/decode_chain.txt
 B2="python bench.py --no-cpu-baseline --caption-tokens 0 --profile-steps 0 --companions off --steps 12 --warmup 3"
-( for g in on piecewise off; do timeout 300 $B2 --graph $g --force-collectives --bucket-timeline 2> /dev/null | python -c "
+( for g in on piecewise "piecewise --pace stream --overlap-optimizer off" off; do timeout 300 $B2 --graph $g --force-collectives --bucket-timeline 2> /dev/null | python -c "
 import sys, json
 d = next(json.loads(l) for l in reversed(sys.stdin.read().strip().splitlines()) if l.startswith('{'))
 bt = d.get('bucket_timeline') or {}
-print('graph=$g, gradient exchange through a 1-rank RCCL group:', d['value'], 'images/s', d['ms_per_step'], 'ms/step, mode', d['config']['graph_mode'], '| eager timeline step: backward', bt.get('backward_ms'), 'ms, exchange finished', bt.get('exchange_finished_ms'), 'ms, exposed', bt.get('exposed_communication_ms'), 'ms,', len(bt.get('buckets', [])), 'buckets')
-if '$g' == 'piecewise':
+print('graph=$g, gradient exchange through a 1-rank RCCL group:', d['value'], 'images/s', d['ms_per_step'], 'ms/step, mode', d['config']['graph_mode'], 'pace', d['config'].get('collective_pace'), 'overlapped optimizer', d['config'].get('overlapped_optimizer'), '| eager timeline step: backward', bt.get('backward_ms'), 'ms, exchange finished', bt.get('exchange_finished_ms'), 'ms, exposed', bt.get('exposed_communication_ms'), 'ms,', len(bt.get('buckets', [])), 'buckets')
+if '$g' == 'off':
     for r in bt.get('buckets', []): print('   ', r)
 "; done
   timeout 300 $B2 --graph on 2> /dev/null | python -c "

@@ -596,7 +596,7 @@ def main():
         torch.cuda.synchronize()
         n = max(step.host_timing.pop("steps", 1), 1)
         piecewise_host = {k: round(v * 1e3 / n, 3) for k, v in step.host_timing.items()}
-        piecewise_host["sub_graphs"] = len(step.graphs) + (1 if step._opt_graph is not None else 0)
+        piecewise_host["sub_graphs"] = len(step.graphs) + (1 if step._opt_graph is not None else 0) + sum(g is not None for g in step._opt_pieces)
         piecewise_host["collectives_issued"] = sum(len(b) for b in step.segment_buckets)
         step.host_timing = None
     if world > 1:

@@ -345,7 +345,7 @@ class PiecewiseGraphedTrainStep:
     def _replay_overlapped(self, ht, t0) -> torch.Tensor:
         """overlap_optimizer=True: forward | all backward segments enqueued | per segment, once the host has seen it finish: its collectives,
         then its optimizer sub-graph, on the side stream | last segment: collectives, finish(), update on the calling stream."""
-        red = self.reducer if (self.reducer is not None and getattr(self.reducer, "cuda", False) and getattr(self.reducer, "active", False)) else None
+        red = self.reducer if (self.reducer is not None and getattr(self.reducer, "active", False)) else None      # (a gloo reducer exchanges synchronously)
         main = torch.cuda.current_stream()
         self.graphs[0].replay()                              # (the previous call ended with this stream waiting for the side stream)
         events = []
@@ -363,7 +363,11 @@ class PiecewiseGraphedTrainStep:
             if ht is not None:
                 t1 = time.perf_counter(); ht["host_waits"] = ht.get("host_waits", 0.0) + t1 - t0; t0 = t1
             if red is not None and self.segment_buckets[i]:
-                red.reduce_buckets(self.segment_buckets[i], producers_done=True)
+                if getattr(red, "cuda", False):
+                    red.reduce_buckets(self.segment_buckets[i], producers_done=True)        # on the reducer's stream = self._side
+                else:
+                    with torch.cuda.stream(self._side):     # a synchronous (gloo) exchange orders itself against the CURRENT stream
+                        red.reduce_buckets(self.segment_buckets[i], producers_done=True)
             if self._opt_pieces[i] is not None:
                 with torch.cuda.stream(self._side):         # behind segment i's collectives: same stream
                     self._opt_pieces[i].replay()

@@ -111,6 +111,8 @@ def parse():
     ap.add_argument("--hoist-kv", default="on", choices=["on", "off"],
                     help="project K / V of all cross-attention layers up front in grouped launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shared-gpu-rehearsal", action="store_true",
+                    help="N > 1 ranks on a box with one GPU: all ranks on device 0, gloo instead of RCCL - a rehearsal of the multi-rank launch contract, not a measurement")
     ap.add_argument("--child", action="store_true", help="internal: a companion run started by the main process (timed region only)")
     ap.add_argument("--caption-tokens", type=int, default=32, help="N=1 only: also time cached greedy decoding of this many tokens per image (0 = skip)")
     ap.add_argument("--gemm-table", default="", help="write the per-shape GEMM timing table (measured inside the timed steps) to this file")
@@ -421,11 +423,17 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (see the docstring)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the fusion path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # --shared-gpu-rehearsal: the N-rank launch contract on a box with ONE GPU - every rank uses device 0 and the exchange goes through gloo (RCCL
+    # refuses two ranks on one device).  It exercises what the driver's `torch.distributed.run ... bench.py --gpus N` command exercises - environment,
+    # rendezvous, reducer, agreement on the graph mode, max-over-ranks timing, one JSON line from rank 0 - and its throughput means nothing.
+    dev_index = 0 if args.shared_gpu_rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1 or args.force_collectives:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world == 1:
+        if args.shared_gpu_rehearsal:
+            dist.init_process_group("gloo")
+        elif world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
@@ -533,6 +541,8 @@ def main():
             attempts = ["piecewise"]
         elif collectives and not sharded:
             attempts = ["full", "piecewise"] if args.graph == "on" else ["piecewise", "full"]
+            if args.shared_gpu_rehearsal:
+                attempts = ["piecewise"]                    # (a gloo exchange happens on the host: it cannot be part of a captured graph)
         else:
             attempts = ["full"]
         overlap_opt = (args.overlap_optimizer == "on" or (args.overlap_optimizer == "auto" and collectives)) and args.pace == "host" and opt is not None and args.optimizer.startswith("fused") and not sharded
@@ -729,7 +739,7 @@ def main():
                        # ("the loss printed by the bench"); `loss` = after the instrumented eager steps that follow
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
-                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
+                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
                        "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,

@@ -111,6 +111,10 @@ def parse():
     ap.add_argument("--hoist-kv", default="on", choices=["on", "off"],
                     help="project K / V of all cross-attention layers up front in grouped launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rccl-channels", type=int, default=0,
+                    help="N > 1: cap RCCL's channels (NCCL_MAX_NCHANNELS; one workgroup per channel on the side stream).  0 = RCCL's choice.  The step's exchange "
+                         "(1.37 GB per rank) needs ~8 ms of a ~25 ms backward at full xGMI speed, while every CU a collective occupies turns a 256-tile "
+                         "one-tile-per-CU GEMM launch into two waves: the first knob to sweep on a multi-GPU node (DESIGN.md section 6)")
     ap.add_argument("--shared-gpu-rehearsal", action="store_true",
                     help="N > 1 ranks on a box with one GPU: all ranks on device 0, gloo instead of RCCL - a rehearsal of the multi-rank launch contract, not a measurement")
     ap.add_argument("--child", action="store_true", help="internal: a companion run started by the main process (timed region only)")
@@ -431,6 +435,8 @@ def main():
     device = torch.device("cuda", dev_index)
     if world > 1 or args.force_collectives:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.rccl_channels > 0:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
         if args.shared_gpu_rehearsal:
             dist.init_process_group("gloo")
         elif world == 1:
@@ -739,7 +745,7 @@ def main():
                        # ("the loss printed by the bench"); `loss` = after the instrumented eager steps that follow
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
-                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
+                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "rccl_channels": (args.rccl_channels or None), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
                        "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,

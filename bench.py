@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--companions", default="auto", choices=["auto", "on", "off"],
                     help="N=1 only: after the main measurement, re-run the same workload in child processes (a) with the op substitutions inside the "
                          "backbones + the tuning file, (b) with the fp32-master / fp32-moment optimizer, and add both to the JSON line (auto = on for the default config B run)")
+    ap.add_argument("--segment-arena", default="on", choices=["on", "off"],
+                    help="piecewise replay with a reducer: the gradient buckets of a backward segment live in one buffer and travel as ONE collective (11 per step instead of 47)")
     ap.add_argument("--overlap-optimizer", default="auto", choices=["auto", "on", "off"],
                     help="piecewise replay with host pacing: AdamW as one sub-graph per backward segment, launched on a side stream as soon as the segment "
                          "(and its collectives) are done, beside the backward of the layers below.  auto = on when the step exchanges gradients (43.0 -> 42.6 ms "
@@ -560,7 +562,7 @@ def main():
                     graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer)
                 else:
                     graphed = PiecewiseGraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer, pace=args.pace,
-                                                        overlap_optimizer=overlap_opt)
+                                                        overlap_optimizer=overlap_opt, segment_arena=args.segment_arena == "on")
             except Exception as e:
                 if world == 1 and not collectives and args.graph in ("on", "piecewise"):
                     raise

@@ -174,11 +174,44 @@ def _flat_offsets(params: Sequence[torch.Tensor]):
     return offs, (total + 1023) // 1024 * 1024       # whole buffer: a multiple of 1024 elements, so it splits evenly over 1/2/4/8 ranks (reduce-scatter)
 
 
+class GradArena:
+    """One buffer for ALL the flat gradient buffers a stretch of backward produces (graphs.PiecewiseGraphedTrainStep: one backward segment),
+    so that the stretch's gradients travel in ONE collective instead of one per fused module.  Without a buffer it only adds up what the
+    stretch asks for (`need`, by dtype and device): the sizing pass.  With one, `take` hands out consecutive slices; a request that does
+    not fit (or is of another dtype) falls back to its own allocation."""
+
+    def __init__(self):
+        self.need, self.buf, self.used = {}, None, 0
+
+    def take(self, total: int, dtype, device):
+        if self.buf is None:
+            self.need[(dtype, device)] = self.need.get((dtype, device), 0) + total
+            return None
+        if self.buf.dtype != dtype or self.buf.device != device or self.used + total > self.buf.numel():
+            return None
+        out = self.buf[self.used:self.used + total]
+        self.used += total
+        return out
+
+
+_grad_arena: Optional[GradArena] = None
+
+
+def set_grad_arena(arena: Optional[GradArena]) -> Optional[GradArena]:
+    """Install (or remove, None) the arena the flat gradient buffers are carved from; returns the previous one.  Process-wide on purpose:
+    backward runs on the autograd engine's thread."""
+    global _grad_arena
+    prev, _grad_arena = _grad_arena, arena
+    return prev
+
+
 def _flat_grads(params: Sequence[torch.Tensor]):
     """One contiguous buffer holding every parameter gradient of a fused module (each slice 16-byte aligned).  Autograd
     adopts the slices as `param.grad` without copying, so the buffer doubles as a ready-made all-reduce bucket."""
     offs, total = _flat_offsets(params)
-    flat = torch.empty(total, dtype=params[0].dtype, device=params[0].device)   # alignment pads are never read
+    flat = _grad_arena.take(total, params[0].dtype, params[0].device) if _grad_arena is not None else None
+    if flat is None:
+        flat = torch.empty(total, dtype=params[0].dtype, device=params[0].device)   # alignment pads are never read
     return flat, [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
 
 

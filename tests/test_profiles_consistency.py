@@ -110,4 +110,4 @@ def test_hipblaslt_yardstick_covers_every_gemm_shape():
     table = [l.split()[:8] for l in open(os.path.join(P, f"{RND}_gemm_table.txt")).read().strip().splitlines()[1:]]
     assert sorted(r[:8] for r in rows) == sorted(table)
     for r in rows:
-        assert float(r[10]) > 0 and float(r[11]) > 0 and abs(float(r[10]) / float(r[11]) - float(r[12])) <= 0.011, r
+        assert float(r[10]) > 0 and float(r[11]) > 0 and abs(float(r[10]) / float(r[11]) - float(r[12])) <= 0.02, r          # (both times are printed to 0.1 us)

@@ -491,3 +491,51 @@ def test_four_gloo_ranks_reduce_dtype_bucket_order_accumulation_and_resume(tmp_p
             assert np.array_equal(res[r]["r." + k], res[r]["p." + k]), k          # resumed from the saved shards: bit-identical step 2
         assert _close(res[0]["p." + k].reshape(-1), want, 5e-4), k
     assert all(int(r["refused"]) == 1 for r in res)
+
+
+def test_gradient_arena_hands_out_consecutive_slices_and_buckets_merge(clean_patches):
+    """functional.GradArena + graphs._merge_arena_buckets (the piecewise step's one-collective-per-segment plumbing), on plain host tensors:
+    a sizing arena only adds up what is asked for; a backed arena hands out consecutive slices and refuses what does not fit or is of another
+    dtype (the caller then allocates as before); `_flat_grads` goes through the installed arena; the recorded buckets that are slices of the
+    arena merge into ONE bucket spanning its used part with the owners' offsets rebased, a foreign bucket (an un-fused parameter's own
+    gradient) keeps its place."""
+    from flamingo_mini_amd import functional as F
+    from flamingo_mini_amd.graphs import _merge_arena_buckets
+    params_a = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
+    params_b = [torch.nn.Parameter(torch.zeros(2000))]
+    sizing = F.GradArena()
+    prev = F.set_grad_arena(sizing)
+    try:
+        fa, ga = F._flat_grads(params_a)
+        fb, gb = F._flat_grads(params_b)
+    finally:
+        assert F.set_grad_arena(prev) is sizing
+    assert sizing.buf is None and sizing.need == {(torch.float32, torch.device("cpu")): fa.numel() + fb.numel()}
+    assert fa.numel() % 1024 == 0 and fb.numel() % 1024 == 0 and fa.data_ptr() != fb.data_ptr()
+    arena = F.GradArena()
+    arena.buf = torch.zeros(fa.numel() + fb.numel(), dtype=torch.float32)
+    F.set_grad_arena(arena)
+    try:
+        fa2, ga2 = F._flat_grads(params_a)
+        fb2, gb2 = F._flat_grads(params_b)
+        fc2, _ = F._flat_grads(params_b)                                      # does not fit any more: its own allocation
+        fd2, _ = F._flat_grads([torch.nn.Parameter(torch.zeros(4, dtype=torch.float64))])     # another dtype: its own allocation
+    finally:
+        F.set_grad_arena(None)
+    base = arena.buf.data_ptr()
+    assert fa2.data_ptr() == base and fb2.data_ptr() == base + fa2.numel() * 4 and arena.used == fa2.numel() + fb2.numel()
+    assert not (base <= fc2.data_ptr() < base + arena.buf.numel() * 4) and fd2.dtype == torch.float64
+    assert [g.shape for g in ga2] == [p.shape for p in params_a] and ga2[1].data_ptr() == base + F._flat_offsets(params_a)[0][1] * 4
+    loose = torch.zeros(11)
+    buckets = [(fa2, F._owners(params_a)), (loose, []), (fb2, F._owners(params_b))]
+    merged = _merge_arena_buckets(buckets, arena)
+    assert len(merged) == 2 and merged[1][0] is loose
+    flat, owners = merged[0]
+    assert flat.data_ptr() == base and flat.numel() == arena.used
+    assert [(p is q, off, n) for (p, off, n), q in zip(owners, params_a + params_b)] == \
+        [(True, 0, 15), (True, F._flat_offsets(params_a)[0][1], 7), (True, fa2.numel(), 2000)]
+    for p, off, n in owners:                                                  # the rebased offsets address the very slices autograd adopted
+        g = {id(q): t for q, t in zip(params_a + params_b, ga2 + gb2)}[id(p)]
+        assert flat[off:off + n].data_ptr() == g.data_ptr()
+    assert _merge_arena_buckets(buckets[:2], arena) == buckets[:2]            # fewer than two arena buckets: nothing to merge
+    assert _merge_arena_buckets(buckets, None) is buckets

@@ -220,7 +220,6 @@ class PiecewiseGraphedTrainStep:
         self._arenas = []              # segment_arena: one buffer per backward segment holding every flat gradient buffer the segment produces
         self._opt_pieces = []          # overlap_optimizer: one optimizer sub-graph per backward segment (None where nothing became final)
         self._side = None
-        self._side_done = None
         self.capture = bool(capture)
         self._loss_fn = loss_fn or (lambda out: out.loss)
         self.cuts = AutogradCuts()

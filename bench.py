@@ -100,6 +100,9 @@ def parse():
     ap.add_argument("--force-collectives", action="store_true", help="N=1: run the gradient exchange through a 1-rank RCCL group (what a single GPU can exercise of the N > 1 path)")
     ap.add_argument("--bucket-timeline", action="store_true", help="after the timed region, one eager step with HIP events around every gradient "
                                                                    "bucket's exchange: when it became ready, when its collective finished (rank 0, `bucket_timeline` in the JSON line)")
+    ap.add_argument("--segment-layers", type=int, default=4,
+                    help="piecewise replay: gated layers per backward segment (= per exchange point; with --wgrad-group / --kv-group set to the same number the "
+                         "launch structure follows it)")
     ap.add_argument("--wgrad-group", type=int, default=0, help="gated layers per grouped weight-gradient launch (0 = default: 12, or 4 with collectives)")
     ap.add_argument("--kv-group", type=int, default=-1, help="gated layers per K / V projection call (-1 = default: all, or 4 with collectives)")
     ap.add_argument("--lm-dropout", type=float, default=None, help="debugging aid: dropout probability inside the stock LM (default: the architecture's)")
@@ -561,7 +564,7 @@ def main():
                 if mode == "full":
                     graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer)
                 else:
-                    graphed = PiecewiseGraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer, pace=args.pace,
+                    graphed = PiecewiseGraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer, pace=args.pace, segment_layers=args.segment_layers,
                                                         overlap_optimizer=overlap_opt, segment_arena=args.segment_arena == "on")
             except Exception as e:
                 if world == 1 and not collectives and args.graph in ("on", "piecewise"):
@@ -747,7 +750,7 @@ def main():
                        # ("the loss printed by the bench"); `loss` = after the instrumented eager steps that follow
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
-                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "rccl_channels": (args.rccl_channels or None), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
+                       "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "rccl_channels": (args.rccl_channels or None), "segment_layers": (args.segment_layers if graph_mode == "piecewise" else None), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
                        "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,

@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = False, debug: bool = False) -> st
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s] + headers) or not os.path.exists(o.replace(".o", ".resources.txt")):      # (objects of a build that kept no resource remarks)
             jobs.append((s, o))
 
     def compile_one(job):

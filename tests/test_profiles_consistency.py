@@ -111,3 +111,21 @@ def test_hipblaslt_yardstick_covers_every_gemm_shape():
     assert sorted(r[:8] for r in rows) == sorted(table)
     for r in rows:
         assert float(r[10]) > 0 and float(r[11]) > 0 and abs(float(r[10]) / float(r[11]) - float(r[12])) <= 0.02, r          # (both times are printed to 0.1 us)
+
+
+def test_launch_modes_under_a_one_rank_exchange_are_ordered_as_the_design_says():
+    """profiles/rNN_launch_modes_one_rank_rccl.txt (round 4 on): with the gradient exchange going through a 1-rank RCCL group the piecewise replay
+    with host-paced collectives beats the stream-ordered one, which beats the whole-step capture, which beats eager launches; and the single
+    graph without collectives is the fastest of all (DESIGN.md section 6 quotes these numbers)."""
+    path = os.path.join(P, f"{RND}_launch_modes_one_rank_rccl.txt")
+    if not os.path.exists(path):
+        pytest.skip("no launch-mode table for this round")
+    rows = [l for l in open(path) if l.startswith("graph=")]
+    if not any(l.startswith("graph=piecewise --pace stream") for l in rows):
+        pytest.skip("table predates the host-paced mode")
+    no_coll = float(re.search(r"([\d.]+) ms/step", [l for l in rows if "no collectives" in l][0]).group(1))
+    captured = float(re.search(r"([\d.]+) ms/step", [l for l in rows if l.startswith("graph=on, gradient")][0]).group(1))
+    host = float(re.search(r"([\d.]+) ms/step", [l for l in rows if l.startswith("graph=piecewise, ")][0]).group(1))
+    stream = float(re.search(r"([\d.]+) ms/step", [l for l in rows if l.startswith("graph=piecewise --pace stream")][0]).group(1))
+    eager = float(re.search(r"([\d.]+) ms/step", [l for l in rows if l.startswith("graph=off")][0]).group(1))
+    assert no_coll < host < stream < captured < eager, (no_coll, host, stream, captured, eager)

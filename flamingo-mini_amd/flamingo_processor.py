@@ -99,8 +99,12 @@ class FlamingoProcessor:
 
     # ------------------------------------------------------------------ images
     def preprocess_images(self, images):
-        """PIL images (or tensors) -> BatchFeature with `pixel_values` (n, 3, 224, 224)."""
-        return self.vision_processor(images=images, return_tensors="pt", padding=True)
+        """PIL images (or tensors) -> BatchFeature with `pixel_values` (n, 3, 224, 224).  (The reference passes `padding=True` as well,
+        flamingo_processor.py:125,140: image processors of transformers < 5 ignore the keyword, those of >= 5 reject it.)"""
+        try:
+            return self.vision_processor(images=images, return_tensors="pt", padding=True)
+        except TypeError:
+            return self.vision_processor(images=images, return_tensors="pt")
 
     def __call__(self, images=None, text=None, device=None) -> dict:
         out = {}

@@ -1,0 +1,68 @@
+"""FlamingoProcessor against the reference's own class.  tests/golden/make_processor_golden.py built a tiny GPT-2-format
+byte-level BPE (tests/golden/tiny_gpt2_tokenizer/: no tokenizer files exist offline), ran /root/reference's FlamingoProcessor on it and stored
+what its public surface returns; here the same calls go through this repository's class with the same tokenizer files."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLDEN)
+
+
+@pytest.fixture(scope="module")
+def proc_and_fixture():
+    import types
+    import transformers
+    from flamingo_mini_amd import flamingo_processor as FP
+    tok_dir = os.path.join(GOLDEN, "tiny_gpt2_tokenizer")
+    orig = FP._load_tokenizer
+    FP._load_tokenizer = lambda lm, use_fast: (transformers.GPT2TokenizerFast if use_fast else transformers.GPT2Tokenizer).from_pretrained(tok_dir)
+    try:
+        proc = FP.FlamingoProcessor(types.SimpleNamespace(lm="gpt2", clip_model_type="openai/clip-vit-large-patch14"))
+    finally:
+        FP._load_tokenizer = orig
+    z = dict(np.load(os.path.join(GOLDEN, "processor_gpt2_tiny.npz")))
+    meta = json.load(open(os.path.join(GOLDEN, "processor_gpt2_tiny.json")))
+    return proc, z, meta
+
+
+def test_tag_token_ids_and_the_added_end_of_chunk_token(proc_and_fixture):
+    proc, z, meta = proc_and_fixture
+    assert list(proc.leq_ids) == z["leq_ids"].tolist() and proc.leq_ids[0] != proc.leq_ids[1]      # "<" and " <" (GPT-2: 27 / 1279)
+    assert int(proc.tokenizer.convert_tokens_to_ids(proc.eoc_token)) == meta["expected"]["eoc_id"]
+    assert len(proc.tokenizer) == meta["expected"]["vocab_size_with_eoc"]
+    assert proc.tokenizer.pad_token == proc.tokenizer.eos_token
+
+
+@pytest.mark.parametrize("mode,kw", [("default", {}), ("max8", {"max_length": 8}), ("len12", {"length": 12})])
+@pytest.mark.parametrize("key", ["single", "batch"])
+def test_encode_text_in_its_three_padding_modes(proc_and_fixture, mode, kw, key):
+    """flamingo_processor.py:63-99: pad to the longest / pad to the longest and cut at max_length / pad and cut to `length`; BOS is added,
+    padding is EOS, every "<" token (either spelling) is a media location."""
+    proc, z, meta = proc_and_fixture
+    ids, ml, am = proc.encode_text(meta["texts"][key], **kw)
+    assert np.array_equal(ids.numpy(), z[f"{mode}.{key}.ids"]) and np.array_equal(am.numpy(), z[f"{mode}.{key}.am"])
+    assert np.array_equal(ml.numpy(), z[f"{mode}.{key}.ml"]) and ml.dtype == ids.dtype
+    assert ids[0, 0].item() == proc.tokenizer.bos_token_id
+
+
+def test_captions_tags_and_the_call_interface(proc_and_fixture):
+    proc, z, meta = proc_and_fixture
+    t, e = meta["texts"], meta["expected"]
+    assert proc.prepare_caption(t["caption"]) == e["prepare_caption"] and proc.prepare_captions(t["captions"]) == e["prepare_captions"]
+    assert proc.remove_tags(t["tagged"][0]) == e["remove_tags_str"] and proc.remove_tags(t["tagged"]) == e["remove_tags_list"]
+    ids = proc.tokenizer(proc.prepare_caption(t["caption"]), return_tensors="pt").input_ids
+    assert np.array_equal(ids.numpy(), z["caption.ids"]) and proc.tokenizer.batch_decode(ids)[0] == e["caption.decoded"]
+    from make_processor_golden import synthetic_image
+    out = proc(images=[synthetic_image(), synthetic_image().rotate(90, expand=True)], text=t["batch"])
+    assert sorted(out) == e["call_keys"]
+    for k, v in out.items():
+        ref = z["call." + k]
+        assert v.shape == ref.shape and (np.array_equal(v.numpy(), ref) if v.dtype != torch.float32 else np.allclose(v.numpy(), ref, atol=1e-6)), k
+    px = proc.preprocess_images([synthetic_image()])["pixel_values"]
+    assert px.shape == (1, 3, 224, 224) and np.allclose(px.numpy(), z["preprocess_images"], atol=1e-6)
+    assert proc(text=t["single"])["media_locations"].sum().item() == 1 and "pixel_values" not in proc(text=t["single"])

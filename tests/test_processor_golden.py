@@ -66,3 +66,45 @@ def test_captions_tags_and_the_call_interface(proc_and_fixture):
     px = proc.preprocess_images([synthetic_image()])["pixel_values"]
     assert px.shape == (1, 3, 224, 224) and np.allclose(px.numpy(), z["preprocess_images"], atol=1e-6)
     assert proc(text=t["single"])["media_locations"].sum().item() == 1 and "pixel_values" not in proc(text=t["single"])
+
+
+def test_generate_captions_end_to_end_on_the_host(proc_and_fixture):
+    """Processor + model together (modeling_flamingo.py:550-605): PIL images through the CLIP preprocessing, the tagged prompt through the
+    tokenizer, cached greedy decoding, decoding back to text.  The fused entry points run on the oracle checker (CPU); the captions must
+    equal an explicit greedy loop of FULL uncached forwards over the growing sequence."""
+    import oracle_backend
+    from flamingo_mini_amd import FlamingoConfig, FlamingoModel
+    from make_processor_golden import synthetic_image
+    from test_model_plumbing import TINY_GPT2
+    proc, z, meta = proc_and_fixture
+    eos = proc.tokenizer.eos_token_id
+    lm_kw = dict(TINY_GPT2["lm_kw"], vocab_size=len(proc.tokenizer) - 1, bos_token_id=eos, eos_token_id=eos)       # (+1 row for <EOC>: added by the model)
+    clip_kw = dict(TINY_GPT2["clip_kw"], image_size=224, patch_size=32)
+    oracle_backend.install()
+    try:
+        torch.manual_seed(3)
+        cfg = FlamingoConfig(**TINY_GPT2["flamingo_kw"], random_init_backbones=True, backbone_overrides={"lm": lm_kw, "clip": clip_kw})
+        model = FlamingoModel(cfg).double().eval()
+        assert model.flamingo.lm.get_input_embeddings().weight.shape[0] == len(proc.tokenizer)
+        images = [synthetic_image(), synthetic_image().rotate(90, expand=True)]
+        prompt, max_length = "<image>a", 10
+        captions = model.generate_captions(proc, images=images, prompt=prompt, max_length=max_length)
+        assert isinstance(captions, list) and len(captions) == 2 and all(isinstance(c, str) for c in captions)
+        px = proc(images=images)["pixel_values"].double()[:, None]
+        ids, ml, am = proc.encode_text(prompt)
+        ids, ml, am = (t[:1].expand(2, -1).contiguous() for t in (ids, ml, am))
+        done = torch.zeros(2, dtype=torch.bool)
+        with torch.no_grad():
+            while ids.shape[1] < max_length and not bool(done.all()):
+                logits = model(input_ids=ids, attention_mask=am, media_locations=ml, pixel_values=px).logits[:, -1]
+                nxt = torch.where(done, torch.full((2,), eos), logits.argmax(-1))
+                done |= nxt.eq(eos)
+                ids = torch.cat([ids, nxt[:, None]], 1)
+                ml = torch.cat([ml, torch.zeros_like(nxt)[:, None]], 1)
+                am = torch.cat([am, torch.ones_like(nxt)[:, None]], 1)
+        expect = [proc.remove_tags(t) for t in proc.tokenizer.batch_decode(ids, skip_special_tokens=True)]
+        assert captions == expect, (captions, expect)
+        one = model.generate_captions(proc, images=images[0], prompt=prompt, max_length=max_length)       # a single PIL image, not a list
+        assert one == expect[:1]
+    finally:
+        oracle_backend.uninstall()

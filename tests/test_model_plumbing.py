@@ -437,3 +437,57 @@ def test_h64_bf16_two_steps_through_graphed_train_step():
             report["worst_update1"] = max(wd.items(), key=lambda kv: kv[1])
             assert max(wd.values()) < 0.05, report            # the update is lr * g / (|g| + eps): a smooth function of the gradient at eps = 1e-3 (measured <= 1.3e-2)
     print("h64 bf16 two-step report:", report)
+
+
+def test_score_sequences_and_freezing_on_the_host():
+    """The two remaining methods of the reference's public surface (modeling_flamingo.py:100-137, 607-712), on the GPT-2-backed tiny model with
+    the fused entry points on the oracle checker.  score_sequences: the score of a candidate is the sum of the log-probabilities of its
+    tokens behind the prefix all candidates share, given the same visuals - compared with plain uncached forwards, one candidate at a
+    time; with k < number of candidates the ones whose first diverging token is least likely get the reference's -inf stand-in.
+    freeze_vm / freeze_lm / unfreeze_lm: the vision encoder is frozen, the LM is frozen except the gated blocks and the token embedding,
+    and parameters_trainable() / state_dict_trainable() follow."""
+    import oracle_backend
+    oracle_backend.install()
+    try:
+        model, z = build(torch.float64, "cpu", "gpt2")
+        model.eval()
+        px = torch.from_numpy(z["px"]).double()[0]              # (N c h w): the images of ONE sample, shared by every candidate
+        base = torch.from_numpy(z["ids"])[0, :12].clone()
+        ml = torch.from_numpy(z["ml"])[0, :12].clone()
+        cands = base[None].repeat(4, 1)
+        cands[1, 8:] = torch.tensor([5, 9, 11, 3])
+        cands[2, 8:] = torch.tensor([7, 7, 2, 40])
+        cands[3, 9:] = torch.tensor([1, 2, 3])                  # diverges one token later: the shared prefix is 8 tokens
+        mls, am = ml[None].repeat(4, 1), torch.ones_like(cands)
+        scores = model.score_sequences(cands, mls, am, pixel_values=px)
+        expect = []
+        with torch.no_grad():
+            for i in range(4):
+                logits = model(input_ids=cands[i:i + 1], attention_mask=am[i:i + 1], media_locations=mls[i:i + 1], pixel_values=px[None]).logits[0]
+                logp = logits[7:-1].float().log_softmax(-1)
+                expect.append(float(logp.gather(-1, cands[i, 8:, None]).sum()))
+        assert scores.shape == (4,) and scores.dtype == torch.float32
+        assert np.allclose(scores.numpy(), np.array(expect), rtol=1e-5, atol=1e-5), (scores, expect)
+        top2 = model.score_sequences(cands, mls, am, pixel_values=px, k=2)
+        with torch.no_grad():
+            first = model(input_ids=cands[:1, :8], attention_mask=am[:1, :8], media_locations=mls[:1, :8], pixel_values=px[None]).logits[0, -1]
+        keep = set(first.index_select(0, cands[:, 8]).topk(2).indices.tolist())
+        for i in range(4):
+            if i in keep:
+                assert abs(float(top2[i]) - expect[i]) < 1e-4
+            else:
+                assert float(top2[i]) == torch.finfo(torch.float).min
+        # freezing
+        named = dict(model.flamingo.named_parameters())
+        trainable = {k for k, p in named.items() if p.requires_grad}
+        assert trainable and not any(k.startswith("vision_encoder.") for k in trainable)
+        assert all(("xattn_block" in k) or k.startswith("resampler.") or "wte" in k or "embed_tokens" in k or "lm_head" in k for k in trainable), trainable
+        model.unfreeze_lm()
+        assert all(p.requires_grad for k, p in model.flamingo.named_parameters() if k.startswith("lm.")) and \
+            not any(p.requires_grad for k, p in model.flamingo.named_parameters() if k.startswith("vision_encoder."))
+        model.freeze_lm()
+        assert {k for k, p in model.flamingo.named_parameters() if p.requires_grad} == trainable
+        assert set(model.state_dict_trainable()) == trainable
+        assert {id(p) for p in model.parameters_trainable()} == {id(named[k]) for k in trainable}
+    finally:
+        oracle_backend.uninstall()

@@ -571,7 +571,7 @@ def main():
                     raise
                 err = e
                 torch.cuda.synchronize()
-                model.install_autograd_cuts(None)
+                graphed = None              # (a piecewise step that raised has already taken its cut points out and ended the reducer's recording)
             captured = err is None
             if world > 1:
                 flag = torch.tensor([1 if captured else 0], device=device, dtype=torch.int32)
@@ -580,6 +580,9 @@ def main():
             if captured:
                 step, graph_mode = graphed, mode
                 break
+            if graphed is not None and hasattr(graphed, "close"):
+                graphed.close()             # this rank captured but another did not: every rank leaves the mode, and leaves the model as it found it
+            model.install_autograd_cuts(None)
             graph_note += f"; {mode} graph capture failed on a rank" + (f" ({type(err).__name__}: {str(err)[:120]})" if err is not None else "")
         if graph_mode == "off":
             graph_note += ", eager launches instead"
@@ -630,7 +633,8 @@ def main():
     prof_steps = max(args.profile_steps, 0)
     max_rec = 4096 * max(prof_steps, 1)
     eager_ms = None
-    model.install_autograd_cuts(None)       # (a piecewise step leaves its cut points installed: the eager steps below run one backward pass)
+    if graph_mode == "piecewise" and hasattr(step, "close"):
+        step.close()                        # the eager steps below run one backward pass over the whole graph
     bucket_timeline = None
     if collectives and reducer is not None and (args.bucket_timeline or world > 1):
         # One eager step with HIP events around every bucket's exchange (rank 0 reports): when each bucket became final, when its collective

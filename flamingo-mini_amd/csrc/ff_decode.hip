@@ -177,15 +177,25 @@ __global__ __launch_bounds__(kDecWaves * 64) void decode_rows32_kernel(const bf1
         const int r = t >> 4, s16 = t & 15;
         const int nch = nk * 8;
         auto piece = [&](int ci) { return sA + (ci >> 3) * (kDecRows * kBK) + r * kBK + (((ci & 7) ^ (r & 7)) << 3); };
-        // (the slice is a whole number of 128-element blocks - decode_ffw_supported - so every thread owns nch / 16 pieces, an even count:
-        // two pieces per iteration, no guards, no clamped duplicates)
-        const float shift = (float)sA[r * kBK + ((0 ^ (r & 7)) << 3)];  // x[r][0]
+        // (the slice is a whole number of 128-element blocks - decode_ffw_supported - so every thread owns nch / 16 pieces; two pieces per
+        // iteration, and when that count is odd (d an odd multiple of 128) the last iteration's second piece does not exist: `two`)
+        // shift of the one-pass sums: the mean of the row's first 16 elements (two 16-byte pieces, read by every thread of the row).  A single
+        // element as the shift loses the variance to cancellation when that element is an outlier of its row (massive-activation channels).
+        float shift;
+        {
+            const bf16x8 h0 = *(const bf16x8*)piece(0), h1 = *(const bf16x8*)piece(1);
+            float hs = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) hs += (float)h0[e] + (float)h1[e];
+            shift = hs * (1.f / 16.f);
+        }
         float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c0 = s16; c0 < nch; c0 += 32) {
-            const bf16x8 x0 = *(const bf16x8*)piece(c0), x1 = *(const bf16x8*)piece(c0 + 16);
+            const bool two = c0 + 16 < nch;
+            const bf16x8 x0 = *(const bf16x8*)piece(c0), x1 = *(const bf16x8*)piece(two ? c0 + 16 : c0);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float d0 = (float)x0[e] - shift, d1 = (float)x1[e] - shift;
+                const float d0 = (float)x0[e] - shift, d1 = two ? (float)x1[e] - shift : 0.f;
                 s1[e] += d0 + d1;
                 s2[e] = fmaf(d1, d1, fmaf(d0, d0, s2[e]));
             }
@@ -204,15 +214,18 @@ __global__ __launch_bounds__(kDecWaves * 64) void decode_rows32_kernel(const bf1
         if (writer && s16 == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
         const float nmr = -mu * rs;
         for (int c0 = s16; c0 < nch; c0 += 32) {
+            const int np = c0 + 16 < nch ? 2 : 1;
             bf16x8 x[2], gq[2], bq[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                x[u] = *(const bf16x8*)piece(c0 + 16 * u);
-                gq[u] = *(const bf16x8*)(s_g + (c0 + 16 * u) * 8);
-                bq[u] = *(const bf16x8*)(s_b + (c0 + 16 * u) * 8);
+                const int ci = u < np ? c0 + 16 * u : c0;
+                x[u] = *(const bf16x8*)piece(ci);
+                gq[u] = *(const bf16x8*)(s_g + ci * 8);
+                bq[u] = *(const bf16x8*)(s_b + ci * 8);
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
+                if (u >= np) break;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = fmaf(fmaf((float)x[u][e], rs, nmr), (float)gq[u][e], (float)bq[u][e]);

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
     }
     FF_XTL(1);
 
-    // ---- LayerNorm statistics: sums shifted by the row's first element (x0), so the one-pass variance has two-pass accuracy ----
+    // ---- LayerNorm statistics: sums shifted by the mean of the row's first piece (x0), so the one-pass variance has two-pass accuracy ----
     {
         float x0 = 0.f, s1 = 0.f, s2 = 0.f;
         for (int base = 0; base < nchunk; base += TPR * NB) {
@@ -342,7 +342,10 @@ __global__ __launch_bounds__(256) void xa_qattn_fwd_kernel(const XaFusedArgs a_i
             } else {
                 float first[VN];
                 unpack16(raw[0], first, T());
-                x0 = __shfl(first[0], (t & 63) - sub, 64);      // element 0 of the row sits in the first piece of the row's first thread
+                float fs = 0.f;                                 // the shift: mean of the row's first 16-byte piece (held by the row's first thread) -
+#pragma unroll
+                for (int e = 0; e < VN; e++) fs += first[e];    // a single element would lose the variance to cancellation when it is an outlier of its row
+                x0 = __shfl(fs * (1.f / VN), (t & 63) - sub, 64);
             }
 #pragma unroll
             for (int u = 0; u < NB; u++) {
@@ -689,6 +692,135 @@ FF_DEV void res_park(bf16* tile, const f32x4 (&acc)[2], float scale, int w, int 
     }
 }
 
+
+// ---- phase 2 of the resident kernels (round 5): the product that runs over ALL heads of a sample, inside the same launch ----
+// to_out (forward: attn_out = O . Wo^T, gated_cross_attention.py:124-126) and d LN(y) = scale * dQs . Wq (backward) contract over heads * 64,
+// i.e. over what the eight (sample, head) workgroups of a sample produced.  They used to be launches of their own (64 x 64 tiles, 5-8 % of
+// the MFMA peak: ~11 us of fixed cost for 1.3 GFLOP).  Here each workgroup publishes its 32 x 64 tile of O (d Q) with write-through
+// stores, counts itself in on the sample's counter, and once all `heads` have arrived reads the whole 32 x 512 operand back (sc1 loads:
+// MI355X guide, Guideline 16, the write-through form - no fences) and computes the output columns [h, h + 1) * dim / heads of all 32 rows:
+// the weight slice (dim / heads rows x 512, or 512 k-rows x dim / heads columns) streams through a 4-deep ring that lives where the
+// activation rows were, its first three tiles requested while the attention is still running.
+// The counters are caller-owned (ff_xattn_desc.sync), zero when first handed over and never reset: every launch adds exactly `heads` to
+// each sample's counter, a workgroup's ticket tells it which multiple of `heads` to wait for, and the comparison is wrap-safe.
+// Co-residency: one workgroup per CU and `heads` consecutive workgroups per sample; workgroups are dispatched in order, so a sample's
+// group is never waiting for a workgroup that sits behind a group that cannot finish.  A bounded spin turns a violated assumption into
+// an error word (sync[kSyncStatus]) and garbage the parity tests catch, not into a hung GPU.
+constexpr int kSyncSlots = FF_XATTN_SYNC_SLOTS;         // samples per counter bank: forward bank, backward bank, status word
+constexpr int kSyncStatus = 2 * kSyncSlots;
+constexpr int kOutNS = 4;                               // ring depth of the phase-2 weight stream
+constexpr int kOutMaxPer = 6;                           // 32-column groups per head slice: dim / heads <= 192
+constexpr int kSpinLimit = 1 << 18;
+
+// one accumulator row -> global, write-through (sc1): the line leaves this XCD's L2, every other CU's sc1 load sees it
+FF_DEV void store_acc_row_wt(bf16* row, const f32x4 (&acc)[kResDH / 16], float scale, int g) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int dt = 0; dt < kResDH / 16; dt++) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = (bf16)(acc[dt][e] * scale);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), r, (unsigned)(dt * 16 + g * 4) * 2u, 0, 16);
+    }
+}
+// thread 0, after a workgroup barrier behind the drained payload stores: count this workgroup in; returns the count to wait for
+FF_DEV unsigned res_arrive(unsigned* cnt, unsigned group) {
+    const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (ticket / group + 1u) * group;
+}
+FF_DEV void res_await(unsigned* cnt, unsigned target, unsigned* status) {
+    int spins = 0;
+    while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinLimit) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+// res_issue_rows with agent-scope (sc1) loads: the rows were written by other CUs during this launch
+FF_DEV void res_issue_rows_sc1(const bf16* rows, int dim, int n_rows, bf16* sA, int w, int l) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)rows, 0, 0x7fffffff, 0x00020000);
+    const int p = w & 3, row = p * 8 + (l >> 3), cp = l & 7;
+    const unsigned voff = row < n_rows ? (unsigned)(row * dim + ((cp ^ (row & 7)) << 3)) * 2u : kOobOffset;
+    const int nk = dim / kBK;
+    for (int tile = w >> 2; tile < nk; tile += 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, FF_LDS_PTR(void, sA + tile * (kResBM * kBK) + p * 8 * kBK), 16, voff, (unsigned)tile * (kBK * 2), 0, 16);
+}
+// The weight slice of phase 2.  BL 0 (forward, Wo [dim][inner]): the slice's rows are the output columns n0 .. n0 + 32 PER - 1, k contiguous:
+// one K-major tile [32 PER][64] per k-step.  BL 1 (backward, Wq [inner][dim]): output columns contiguous: PER M-major sub-tiles [64 k][32].
+// Either way a DMA wave issues PER instructions per k-step.
+template <int PER, int BL>
+FF_DEV void res_out_prepare(const RowMap& b_map, int n0, int pw, int l, unsigned (&vb)[kOutMaxPer]) {
+    if (BL == 0) dma_prepare<32 * PER, 0, 4>(b_map, n0, n0 + 32 * PER, pw, l, vb);
+    else {
+#pragma unroll
+        for (int sidx = 0; sidx < PER; sidx++) dma_prepare<32, 1, 4>(b_map, n0 + 32 * sidx, n0 + 32 * PER, pw, l, vb + sidx);
+    }
+}
+template <int PER, int BL>
+FF_DEV void res_out_issue(__amdgpu_buffer_rsrc_t rb, bf16* ring, const unsigned (&vb)[kOutMaxPer], unsigned b_step, int tile, int pw) {
+    bf16* st = ring + (tile % kOutNS) * (32 * PER * kBK);
+    const unsigned soff = (unsigned)(tile * kBK) * b_step;
+    if (BL == 0) dma_tile_fast<32 * PER, 0, 4>(rb, st, vb, soff, pw);
+    else {
+#pragma unroll
+        for (int sidx = 0; sidx < PER; sidx++) dma_tile_fast<32, 1, 4>(rb, st + sidx * (32 * kBK), vb + sidx, soff, pw);
+    }
+}
+// acc[j][r] = sum_k A2[rb*16 + c][k] * B[n0 + ch * 16 PER + j*16 + g*4 + r][k]   (cw = rb | ch << 1; the four DMA waves keep the ring full).
+// On entry the first kOutNS - 1 tiles have been issued AND have landed (the caller waited for vmcnt(0) when it staged A2).
+template <int PER, int BL>
+FF_DEV void res_out_project(const bf16* sA2, bf16* ring, __amdgpu_buffer_rsrc_t rb, const unsigned (&vb)[kOutMaxPer], unsigned b_step, int nk2, int w,
+                            f32x4 (&acc)[kOutMaxPer]) {
+    constexpr int STAGE = 32 * PER * kBK;
+    if (w >= 4) {
+        const int pw = w - 4;
+        for (int kt = 0; kt < nk2; kt++) {
+            wait_tiles<PER, kOutNS - 2>(min(nk2 - 1 - kt, kOutNS - 2));
+            __builtin_amdgcn_s_barrier();
+            if (kt + kOutNS - 1 < nk2) res_out_issue<PER, BL>(rb, ring, vb, b_step, kt + kOutNS - 1, pw);
+        }
+    } else {
+        const int rb16 = (w & 1) * 16, ch = w >> 1;
+        for (int kt = 0; kt < nk2; kt++) {
+            __builtin_amdgcn_s_barrier();
+            const bf16* sAt = sA2 + kt * (kResBM * kBK);
+            const bf16* sBt = ring + (kt % kOutNS) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < kBK / 32; ks++) {
+                const bf16x8 fa = frag_read2<kResBM, 0>(sAt, rb16, ks);
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    bf16x8 fb;
+                    if (BL == 0) fb = frag_read2<32 * PER, 0>(sBt, ch * (16 * PER) + j * 16, ks);
+                    else {
+                        const int jn = ch * PER + j;
+                        fb = frag_read2<32, 1>(sBt + (jn >> 1) * (32 * kBK), (jn & 1) * 16, ks);
+                    }
+                    acc[j] = mfma_bf16(fb, fa, acc[j]);                  // D[n][m]
+                }
+            }
+        }
+    }
+}
+// the four MFMA waves park their fp32 tiles as rows of cs + 4 floats (16-byte pieces, conflict-free) for the row-contiguous epilogue
+template <int PER> FF_DEV void res_out_park(float* tile, const f32x4 (&acc)[kOutMaxPer], int w, int c, int g) {
+    constexpr int LD = 32 * PER + 4;
+    const int row = (w & 1) * 16 + c, col0 = (w >> 1) * (16 * PER);
+#pragma unroll
+    for (int j = 0; j < PER; j++) *(f32x4*)(tile + row * LD + col0 + j * 16 + g * 4) = acc[j];
+}
+#define FF_RES_PER(per, ...)                                         \
+    switch (per) {                                                   \
+        case 1: { constexpr int PER = 1; __VA_ARGS__; } break;       \
+        case 2: { constexpr int PER = 2; __VA_ARGS__; } break;       \
+        case 3: { constexpr int PER = 3; __VA_ARGS__; } break;       \
+        case 4: { constexpr int PER = 4; __VA_ARGS__; } break;       \
+        case 5: { constexpr int PER = 5; __VA_ARGS__; } break;       \
+        default: { constexpr int PER = 6; __VA_ARGS__; } break;      \
+    }
+
 }  // namespace
 
 template <int NSB>
@@ -756,7 +888,18 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
         // round 3's two passes were two serial chains of up to 96 dependent additions per thread (round 4: ff_decode.hip's probe put the same
         // code at half of that kernel's time)
         uint4 raw[MAXC];
-        const float shift = (float)sA[r * kBK + ((r & 7) << 3)];        // x[r][0]: chunk 0 of row r sits in slot 0 ^ (r & 7)
+        // the shift: mean of the row's first 16 elements (chunks 0 and 1 sit in slots 0 ^ (r & 7) and 1 ^ (r & 7)).  One element as the shift
+        // loses the variance to cancellation when that element is an outlier of its row (massive-activation channels of an LM's residual stream).
+        float shift;
+        {
+            float h0[8], h1[8];
+            unpack16(*(const uint4*)(sA + r * kBK + ((r & 7) << 3)), h0, bf16());
+            unpack16(*(const uint4*)(sA + r * kBK + ((1 ^ (r & 7)) << 3)), h1, bf16());
+            float hs = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) hs += h0[e] + h1[e];
+            shift = hs * (1.f / 16.f);
+        }
         float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < MAXC; u++) {

@@ -30,13 +30,29 @@ def _bucket_launch_structure(model: torch.nn.Module, layers_per_bucket: int = 4)
     kv_project_group): each call is its own autograd node with its own gradient bucket, ready as soon as its layers' backward is done;
     and the deferred weight gradients of the blocks are flushed every `layers_per_bucket` layers as well (single-GPU default: 12, which is
     faster per launch but would hold back every bucket until a third of backward has passed).  These are settings OF THE MODEL
-    (set_launch_structure), not of the process: returns [(module, previous settings)] for close() to restore."""
+    (set_launch_structure), not of the process.  Returns what close() needs to take back exactly what was changed here and nothing else:
+    [(owner object, attribute, value before, value set)] - the K / V group of the model and `wgrad_group` of EVERY block (per block: blocks
+    may differ), so that a setting the user changed after constructing the reducer, or one this function never touched (hoist_kv,
+    defer_wgrad), survives close()."""
     undo = []
     for m in model.modules():
-        if hasattr(m, "set_launch_structure") and hasattr(m, "kv_project_group"):
+        if hasattr(m, "set_launch_structure") and hasattr(m, "kv_project_group") and hasattr(m, "get_modified_layers"):
             group = m.kv_project_group if m.kv_project_group > 0 else layers_per_bucket
-            undo.append((m, m.set_launch_structure(kv_project_group=group, wgrad_group=layers_per_bucket)))
+            if m.kv_project_group != group:
+                undo.append((m, "kv_project_group", m.kv_project_group, group))
+                m.kv_project_group = group
+            for hook in m.get_modified_layers():
+                blk = hook.xattn_block
+                if blk.wgrad_group != layers_per_bucket:
+                    undo.append((blk, "wgrad_group", blk.wgrad_group, layers_per_bucket))
+                    blk.wgrad_group = layers_per_bucket
     return undo
+
+
+def _restore_launch_structure(undo: list) -> None:
+    for obj, name, before, set_to in undo:
+        if getattr(obj, name) == set_to:        # still what the reducer set: nobody has changed it since
+            setattr(obj, name, before)
 
 
 def _bucket_is_ours(owners, ids) -> bool:
@@ -90,12 +106,12 @@ class GradientAllReducer:
         F.add_grad_ready_callback(self._on_bucket)
 
     def close(self):
-        """Detach from the model: callbacks and hooks removed, the model's launch structure restored to what it was before."""
+        """Detach from the model: callbacks and hooks removed; the launch-structure settings this reducer changed (and only those, and only
+        where they still hold the value it set) go back to what they were."""
         F.remove_grad_ready_callback(self._on_bucket)
         for h in self._hooks:
             h.remove()
-        for m, prev in self._undo:
-            m.set_launch_structure(**prev)
+        _restore_launch_structure(self._undo)
         self._undo = []
 
     # -- piecewise capture: record instead of exchanging --
@@ -320,8 +336,7 @@ class ShardedAdamW(torch.optim.Optimizer):
         F.remove_grad_ready_callback(self._on_bucket)
         for h in self._hooks:
             h.remove()
-        for m, prev in self._undo:
-            m.set_launch_structure(**prev)
+        _restore_launch_structure(self._undo)
         self._undo = []
 
     @contextlib.contextmanager

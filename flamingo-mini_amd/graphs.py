@@ -116,12 +116,22 @@ class AutogradCuts:
 
     def __init__(self):
         self.pairs = []
+        self.armed = False      # cut() only cuts while the owning step runs a forward of its own (armed()): an ordinary training-mode
+                                # model(**batch).loss.backward() on a model that still has the cuts installed sees the whole graph
 
     def reset(self) -> None:
         self.pairs = []
 
+    @contextlib.contextmanager
+    def arm(self):
+        prev, self.armed = self.armed, True
+        try:
+            yield self
+        finally:
+            self.armed = prev
+
     def cut(self, t: torch.Tensor) -> torch.Tensor:
-        if not (torch.is_grad_enabled() and t.requires_grad):
+        if not (self.armed and torch.is_grad_enabled() and t.requires_grad):
             return t
         twin = t.detach().requires_grad_(True)
         self.pairs.append((t, twin))
@@ -233,6 +243,32 @@ class PiecewiseGraphedTrainStep:
         if not self.capture:
             self.loss = None
             return
+        try:
+            self._capture(model, optimizer, reducer, warmup)
+        except BaseException:
+            # A capture that raised must leave nothing behind: the caller falls back to another launch mode ON THE SAME model and reducer
+            # (bench.py does), where a reducer still in recording mode would never exchange a bucket again and installed cuts would make an
+            # ordinary backward stop at the top segment.
+            if reducer is not None and hasattr(reducer, "end_collect"):
+                reducer.end_collect()
+            self.close()
+            raise
+
+    def close(self) -> None:
+        """Take the cut points out of the model (idempotent).  The step cannot run afterwards."""
+        if getattr(self.model, "install_autograd_cuts", None) is not None:
+            self.model.install_autograd_cuts(None)
+        self.cuts.reset()
+        self.graphs, self._opt_pieces, self._opt_graph = [], [], None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def _capture(self, model, optimizer, reducer, warmup) -> None:
         if not torch.cuda.is_available():
             raise RuntimeError("PiecewiseGraphedTrainStep(capture=True) needs a GPU")
         _refuse_live_autograd_graphs(model)
@@ -257,7 +293,8 @@ class PiecewiseGraphedTrainStep:
 
         model.zero_grad(set_to_none=True)
         self.cuts.reset()
-        loss = piece(lambda: self._loss_fn(self.model(**self.static)))
+        with self.cuts.arm():
+            loss = piece(lambda: self._loss_fn(self.model(**self.static)))
         self.loss = loss.detach()
         trainable = [p for p in model.parameters() if p.requires_grad]
         last_touched, seen = {}, {}
@@ -272,11 +309,13 @@ class PiecewiseGraphedTrainStep:
             if reducer is not None:
                 reducer.begin_collect()
             prev = F.set_grad_arena(arena)
+            buckets = []
             try:
                 piece(seg)
             finally:
                 F.set_grad_arena(prev)
-            buckets = reducer.end_collect() if reducer is not None else []
+                if reducer is not None:
+                    buckets = reducer.end_collect()      # also when the capture raised: the reducer must not stay in recording mode
             self.segment_buckets.append(_merge_arena_buckets(buckets, arena))
             for p in trainable:                 # which segment wrote (or accumulated into) which gradient
                 if p.grad is not None:
@@ -321,7 +360,8 @@ class PiecewiseGraphedTrainStep:
         rng = torch.cuda.get_rng_state()                    # (the pass must not shift the dropout stream of the steps that follow)
         ctx = self.reducer.no_sync() if self.reducer is not None and hasattr(self.reducer, "no_sync") else contextlib.nullcontext()
         with ctx:
-            loss = self._loss_fn(self.model(**self.static))
+            with self.cuts.arm():
+                loss = self._loss_fn(self.model(**self.static))
             for seg in self.cuts.segments(loss):
                 arena = F.GradArena()
                 prev = F.set_grad_arena(arena)
@@ -341,7 +381,8 @@ class PiecewiseGraphedTrainStep:
         that un-fused parameters, whose gradient is accumulated by two segments, are exchanged after the last one (reducer.finish())."""
         self.model.zero_grad(set_to_none=True)
         self.cuts.reset()
-        loss = self._loss_fn(self.model(**self.static))
+        with self.cuts.arm():
+            loss = self._loss_fn(self.model(**self.static))
         if self.reducer is not None:
             self.reducer.defer_loose = True
         try:

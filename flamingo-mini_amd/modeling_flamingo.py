@@ -107,10 +107,12 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
             # a K / V projection call must not serve layers of two segments (its backward node would be entered by both): one call per
             # segment, or per whole fraction of one
             if not (self.kv_project_group > 0 and seg % self.kv_project_group == 0):
-                self._kv_group_before_cuts = self.kv_project_group
+                self._kv_group_before_cuts = (self.kv_project_group, seg)
                 self.kv_project_group = seg
         elif hasattr(self, "_kv_group_before_cuts"):
-            self.kv_project_group = self._kv_group_before_cuts
+            before, set_to = self._kv_group_before_cuts
+            if self.kv_project_group == set_to:     # still what the cuts set (a reducer's close() may have restored its own value meanwhile)
+                self.kv_project_group = before
             del self._kv_group_before_cuts
         for i, hook in enumerate(self.get_modified_layers()):
             hook.autograd_cut = cuts.cut if (cuts is not None and i > 0 and i % max(1, segment_layers) == 0) else None

@@ -16,10 +16,20 @@ from __future__ import annotations
 import os
 import sys
 
+# Bit-reproducible output: float64 BLAS reductions depend on how many threads split them, so every pool is pinned to ONE
+# thread before numpy / torch load their BLAS, and torch is told to refuse nondeterministic algorithms.  With that, two runs in this
+# container give byte-identical files (tests/test_oracle_golden.py::test_interchange_fixture_regenerates_bit_for_bit).
+for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ[_v] = "1"
+
 import numpy as np
 import torch
 
+torch.set_num_threads(1)
+torch.use_deterministic_algorithms(True)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("FLAMINGO_GOLDEN_OUT", HERE)        # where the fixture is written (the regeneration test writes to a scratch directory)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 for p in (ROOT, os.path.join(ROOT, "tests"), HERE):
     if p not in sys.path:
@@ -89,7 +99,7 @@ def main():
     assert float(np.abs(logits.numpy() - before).max()) > 1e-4, "the optimizer step must have changed the function"
     save = {"t." + k: v.numpy() for k, v in exported.items()}
     save.update(logits=logits.numpy(), lr=np.array(LR))
-    np.savez_compressed(os.path.join(HERE, "interchange_gpt2_tiny.npz"), **save)
+    np.savez_compressed(os.path.join(OUT, "interchange_gpt2_tiny.npz"), **save)
     print("interchange_gpt2_tiny:", len(exported), "trainable tensors exported by the build, loaded by the reference; logits", tuple(logits.shape),
           "max |delta logits| vs the unstepped weights", float(np.abs(logits.numpy() - before).max()))
 

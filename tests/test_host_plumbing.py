@@ -128,8 +128,62 @@ def test_segmented_backward_equals_one_backward_on_the_product_gradient_flow(cle
     grouped = [int(c.split("[")[1][:-1]) for c in host.calls if c.startswith("ff_xattn_wgrad_grouped")]
     assert grouped == [1] * n_hooks, grouped
     assert host.calls.index("ff_resampler_bwd") > max(i for i, c in enumerate(host.calls) if c.startswith("ff_xattn_wgrad_grouped"))
-    model.install_autograd_cuts(None)
+    # While the step is not running, the installed cut points are inert: an ordinary training-mode backward on the same model
+    # reaches every layer and the resampler, and records no pairs.
+    model.zero_grad(set_to_none=True)
+    plain = _loss(model, z, [0, 1], torch.float32)
+    plain.backward()
+    assert step.cuts.pairs == []
+    got = _grads(model)
+    for k in want:
+        assert np.isfinite(got[k]).all() and _close(got[k], want[k], 2e-4), k
+    step.close()
     assert all(h.autograd_cut is None for h in model.flamingo.get_modified_layers())
+    step.close()                                            # idempotent
+
+
+def test_a_piecewise_step_that_fails_to_capture_leaves_model_and_reducer_as_it_found_them(clean_patches, monkeypatch):
+    """bench.py falls back to another launch mode ON THE SAME model and reducer when the piecewise capture raises.  The failed
+    constructor must have ended the reducer's recording mode (a reducer left recording never exchanges a bucket again) and removed the cut
+    points (an ordinary backward would stop at the top segment), and must have restored the K / V projection group."""
+    from flamingo_mini_amd import graphs
+    model, z, _ = _model("host")
+
+    class Recorder:
+        def __init__(self):
+            self.collecting = False
+        def begin_collect(self):
+            self.collecting = True
+        def end_collect(self):
+            self.collecting = False
+            return []
+
+    red = Recorder()
+    kv_before = model.flamingo.kv_project_group
+
+    def failing_capture(self, model_, optimizer, reducer, warmup):      # what a capture does up to the point where a segment's capture raises
+        reducer.begin_collect()
+        raise RuntimeError("capture refused")
+
+    monkeypatch.setattr(graphs.PiecewiseGraphedTrainStep, "_capture", failing_capture)
+    with pytest.raises(RuntimeError, match="capture refused"):
+        graphs.PiecewiseGraphedTrainStep(model, None, _batch(z, [0, 1], torch.float32), capture=True, segment_layers=1, reducer=red)
+    assert not red.collecting
+    assert all(h.autograd_cut is None for h in model.flamingo.get_modified_layers())
+    assert model.flamingo.kv_project_group == kv_before
+
+
+def test_uninstalling_cuts_after_a_reducer_closed_does_not_resurrect_a_stale_kv_group(clean_patches):
+    """ADVICE r04 (order hazard): cuts installed (K / V group 0 -> segment size), then a reducer-style change of the group, then the cuts
+    removed: the group the cuts had saved is stale by then and must not be written back."""
+    model, z, _ = _model("host")
+    from flamingo_mini_amd.graphs import AutogradCuts
+    assert model.flamingo.kv_project_group == 0
+    model.install_autograd_cuts(AutogradCuts(), 2)
+    assert model.flamingo.kv_project_group == 2
+    model.flamingo.kv_project_group = 1                     # somebody else's setting, made after the cuts were installed
+    model.install_autograd_cuts(None)
+    assert model.flamingo.kv_project_group == 1
 
 
 def test_reducers_restore_the_models_launch_structure_on_close(clean_patches):
@@ -143,9 +197,13 @@ def test_reducers_restore_the_models_launch_structure_on_close(clean_patches):
     undo = _bucket_launch_structure(model)
     blocks = [h.xattn_block for h in model.flamingo.get_modified_layers()]
     assert model.flamingo.kv_project_group == 4 and all(b.wgrad_group == 4 for b in blocks) and F._wgrad_queue.group == before
-    for m, prev in undo:
-        m.set_launch_structure(**prev)
-    assert model.flamingo.kv_project_group == 0 and all(b.wgrad_group == 7 for b in blocks)
+    from flamingo_mini_amd.data_parallel import _restore_launch_structure
+    # what the user changes AFTER the reducer was built survives close(): one block's group, and a key the reducer never touched
+    blocks[0].wgrad_group = 2
+    model.set_launch_structure(hoist_kv=False)
+    _restore_launch_structure(undo)
+    assert model.flamingo.kv_project_group == 0 and blocks[0].wgrad_group == 2 and all(b.wgrad_group == 7 for b in blocks[1:])
+    assert model.flamingo.hoist_kv is False
 
 
 def test_per_layer_projection_and_cached_decoding_on_the_host_library(clean_patches):
@@ -208,7 +266,9 @@ def _worker(rank, world, port, out_dir, mode):
         reducer.finish()
         out.update({"acc." + k: v for k, v in _grads(model).items()})
         reducer.close()
-        assert model.flamingo.kv_project_group == 0        # close() restores what the constructor found (one projection call for all layers)
+        # close() takes back what the reducer set where it still stands (every block's weight-gradient group), and leaves alone what was
+        # changed afterwards (the K / V projection group, set to 1 above)
+        assert model.flamingo.kv_project_group == 1 and all(h.xattn_block.wgrad_group is None for h in model.flamingo.get_modified_layers())
     elif mode == "piecewise":
         # the segmented step (graphs.PiecewiseGraphedTrainStep, eager launches on CPU ranks): bucket exchanges are issued from inside each
         # segment's backward, the tied embedding - accumulated by two segments - is exchanged once, in finish()

@@ -143,3 +143,18 @@ def test_xattn_block_torch_port_matches_reference(path):
     with torch.no_grad():
         out_c, _ = TP.gated_xattn_block(yt[:, -1:], None, ml, pt, n_visual=n_visual, previous_kv=(k, v), **kw)
     assert rel(out_c.numpy(), z["y_out_cached_last"]) < tol
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("FLAMINGO_REFERENCE", "/root/reference")),
+                    reason="regenerating a fixture imports the reference (build container only)")
+def test_interchange_fixture_regenerates_bit_for_bit(tmp_path):
+    """VERDICT r04 (fixture hygiene): tests/golden/make_interchange.py pins every BLAS pool to one thread and refuses nondeterministic torch
+    algorithms, so a fresh run in the build container reproduces the committed file byte for byte (a child process: the generator patches
+    transformers' from_pretrained and sets thread limits)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FLAMINGO_GOLDEN_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(G, "make_interchange.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(os.path.join(G, "interchange_gpt2_tiny.npz"), "rb") as f, open(tmp_path / "interchange_gpt2_tiny.npz", "rb") as g:
+        assert f.read() == g.read()

@@ -14,6 +14,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 #              <= 6.7e-3 on outputs (six stacked resampler layers, config D) and <= 9.7e-3 on gradients                -> 8e-3 / 1.2e-2
 #              The reference's own bf16-vs-fp32 deviation is 6.6e-3 (resampler) / 2.9e-3 (xattn block).
 TOL = {torch.float32: dict(out=5e-6, grad=1e-5), torch.bfloat16: dict(out=8e-3, grad=1.2e-2)}
+# A THIRD class: the WHOLE drop-in model in bf16 against the reference's float64 vectors - the stock CLIP and GPT-2 stacks run in
+# bf16 on PyTorch-ROCm here too, so every stock op rounds on top of the fusion path's own error and the module tolerances above do not apply.
+# Measured on an MI355X (rounds 2 and 4): logits 8.9e-3 (tiny GPT-2 fixture) / 6.5e-3 (h64 fixture, step 1), worst parameter gradient
+# 1.5e-2 / 1.1e-2, loss |difference| <= 1.2e-2; step 2 of the h64 fixture (weights have left the bf16 grid) is held to twice these bounds,
+# measured 2.0e-2 / 3.6e-2.  Used by tests/test_model_plumbing.py::test_full_gpt2_model_bf16_on_hip and ::test_h64_bf16_two_steps_...
+TOL_FULL_BF16 = dict(out=1.5e-2, grad=2.5e-2, loss=3e-2)
 
 
 def gate_grad_ok(got, ref, tol, scale) -> bool:

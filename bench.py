@@ -105,6 +105,9 @@ def parse():
                          "launch structure follows it)")
     ap.add_argument("--wgrad-group", type=int, default=0, help="gated layers per grouped weight-gradient launch (0 = default: 12, or 4 with collectives)")
     ap.add_argument("--kv-group", type=int, default=-1, help="gated layers per K / V projection call (-1 = default: all, or 4 with collectives)")
+    ap.add_argument("--sync-exchange", default="on", choices=["on", "off"],
+                    help="off: the gated blocks keep to_out (+ gate + residual) and d LN(y) as launches of their own instead of running them inside the fused "
+                         "attention launches through the in-launch exchange (ff_xattn_desc.sync; A/B timing)")
     ap.add_argument("--lm-dropout", type=float, default=None, help="debugging aid: dropout probability inside the stock LM (default: the architecture's)")
     ap.add_argument("--profile-steps", type=int, default=3, help="instrumented eager steps after the timed region (roofline objects)")
     ap.add_argument("--stock-tuning", default="auto", choices=["auto", "on", "off"],
@@ -175,14 +178,19 @@ def gemm_profile_summary(lib, ffi, max_records):
     groups, shapes, attn = {}, {}, {}
     for i in range(n):
         r = recs[i]
-        if r.tile in (-4, -5):   # fused LayerNorm + projection + attention of a cross-attention block (forward / backward): every operand once
+        if r.tile in (-4, -5, -6, -7):   # fused LayerNorm + projection + attention of a cross-attention block (forward / backward): every operand once
             es = 2 if r.dtype == ffi.DTYPE_BF16 else 4
             heads, dh = r.a_layout, r.split_k
             batch, inner = r.nz // heads, heads * dh
             rows_d, rows_i, kv_i, w_b = batch * r.M * r.K * es, batch * r.M * inner * es, batch * r.N * inner * es, inner * r.K * es
+            # -6 / -7 (round 5): the same launches with to_out + gate + residual resp. d LN(y) = d q . Wq inside (in-launch exchange): the second
+            # weight, the re-read of O / d Q by the sample's workgroups, and the outputs y1 + to_out(o) resp. d LN(y)
             nbytes = {-4: 2 * rows_d + w_b + 2 * kv_i + 2 * rows_i,            # y, yn | Wq | K, V | Qs, O
-                      -5: rows_d + w_b + 3 * rows_i + 4 * kv_i}[r.tile]        # dy1 | Wo | Qs, O, dQ | K, V, dK, dV
-            a = attn.setdefault({-4: "xattn_fused_fwd", -5: "xattn_fused_bwd"}[r.tile], dict(ms=0.0, bytes=0.0, launches=0))
+                      -5: rows_d + w_b + 3 * rows_i + 4 * kv_i,                # dy1 | Wo | Qs, O, dQ | K, V, dK, dV
+                      -6: 4 * rows_d + 2 * w_b + 2 * kv_i + 3 * rows_i,        # y, yn, y1, to_out(o) | Wq, Wo | K, V | Qs, O, O again
+                      -7: 2 * rows_d + 2 * w_b + 4 * rows_i + 4 * kv_i}[r.tile]    # dy1, d LN(y) | Wo, Wq | Qs, O, dQ, dQ again | K, V, dK, dV
+            a = attn.setdefault({-4: "xattn_fused_fwd", -5: "xattn_fused_bwd", -6: "xattn_fused_fwd", -7: "xattn_fused_bwd"}[r.tile], dict(ms=0.0, bytes=0.0, launches=0))
+            a["with_out_projection"] = r.tile in (-6, -7)
             a["ms"] += r.ms; a["bytes"] += nbytes; a["launches"] += 1
             continue
         if r.tile < 0:      # attention core: algorithmic HBM bytes = each of Q, K, V, O (and their gradients) touched once
@@ -494,6 +502,9 @@ def main():
     reducer = None if sharded else GradientAllReducer(model, reduce_dtype=torch.float32 if args.reduce_dtype == "f32" else None,
                                                       force_collectives=args.force_collectives)
     # explicit launch structure (after the reducer chose its own): what tools/bucket_timeline.py traces on one GPU
+    if args.sync_exchange == "off":
+        from flamingo_mini_amd import functional as _F
+        _F.use_sync_exchange = False
     if args.wgrad_group > 0:
         model.set_launch_structure(wgrad_group=args.wgrad_group)
     if args.kv_group >= 0:
@@ -755,7 +766,7 @@ def main():
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
                        "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "rccl_channels": (args.rccl_channels or None), "segment_layers": (args.segment_layers if graph_mode == "piecewise" else None), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
-                       "hoisted_kv": bool(model.flamingo.hoist_kv), "stock_gemm_tuning_file": stock_tuned,
+                       "hoisted_kv": bool(model.flamingo.hoist_kv), "sync_exchange": args.sync_exchange == "on", "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,
         }
@@ -763,7 +774,8 @@ def main():
             result["attention_roofline"] = {
                 k: {"bound": "hbm", "achieved": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 4), "launches": v["launches"],
-                    "avg_launch_us": round(v["ms"] / v["launches"] * 1e3, 2), "avg_launch_mb": round(v["bytes"] / v["launches"] / 1e6, 2)}
+                    "avg_launch_us": round(v["ms"] / v["launches"] * 1e3, 2), "avg_launch_mb": round(v["bytes"] / v["launches"] / 1e6, 2),
+                    **({"with_out_projection": True} if v.get("with_out_projection") else {})}
                 for k, v in attn.items()}
         if bucket_timeline is not None:
             result["bucket_timeline"] = bucket_timeline

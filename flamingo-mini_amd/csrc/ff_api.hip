@@ -489,9 +489,14 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     } else {
         Kp = ck; Vp = cv;
     }
+    bool out_fused = false;
     if (xa_fused_enabled() && xa_fused_supported(s.dt, s.dh, s.d, s.inner)) {
         // y = norm(y); q = to_q(y) * scale; masked softmax(q k^T) v (:74-78, :95-123) in ONE launch per block
-        FF_TRY(xa_qattn_fwd(xa_fused_args(*d, s, cached), s.dt, s.dh, y, P[2], P[3], P[4], Kp, Vp, tt, S.yn, S.Qs, S.O, S.mean_a, S.rstd_a, S.lse, st));
+        // ... and, with a sync buffer at the training / decode shape, y1 = y + tanh(alpha_attn) * to_out(o) (:126, :180) in the same launch
+        const XaFusedArgs fa = xa_fused_args(*d, s, cached);
+        const XaOutArgs oa = {(const bf16*)P[6], (const bf16*)P[0], (bf16*)S.y1, (bf16*)S.attn_out, (unsigned*)d->sync};
+        out_fused = d->sync != nullptr && xa_out_fusable(fa, s.dt, s.dh);
+        FF_TRY(xa_qattn_fwd(fa, s.dt, s.dh, y, P[2], P[3], P[4], Kp, Vp, tt, S.yn, S.Qs, S.O, S.mean_a, S.rstd_a, S.lse, st, out_fused ? &oa : nullptr));
     } else {
         // y = norm(y); q = to_q(y) * scale (:74-78)
         FF_TRY(layernorm_fwd(ln_args(s.dt, M, s.d, pd, pd, pd), y, nullptr, P[2], P[3], S.yn, S.mean_a, S.rstd_a, st));
@@ -499,7 +504,7 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
         FF_TRY(attention_fwd(xa_attn_desc(*d, s, cached), S.Qs, Kp, Vp, tt, S.O, S.lse, st));           // :95-123
     }
     // y = y + tanh(alpha_attn) * to_out(o) (:126, :180)
-    FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(0, pI).c(pd).problem(S.O, P[6], S.y1, S.attn_out, nullptr, y, P[0]).run(W.ws, W.ws_bytes, st));
+    if (!out_fused) FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(0, pI).c(pd).problem(S.O, P[6], S.y1, S.attn_out, nullptr, y, P[0]).run(W.ws, W.ws_bytes, st));
     // y = y + tanh(alpha_ffw) * ffw(y) (:182)
     if (decode_ffw_supported(s.dt, M, s.d, s.ffi))      // <= 32 rows (the cached decode step): LayerNorm + up-projection and down-projection + gate + residual, two launches
         return decode_ffw(M, s.d, s.ffi, s.act, 1e-5f, S.y1, P[7], P[8], P[9], P[10], P[1], S.xn_f, S.mean_f, S.rstd_f, S.Hpre, S.Aact, S.ffw_out, y_out,
@@ -569,11 +574,16 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     char* dV = dK + (size_t)s.inner * s.es;
     const void* Kp = hoisted ? ext_k : S.KV;
     const void* Vp = hoisted ? ext_v : (const void*)((const char*)S.KV + (size_t)s.inner * s.es);
+    bool dyn_fused = false;
     if (xa_fused_enabled() && xa_fused_supported(s.dt, s.dh, s.d, s.inner)) {
         // d o = tanh(alpha_attn) * d y1 . Wo and the attention backward in one launch (two when the queries of a sample span several tiles)
+        // ... and, with a sync buffer at the training shape, d LN(y) = scale * d Qs . Wq in the same launch
         int single = 0;
-        FF_TRY(xa_dattn_bwd(xa_fused_args(*d, s, hoisted), s.dt, s.dh, T.dy1, P[6], P[0], S.Qs, Kp, Vp, tt, S.O, S.lse, W.dO, T.dQs, dK, dV, attn_ws,
-                            &single, st));
+        const XaFusedArgs fa = xa_fused_args(*d, s, hoisted);
+        const XaOutArgs oa = {(const bf16*)P[4], nullptr, (bf16*)W.dyn, nullptr, (unsigned*)d->sync};
+        dyn_fused = d->sync != nullptr && xa_out_fusable(fa, s.dt, s.dh);
+        FF_TRY(xa_dattn_bwd(fa, s.dt, s.dh, T.dy1, P[6], P[0], S.Qs, Kp, Vp, tt, S.O, S.lse, W.dO, T.dQs, dK, dV, attn_ws, &single, st,
+                            dyn_fused ? &oa : nullptr));
         if (!single) FF_TRY(attention_bwd_dkv(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, W.dO, S.lse, attn_ws, dK, dV, st));
     } else {
         FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(T.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
@@ -584,7 +594,7 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
         FF_TRY(Gemm(s.dt, 2 * s.inner, s.dv, Mk).a(1, pKV).b(1, pV).c(pV).problem(W.dKV, vf, G[5]).run(W.ws, gws, st));
         if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(W.ws, gws, st));
     }
-    FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(T.dQs, P[4], W.dyn).run(W.ws, gws, st));
+    if (!dyn_fused) FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(T.dQs, P[4], W.dyn).run(W.ws, gws, st));
     if (defer_ln) {
         FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, T.dy1, G[2], G[3], T.lnp_a,
                              layernorm_bwd_partial_bytes(M, s.d), st, nullptr, &pend_a));
@@ -726,7 +736,7 @@ static int kv_project_bwd(const ff_kvproj_desc* d, const void* vf, const void* c
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
-extern "C" int ff_version(void) { return 3; }
+extern "C" int ff_version(void) { return 4; }
 extern "C" const char* ff_arch(void) { return "gfx950"; }
 extern "C" const char* ff_last_error(void) { return ff::g_err; }
 
@@ -750,6 +760,15 @@ extern "C" int ff_resampler_bwd(const ff_resampler_desc* d, const void* x_f, con
     return ff::resampler_bwd(d, x_f, params, dout, saved, saved_bytes, grads, dx_f, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
+extern "C" size_t ff_xattn_sync_bytes(void) { return (size_t)(2 * FF_XATTN_SYNC_SLOTS + 64) * sizeof(unsigned); }
+extern "C" int ff_xattn_sync_status(const void* sync, hipStream_t stream) {
+    FF_CHECK(sync, FF_ERR_SHAPE, "ff_xattn_sync_status: null buffer");
+    unsigned flag = 0;
+    hipError_t e = hipMemcpyAsync(&flag, (const unsigned*)sync + 2 * FF_XATTN_SYNC_SLOTS, sizeof(flag), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "ff_xattn_sync_status: %s", hipGetErrorString(e));
+    return flag ? 1 : 0;
+}
 extern "C" size_t ff_xattn_saved_bytes(const ff_xattn_desc* d) {
     if (ff::xa_check(d) != FF_OK) return 0;
     ff::XaSaved S;

@@ -143,14 +143,27 @@ struct XaFusedArgs {
     int reserved;
     ff_strides k, v, dk, dv;
 };
+// Phase 2 of the resident kernels (round 5): the product over all heads of a sample inside the same launch.  Forward: W = to_out.weight
+// [dim][inner], out = y1 = y + tanh(*gate) * O . W^T, aux = O . W^T.  Backward: W = to_q.weight [inner][dim], out = scale * dQs . W (d LN(y)).
+// sync: the caller-owned counters of ff_xattn_desc.sync.
+struct XaOutArgs {
+    const bf16* W;
+    const bf16* gate;
+    bf16* out;
+    bf16* aux;
+    unsigned* sync;
+};
+// whether xa_qattn_fwd / xa_dattn_bwd will take the resident kernels WITH phase 2 for this problem when handed a sync buffer
+bool xa_out_fusable(const XaFusedArgs& a, int dtype, int dim_head);
 bool xa_fused_supported(int dtype, int dim_head, int dim, int inner);
 // LayerNorm(y) -> q = to_q * scale -> masked attention; writes Qs, O, lse, the LayerNorm statistics and (optionally) the normalised rows yn
 int xa_qattn_fwd(const XaFusedArgs& a, int dtype, int dim_head, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K,
-                 const void* V, const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st);
+                 const void* V, const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st,
+                 const XaOutArgs* out = nullptr);
 // d O = tanh(*gate) * d y1 . Wo -> d Q (and d K / d V when *single_tile comes back 1; otherwise d O and Dsum are left for attention_bwd_dkv)
 int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1, const void* Wo, const void* gate, const void* Qs, const void* K,
                  const void* V, const int* tt, const void* O, const float* lse, void* dO, void* dQ, void* dK, void* dV, float* Dsum,
-                 int* single_tile, hipStream_t st);
+                 int* single_tile, hipStream_t st, const XaOutArgs* out = nullptr);
 
 // ---- decode-shaped feed-forward (ff_decode.hip): <= 32 rows, activations resident in LDS, weights streamed HBM -> VGPR -> MFMA ----
 bool decode_ffw_supported(int dtype, int M, int d, int ffi);

@@ -811,6 +811,25 @@ template <int PER> FF_DEV void res_out_park(float* tile, const f32x4 (&acc)[kOut
 #pragma unroll
     for (int j = 0; j < PER; j++) *(f32x4*)(tile + row * LD + col0 + j * 16 + g * 4) = acc[j];
 }
+// DMA waves: byte offsets of this wave's pieces + the first kOutNS - 1 tiles of the slice
+template <int PER, int BL>
+FF_DEV void res_out_start(const RowMap& b_map, int n0, __amdgpu_buffer_rsrc_t rb, bf16* ring, unsigned (&vb)[kOutMaxPer], unsigned b_step, int nk2, int pw, int l) {
+    res_out_prepare<PER, BL>(b_map, n0, pw, l, vb);
+#pragma unroll
+    for (int s2 = 0; s2 < kOutNS - 1; s2++)
+        if (s2 < nk2) res_out_issue<PER, BL>(rb, ring, vb, b_step, s2, pw);
+}
+// all eight waves: the product, then the fp32 tile parked where the ring was (`sP`, rows of 32 PER + 4 floats)
+template <int PER, int BL>
+FF_DEV void res_out_phase(const bf16* sA2, bf16* ring, __amdgpu_buffer_rsrc_t rb, const unsigned (&vb)[kOutMaxPer], unsigned b_step, int nk2, int w, int c, int g,
+                          float* sP) {
+    f32x4 acc2[kOutMaxPer];
+#pragma unroll
+    for (int j = 0; j < kOutMaxPer; j++) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    res_out_project<PER, BL>(sA2, ring, rb, vb, b_step, nk2, w, acc2);
+    __syncthreads();                                                   // the ring is dead: it takes the fp32 tile
+    if (w < 4) res_out_park<PER>(sP, acc2, w, c, g);
+}
 #define FF_RES_PER(per, ...)                                         \
     switch (per) {                                                   \
         case 1: { constexpr int PER = 1; __VA_ARGS__; } break;       \
@@ -823,12 +842,14 @@ template <int PER> FF_DEV void res_out_park(float* tile, const f32x4 (&acc)[kOut
 
 }  // namespace
 
-template <int NSB>
+// OUTP: phase 2 - to_out + tanh gate + residual for this workgroup's column slice of all 32 rows (see the helpers above); `O` is then
+// written through and read back by the sample's other workgroups, so it is NOT __restrict__ in that instantiation's eyes.
+template <int NSB, bool OUTP>
 __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs a_in, const bf16* __restrict__ y, const bf16* __restrict__ gamma,
                                                                const bf16* __restrict__ beta, const bf16* __restrict__ Wq, const bf16* __restrict__ K,
                                                                const bf16* __restrict__ V, const int* __restrict__ tt, bf16* __restrict__ yn,
-                                                               bf16* __restrict__ Qs, bf16* __restrict__ O, float* __restrict__ mean,
-                                                               float* __restrict__ rstd, float* __restrict__ lse) {
+                                                               bf16* __restrict__ Qs, bf16* O, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, float* __restrict__ lse, const XaOutArgs o_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const XaFusedArgs a = fetch_args(a_in);
     constexpr int DH = kResDH, BM = kResBM, NT = DH / 16;
@@ -950,7 +971,17 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
     res_project<NSB, 0>(sA, sB, rw, w_map, vb, nk, w, acc);
     __syncthreads();                                                   // the ring is dead: it becomes the Q tile
     if (w < 4) res_park(sQ, acc, a.scale, w, c, g);
-    __syncthreads();
+    res_barrier();                                                     // (raw: phase 2's weight tiles, requested next, stay in flight across later barriers)
+    // ---- phase 2, requests first: the activation rows are dead too - their place takes the ring of the Wo slice (rows n0 .. n0 + cs - 1) ----
+    const XaOutArgs oa = OUTP ? fetch_args(o_in) : XaOutArgs{};
+    const int cs = a.dim / a.heads, per = cs / 32, n0 = h * cs, nk2 = a.inner / kBK;
+    bf16* ring2 = sA;
+    unsigned vo[kOutMaxPer] = {kOobOffset, kOobOffset, kOobOffset, kOobOffset, kOobOffset, kOobOffset};
+    const __amdgpu_buffer_rsrc_t rwo = __builtin_amdgcn_make_buffer_rsrc((void*)(OUTP ? oa.W : Wq), 0, 0x7fffffff, 0x00020000);
+    const RowMap wo_map{a.inner, 0, 0};
+    if (OUTP && w >= 4) {
+        FF_RES_PER(per, (res_out_start<PER, 0>(wo_map, n0, rwo, ring2, vo, 2u, nk2, w - 4, l)));
+    }
     if (t < 256) {                                                     // saved for backward: 32 rows x 8 pieces
         const int r = t >> 3, ch = t & 7;
         if (r < n_rows) *(uint4*)(Qs + ((long long)b * a.n_q + r) * a.inner + h * DH + ch * 8) = *(const uint4*)(sQ + SwzLayout::off(r, ch * 8));
@@ -969,18 +1000,52 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
         lsum = group_sum(lsum);
         if (own_ok) {
             const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-            store_acc_row<bf16, DH>(O + ((long long)b * a.n_q + m_own) * a.inner + h * DH, o, inv, g);
+            bf16* orow = O + ((long long)b * a.n_q + m_own) * a.inner + h * DH;
+            if (OUTP) store_acc_row_wt(orow, o, inv, g);
+            else store_acc_row<bf16, DH>(orow, o, inv, g);
             if (g == 0) lse[((long long)b * a.heads + h) * a.n_q + m_own] = lsum > 0.f ? m + __logf(lsum) : kPosBig;
+        }
+        if (OUTP) wait_vmcnt<0>();                                     // this wave's share of O has left the CU
+    }
+    if (!OUTP) return;
+
+    // ---- phase 2: attn_out = O . Wo^T for the columns [n0, n0 + cs) of the sample's rows; y1 = y + tanh(alpha) * attn_out ----
+    res_barrier();                                                     // the workgroup's tile of O is out
+    unsigned* cnt = oa.sync + (b % kSyncSlots);
+    if (t == 0) res_await(cnt, res_arrive(cnt, (unsigned)a.heads), oa.sync + kSyncStatus);
+    res_barrier();                                                     // every head's tile of this sample is out
+    bf16* sA2 = sB;                                                    // [inner / 64][32][64]: the dead weight ring, Q tile and key tiles
+    res_issue_rows_sc1(O + (long long)b * a.n_q * a.inner, a.inner, n_rows, sA2, w, l);
+    wait_vmcnt<0>();                                                   // (also: the first three tiles of the Wo slice, requested long ago)
+    res_barrier();
+    float* sP = (float*)ring2;
+    FF_RES_PER(per, (res_out_phase<PER, 0>(sA2, ring2, rwo, vo, 2u, nk2, w, c, g, sP)));
+    __syncthreads();
+    {
+        const float gt = tanhf(to_f32(oa.gate[0]));
+        const int cpr = cs / 8, ld = cs + 4;
+        for (int i = t; i < n_rows * cpr; i += 512) {
+            const int r = i / cpr, c8 = i - r * cpr;
+            const float* src = sP + r * ld + c8 * 8;
+            const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+            const long long go = ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8;
+            float yv[8], av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, ov[8];
+            Vec<bf16>::load(y + go, yv);
+#pragma unroll
+            for (int e = 0; e < 8; e++) ov[e] = av[e] * gt + yv[e];
+            Vec<bf16>::store(oa.aux + go, av);                         // to_out(attention): an operand of d alpha_attn
+            Vec<bf16>::store(oa.out + go, ov);
         }
     }
 }
 
-template <int NSB>
+// OUTP: phase 2 - d LN(y) = scale * dQs . Wq for this workgroup's column slice of all 32 rows (dQ is written through and read back).
+template <int NSB, bool OUTP>
 __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs a_in, const bf16* __restrict__ dy1, const bf16* __restrict__ Wo,
                                                                const bf16* __restrict__ gate, const bf16* __restrict__ Qs, const bf16* __restrict__ K,
                                                                const bf16* __restrict__ V, const int* __restrict__ tt, const bf16* __restrict__ O,
-                                                               const float* __restrict__ lse, bf16* __restrict__ dQ, bf16* __restrict__ dK,
-                                                               bf16* __restrict__ dV, float* __restrict__ Dsum) {
+                                                               const float* __restrict__ lse, bf16* dQ, bf16* __restrict__ dK,
+                                                               bf16* __restrict__ dV, float* __restrict__ Dsum, const XaOutArgs o_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const XaFusedArgs a = fetch_args(a_in);
     constexpr int DH = kResDH, BM = kResBM, NT = DH / 16;
@@ -1066,9 +1131,29 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
         for (int dt = 0; dt < NT; dt++) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int bhi = __any(rr.hi > rr.lo) ? min(a.n_kv, kTile) : 0;
         attn_dq_loop<bf16, DH, DmaStage64>(d, fq, fdo, rr, Lq, Dq, 0, bhi, Kb, Vb, sK, sV, dq, 0);
-        if (own_ok) store_acc_row<bf16, DH>(dQ + ((long long)b * a.n_q + m_own) * a.inner + h * DH, dq, 1.f, g);
+        if (own_ok) {
+            bf16* qrow = dQ + ((long long)b * a.n_q + m_own) * a.inner + h * DH;
+            if (OUTP) store_acc_row_wt(qrow, dq, 1.f, g);
+            else store_acc_row<bf16, DH>(qrow, dq, 1.f, g);
+        }
+        if (OUTP) wait_vmcnt<0>();                                      // this wave's share of dQ has left the CU
     }
-    __syncthreads();                                                    // the per-query tables are complete
+    __syncthreads();                                                    // the per-query tables are complete (and, OUTP, the workgroup's tile of dQ is out)
+    // ---- phase 2, first half: count this workgroup in and request the first tiles of the Wq slice (columns n0 .. n0 + cs - 1) into the dead
+    //      activation rows - the other heads' workgroups arrive while this one computes dK / dV ----
+    const XaOutArgs oa = OUTP ? fetch_args(o_in) : XaOutArgs{};
+    const int cs = a.dim / a.heads, per = cs / 32, n0 = h * cs, nk2 = a.inner / kBK;
+    bf16* ring2 = sA;
+    unsigned vo[kOutMaxPer] = {kOobOffset, kOobOffset, kOobOffset, kOobOffset, kOobOffset, kOobOffset};
+    const __amdgpu_buffer_rsrc_t rwq = __builtin_amdgcn_make_buffer_rsrc((void*)(OUTP ? oa.W : Wo), 0, 0x7fffffff, 0x00020000);
+    const RowMap wq_map{a.dim, 0, 0};
+    const unsigned wq_step = (unsigned)a.dim * 2u;
+    unsigned* cnt = OUTP ? oa.sync + kSyncSlots + (b % kSyncSlots) : nullptr;
+    unsigned target = 0;
+    if (OUTP) {
+        if (t == 0) target = res_arrive(cnt, (unsigned)a.heads);
+        if (w >= 4) FF_RES_PER(per, (res_out_start<PER, 1>(wq_map, n0, rwq, ring2, vo, wq_step, nk2, w - 4, l)));
+    }
 
     // ---- own rows = keys (all of the sample's queries and keys are in this tile): dK, dV ----
     if (att) {
@@ -1084,6 +1169,29 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
         if (kok) {
             store_acc_row<bf16, DH>(dK + b * a.dk.sb + (long long)key * a.dk.sr + h * a.dk.sh, acc_k, 1.f, g);
             store_acc_row<bf16, DH>(dV + b * a.dv.sb + (long long)key * a.dv.sr + h * a.dv.sh, acc_v, 1.f, g);
+        }
+    }
+    if (!OUTP) return;
+
+    // ---- phase 2, second half: d LN(y)[m][n] = scale * sum_k dQs[m][k] Wq[k][n] for the columns [n0, n0 + cs) of the sample's rows ----
+    res_barrier();                                                      // the tiles in LDS are dead
+    if (t == 0) res_await(cnt, target, oa.sync + kSyncStatus);
+    res_barrier();                                                      // every head's tile of dQ is out
+    bf16* sA2 = sB;                                                     // [inner / 64][32][64] over the dead ring / dO tile
+    res_issue_rows_sc1(dQ + (long long)b * a.n_q * a.inner, a.inner, n_rows, sA2, w, l);
+    wait_vmcnt<0>();
+    res_barrier();
+    float* sP = (float*)ring2;
+    FF_RES_PER(per, (res_out_phase<PER, 1>(sA2, ring2, rwq, vo, wq_step, nk2, w, c, g, sP)));
+    __syncthreads();
+    {
+        const int cpr = cs / 8, ld = cs + 4;
+        for (int i = t; i < n_rows * cpr; i += 512) {
+            const int r = i / cpr, c8 = i - r * cpr;
+            const float* src = sP + r * ld + c8 * 8;
+            const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+            float ov[8] = {a0[0] * a.scale, a0[1] * a.scale, a0[2] * a.scale, a0[3] * a.scale, a1[0] * a.scale, a1[1] * a.scale, a1[2] * a.scale, a1[3] * a.scale};
+            Vec<bf16>::store(oa.out + ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8, ov);
         }
     }
 }
@@ -1159,36 +1267,50 @@ static int res_ring_depth(const XaFusedArgs& a, int dtype, int dim_head, bool bw
         if (nk >= nsb && (bwd ? res_lds_bwd(a.dim, nsb) : res_lds_fwd(a.dim, nsb)) <= 160 * 1024) return nsb;
     return 0;
 }
-template <int NSB>
+template <int NSB, bool OUTP>
 static int launch_fwd_res(const XaFusedArgs& a, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K, const void* V,
-                          const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st) {
+                          const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, const XaOutArgs& out, hipStream_t st) {
     const size_t lds = res_lds_fwd(a.dim, NSB);
-    auto kernel = xa_qattn_fwd_res_kernel<NSB>;
+    auto kernel = xa_qattn_fwd_res_kernel<NSB, OUTP>;
     FF_TRY(allow_lds(kernel, lds, "xa_qattn_fwd_res"));
     kernel<<<dim3(a.heads * a.batch), dim3(512), lds, st>>>(a, (const bf16*)y, (const bf16*)gamma, (const bf16*)beta, (const bf16*)Wq, (const bf16*)K,
-                                                             (const bf16*)V, tt, (bf16*)yn, (bf16*)Qs, (bf16*)O, mean, rstd, lse);
+                                                             (const bf16*)V, tt, (bf16*)yn, (bf16*)Qs, (bf16*)O, mean, rstd, lse, out);
     return check_launch("xa_qattn_fwd_res");
 }
-template <int NSB>
+template <int NSB, bool OUTP>
 static int launch_bwd_res(const XaFusedArgs& a, const void* dy1, const void* Wo, const void* gate, const void* Qs, const void* K, const void* V,
-                          const int* tt, const void* O, const float* lse, void* dQ, void* dK, void* dV, float* Dsum, hipStream_t st) {
+                          const int* tt, const void* O, const float* lse, void* dQ, void* dK, void* dV, float* Dsum, const XaOutArgs& out, hipStream_t st) {
     const size_t lds = res_lds_bwd(a.dim, NSB);
-    auto kernel = xa_dattn_bwd_res_kernel<NSB>;
+    auto kernel = xa_dattn_bwd_res_kernel<NSB, OUTP>;
     FF_TRY(allow_lds(kernel, lds, "xa_dattn_bwd_res"));
     kernel<<<dim3(a.heads * a.batch), dim3(512), lds, st>>>(a, (const bf16*)dy1, (const bf16*)Wo, (const bf16*)gate, (const bf16*)Qs, (const bf16*)K,
-                                                             (const bf16*)V, tt, (const bf16*)O, lse, (bf16*)dQ, (bf16*)dK, (bf16*)dV, Dsum);
+                                                             (const bf16*)V, tt, (const bf16*)O, lse, (bf16*)dQ, (bf16*)dK, (bf16*)dV, Dsum, out);
     return check_launch("xa_dattn_bwd_res");
 }
 
+// Phase 2 needs the resident kernels in BOTH directions (a block that fused to_out forward must find d LN(y) fused backward), eight heads
+// of 64 (the contraction is 8 k-steps, the operand of all heads 32 KiB), a head's column slice dim / 8 that is a whole number of 32-column
+// groups, and one counter per sample.
+bool xa_out_fusable(const XaFusedArgs& a, int dtype, int dim_head) {
+    static const int on = dbg_switch("FF_XATTN_OUTFUSE", 1);
+    if (!on || a.heads != 8 || a.inner != 8 * kResDH || a.dim % 256 != 0 || a.dim / 8 > 32 * kOutMaxPer || a.batch > kSyncSlots) return false;
+    return res_ring_depth(a, dtype, dim_head, false) != 0 && res_ring_depth(a, dtype, dim_head, true) != 0;
+}
+
 int xa_qattn_fwd(const XaFusedArgs& a, int dtype, int dim_head, const void* y, const void* gamma, const void* beta, const void* Wq, const void* K,
-                 const void* V, const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st) {
+                 const void* V, const int* tt, void* yn, void* Qs, void* O, float* mean, float* rstd, float* lse, hipStream_t st, const XaOutArgs* out) {
     FF_CHECK(xa_fused_supported(dtype, dim_head, a.dim, a.inner), FF_ERR_UNSUPPORTED, "xa_qattn_fwd: unsupported dtype / head size");
     FF_CHECK(y && gamma && beta && Wq && K && V && tt && Qs && O && mean && rstd && lse, FF_ERR_SHAPE, "xa_qattn_fwd: null argument");
-    const int pid = profile_begin(dtype, -4, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
+    FF_CHECK(!out || (xa_out_fusable(a, dtype, dim_head) && out->W && out->gate && out->out && out->aux && out->sync), FF_ERR_SHAPE,
+             "xa_qattn_fwd: phase 2 (to_out inside the launch) asked for a problem that does not take it, or with a null argument");
+    const int pid = profile_begin(dtype, out ? -6 : -4, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
     int rc;
     const int nsb = res_ring_depth(a, dtype, dim_head, false);
-    if (nsb == 6) rc = launch_fwd_res<6>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st);
-    else if (nsb == 4) rc = launch_fwd_res<4>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st);
+    const XaOutArgs none = {};
+    if (nsb == 6 && out) rc = launch_fwd_res<6, true>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, *out, st);
+    else if (nsb == 4 && out) rc = launch_fwd_res<4, true>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, *out, st);
+    else if (nsb == 6) rc = launch_fwd_res<6, false>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, none, st);
+    else if (nsb == 4) rc = launch_fwd_res<4, false>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, none, st);
     else if (a.n_q <= 32) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_fwd<T, DH, 32>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st)));
     else FF_XA_DISPATCH(dtype, dim_head, rc = (launch_fwd<T, DH, 64>(a, y, gamma, beta, Wq, K, V, tt, yn, Qs, O, mean, rstd, lse, st)));
     profile_end(pid, st);
@@ -1210,17 +1332,22 @@ static int launch_bwd(const XaFusedArgs& a, const void* dy1, const void* Wo, con
 // *single_tile = 1: d K / d V were produced too (every sample's queries fit one tile); 0: the caller runs the d K / d V kernel on dO / Dsum.
 int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1, const void* Wo, const void* gate, const void* Qs, const void* K,
                  const void* V, const int* tt, const void* O, const float* lse, void* dO, void* dQ, void* dK, void* dV, float* Dsum,
-                 int* single_tile, hipStream_t st) {
+                 int* single_tile, hipStream_t st, const XaOutArgs* out) {
     FF_CHECK(xa_fused_supported(dtype, dim_head, a.dim, a.inner), FF_ERR_UNSUPPORTED, "xa_dattn_bwd: unsupported dtype / head size");
     FF_CHECK(dy1 && Wo && gate && Qs && K && V && tt && O && lse && dQ && dK && dV && Dsum && single_tile, FF_ERR_SHAPE, "xa_dattn_bwd: null argument");
+    FF_CHECK(!out || (xa_out_fusable(a, dtype, dim_head) && out->W && out->out && out->sync), FF_ERR_SHAPE,
+             "xa_dattn_bwd: phase 2 (d LN(y) inside the launch) asked for a problem that does not take it, or with a null argument");
     const bool single = a.n_q <= 64;
     FF_CHECK(single || dO, FF_ERR_SHAPE, "xa_dattn_bwd: dO buffer needed when the queries span several tiles");
     *single_tile = single ? 1 : 0;
-    const int pid = profile_begin(dtype, -5, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
+    const int pid = profile_begin(dtype, out ? -7 : -5, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
     int rc;
     const int nsb = res_ring_depth(a, dtype, dim_head, true);
-    if (nsb == 6) rc = launch_bwd_res<6>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dQ, dK, dV, Dsum, st);
-    else if (nsb == 4) rc = launch_bwd_res<4>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dQ, dK, dV, Dsum, st);
+    const XaOutArgs none = {};
+    if (nsb == 6 && out) rc = launch_bwd_res<6, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dQ, dK, dV, Dsum, *out, st);
+    else if (nsb == 4 && out) rc = launch_bwd_res<4, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dQ, dK, dV, Dsum, *out, st);
+    else if (nsb == 6) rc = launch_bwd_res<6, false>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dQ, dK, dV, Dsum, none, st);
+    else if (nsb == 4) rc = launch_bwd_res<4, false>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dQ, dK, dV, Dsum, none, st);
     else if (a.n_q <= 32) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 32, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
     else if (single) FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 64, true>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));
     else FF_XA_DISPATCH(dtype, dim_head, rc = (launch_bwd<T, DH, 64, false>(a, dy1, Wo, gate, Qs, K, V, tt, O, lse, dO, dQ, dK, dV, Dsum, st)));

@@ -16,7 +16,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # kernels' A/B switches read the environment), or a path; default = the shipped library
 _which = os.environ.get("FLAMINGO_FUSION_LIB", "")
 LIB_PATH = os.path.join(PKG_DIR, "libflamingo_fusion_debug.so") if _which == "debug" else (_which or os.path.join(PKG_DIR, "libflamingo_fusion.so"))
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FF_OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -89,7 +89,8 @@ class KvProjDesc(C.Structure):
 class XattnDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("batch", C.c_int), ("n_tokens", C.c_int), ("dim", C.c_int), ("dim_visual", C.c_int),
                 ("n_media", C.c_int), ("n_visual", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int), ("ff_mult", C.c_int),
-                ("act", C.c_int), ("tt_stride", C.c_int), ("tt_offset", C.c_int), ("cached_k", Strides), ("cached_v", Strides)]
+                ("act", C.c_int), ("tt_stride", C.c_int), ("tt_offset", C.c_int), ("cached_k", Strides), ("cached_v", Strides),
+                ("sync", C.c_void_p)]
 
 
 _P, _SZ, _I = C.c_void_p, C.c_size_t, C.c_int
@@ -118,6 +119,8 @@ _SIGNATURES = {
     "ff_resampler_scratch_bytes": (_SZ, [C.POINTER(ResamplerDesc)]),
     "ff_resampler_fwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
     "ff_resampler_bwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _P, _SZ, _P, _P, _P, _SZ, _P]),
+    "ff_xattn_sync_bytes": (_SZ, []),
+    "ff_xattn_sync_status": (_I, [_P, _P]),
     "ff_xattn_saved_bytes": (_SZ, [C.POINTER(XattnDesc)]),
     "ff_xattn_scratch_bytes": (_SZ, [C.POINTER(XattnDesc)]),
     "ff_xattn_kv_offset": (_SZ, [C.POINTER(XattnDesc)]),

@@ -299,6 +299,41 @@ def resampler(x_f: torch.Tensor, params: Sequence[torch.Tensor], cfg) -> torch.T
 # ----------------------------------------------------------------------------------------------------
 # GatedCrossAttentionBlock
 # ----------------------------------------------------------------------------------------------------
+# ff_xattn_desc.sync: the arrival counters through which the (sample, head) workgroups of the fused cross-attention kernels exchange their
+# tiles inside a launch (to_out / d LN(y) without a launch of their own).  One buffer per device, zeroed once, at allocation; only the
+# library writes it.  Calls that share it must be stream-ordered: every block of a model runs on the stream its step runs on, and this
+# process runs one step at a time.  (Two models stepping concurrently on two streams of one device need use_sync_exchange = False.)
+_sync_buffers: dict = {}
+use_sync_exchange = True        # False: every block keeps its separate to_out / d LN(y) launches (A/B timing, debugging)
+
+
+def ensure_sync_buffer(device) -> Optional[torch.Tensor]:
+    """Allocate (once) and return the device's sync buffer.  Call sites that capture HIP graphs call this BEFORE the capture begins: the
+    zero fill must not become a graph node, and the memory must be the process's, not a graph pool's."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _sync_buffers.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                     # a capture that nobody prepared: this call keeps its separate launches
+        buf = torch.zeros(int(ffi.lib().ff_xattn_sync_bytes()), dtype=torch.uint8, device=device)
+        _sync_buffers[key] = buf
+    return buf
+
+
+def _sync_buffer(device) -> Optional[torch.Tensor]:
+    return ensure_sync_buffer(device) if use_sync_exchange else None
+
+
+def sync_exchange_status(device=None) -> int:
+    """1 if an in-launch arrival wait of the fused cross-attention kernels ever timed out on `device` (that call's output was invalid), else 0."""
+    bad = 0
+    for dev, buf in list(_sync_buffers.items()):
+        if device is None or torch.device(device).index in (None, dev):
+            bad |= int(ffi.lib().ff_xattn_sync_status(buf.data_ptr(), ffi.stream_handle(buf.device)))
+    return bad
+
+
 def _xattn_desc(y, n_media, n_visual, dim_visual, cfg, tt, tt_offset=0, ck=None, cv=None) -> ffi.XattnDesc:
     heads, dim_head, ff_mult, act = cfg
     b, L, d = y.shape
@@ -307,6 +342,9 @@ def _xattn_desc(y, n_media, n_visual, dim_visual, cfg, tt, tt_offset=0, ck=None,
     if ck is not None:
         desc.cached_k = ffi.Strides(ck.stride(0), ck.stride(2), ck.stride(1))   # (b, h, n, d) tensor -> (sb, sr, sh)
         desc.cached_v = ffi.Strides(cv.stride(0), cv.stride(2), cv.stride(1))
+    if y.is_cuda and y.dtype == torch.bfloat16 and heads == 8 and dim_head == 64 and L <= 32:
+        sync = _sync_buffer(y.device)
+        desc.sync = None if sync is None else sync.data_ptr()
     return desc
 
 

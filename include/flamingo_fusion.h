@@ -44,7 +44,8 @@ enum { FF_OK = 0, FF_ERR_SHAPE = -1, FF_ERR_UNSUPPORTED = -2, FF_ERR_WORKSPACE =
 enum { FF_DTYPE_F32 = 0, FF_DTYPE_BF16 = 1 };
 enum { FF_ACT_NONE = -1, FF_ACT_GELU = 0, FF_ACT_SQRELU = 1, FF_ACT_RELU = 2 }; /* utils.py:26-30 */
 
-int ff_version(void);          /* ABI version, bumped on any signature change (3: ff_gemm_desc.tile / .stages replace ff_gemm_set_tuning) */
+int ff_version(void);          /* ABI version, bumped on any signature change (3: ff_gemm_desc.tile / .stages replace ff_gemm_set_tuning;
+                                * 4: ff_xattn_desc.sync, ff_xattn_sync_bytes / _status, ff_resampler_layer_* / _prologue_* / _epilogue_*) */
 const char* ff_arch(void);     /* "gfx950" */
 const char* ff_last_error(void);
 
@@ -227,15 +228,28 @@ int ff_resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void* co
  * Uncached: K/V are produced in `saved` at ff_xattn_kv_offset() as (batch, n_media*n_visual, 2, heads, dim_head).
  * Non-zero cached_k / cached_v strides in the descriptor <=> K / V come from outside (cached decode or ff_kv_project_fwd); `saved`
  * then holds no K/V region (size queries and calls must use the same descriptor).
+ * `sync` (ABI 4, optional): ff_xattn_sync_bytes() bytes of device memory that were ZERO when first handed to the library and that only the
+ * library writes afterwards.  With it, and at the training / decode shape of the published configurations (bf16, 8 heads of 64, at most 32
+ * tokens and 64 keys per sample, dim a multiple of 256 up to 1536, batch <= FF_XATTN_SYNC_SLOTS), `to_out` + tanh gate + residual
+ * (gated_cross_attention.py:124-126,180) run INSIDE the fused LayerNorm -> to_q -> attention launch, and d LN(y) = d q . Wq inside the fused
+ * attention-backward launch: the eight (sample, head) workgroups of a sample exchange their tiles through per-sample arrival counters in
+ * `sync` instead of through a kernel boundary (two 64 x 64-tile GEMM launches per block and step less).  Calls that share a `sync`
+ * buffer must be ordered on one stream (the counters are per sample, not per call); NULL keeps the separate launches.  Results are the
+ * same either way up to the rounding of one fp32 sum order; the buffer's last word is an error flag (non-zero: an arrival wait timed
+ * out - a launch was denied co-residency of a sample's eight workgroups - and that call's output is invalid).
  * ------------------------------------------------------------------------------------------------------ */
 #define FF_XATTN_PARAMS 11
+#define FF_XATTN_SYNC_SLOTS 1024
 typedef struct ff_xattn_desc {
     int dtype;
     int batch, n_tokens, dim, dim_visual;
     int n_media, n_visual, heads, dim_head, ff_mult, act;
     int tt_stride, tt_offset;
     ff_strides cached_k, cached_v; /* used only when cached_k != NULL */
+    void* sync;                    /* see above; NULL = none */
 } ff_xattn_desc;
+size_t ff_xattn_sync_bytes(void);              /* (2 * FF_XATTN_SYNC_SLOTS + 64) * 4 */
+int ff_xattn_sync_status(const void* sync, ff_stream_t stream);   /* synchronises `stream`; 0 = no wait ever timed out, 1 = one did, < 0 = error */
 size_t ff_xattn_saved_bytes(const ff_xattn_desc* d);
 size_t ff_xattn_scratch_bytes(const ff_xattn_desc* d);
 size_t ff_xattn_kv_offset(const ff_xattn_desc* d);

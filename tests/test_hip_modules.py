@@ -272,6 +272,76 @@ def test_resident_fused_kernels_bf16_vs_oracle(b, L, nv, dim):
     assert rel(out_c - yd[:, -1:].detach(), want) < t["out"]
 
 
+@pytest.mark.parametrize("b,L,nv,dim", [(32, 32, 64, 1280), (5, 20, 64, 768), (3, 7, 40, 1536), (64, 32, 64, 1024), (2, 32, 64, 256), (32, 1, 64, 1280)],
+                         ids=["config-B", "L20-dim768", "L7-40keys-dim1536", "b64-dim1024", "dim256", "one-token"])
+def test_in_launch_exchange_equals_separate_launches_and_oracle(b, L, nv, dim):
+    """Round 5: with a sync buffer (ff_xattn_desc.sync) `to_out` + gate + residual run inside the fused LN -> q -> attention launch and
+    d LN(y) = d q . Wq inside the fused attention-backward launch - the eight (sample, head) workgroups of a sample exchange their tiles of
+    O / d Q through per-sample arrival counters (write-through stores, sc1 loads) instead of through a kernel boundary.
+    (1) Same results as the separate launches up to the order of one fp32 sum, and within the bf16 tolerances of the oracle;
+    (2) a hand-off must not read stale lines, whatever else the chip is doing and however warm the consumer's caches are: the same call, again
+        and again, next to a stream of unrelated matmuls that take CUs away from the launch, gives the SAME BITS every time (MI355X guide:
+        test every hand-off under uneven load, checking every word);
+    (3) no arrival wait ever timed out (the buffer's status word)."""
+    from flamingo_mini_amd import functional as F
+    dtype = torch.bfloat16
+    dv, heads, dh, ffm = 256, 8, 64, 2
+    p = xattn_params(dim, dv, heads, dh, ffm, tag=f"xch{L}{nv}{dim}")
+    m = build_block(p, dim, dv, heads, dh, nv, ffm, "gelu", dtype)
+    ml = np.zeros((b, L), np.int64)
+    ml[:, 0] = 1
+    if L > 4:
+        ml[1, 0] = 0; ml[1, 3] = 1                  # tokens 0..2 of sample 1 see nothing
+        if b > 2:
+            ml[2, L - 2] = 1                        # a second tag without a second image: uniform rows
+    yd = dev(det((b, L, dim), "xch-y"), dtype).requires_grad_(True)
+    vfd = dev(det((b, 1, nv, dv), "xch-vf"), dtype).requires_grad_(True)
+    dyd = dev(det((b, L, dim), "xch-dy"), dtype)
+    mlt = torch.as_tensor(ml).cuda()
+
+    def run():
+        for t_ in (yd, vfd, *m.parameters()):
+            t_.grad = None
+        out, _ = m(yd, vfd, mlt)
+        out.backward(dyd)
+        torch.cuda.synchronize()
+        return [out.detach().clone(), yd.grad.clone(), vfd.grad.clone()] + [q.grad.clone() for q in m.parameters()]
+
+    names = ["out", "dy", "dvf"] + [k for k, _ in m.named_parameters()]
+    assert F.use_sync_exchange
+    try:
+        F.use_sync_exchange = False
+        separate = run()
+    finally:
+        F.use_sync_exchange = True
+    fused = run()
+    assert F.sync_exchange_status() == 0
+    for k, a_, b_ in zip(names, fused, separate):
+        if a_.numel() > 1:
+            assert rel(a_, b_) < 3e-3, k            # (bf16 roundings of sums taken in another order; measured ~1e-3)
+    p64 = {k: as64(v) for k, v in m.state_dict().items()}
+    outr, _, cache = O.gated_xattn_block_fwd(as64(yd), as64(vfd), ml, p64, n_visual=nv)
+    dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd), cache, p64)
+    t = TOL[dtype]
+    assert rel(fused[0] - yd.detach(), outr - as64(yd)) < t["out"]
+    assert rel(fused[1], dyr) < t["grad"] and rel(fused[2], dvfr) < t["grad"]
+    for k, g_ in zip(names[3:], fused[3:]):
+        if gr[k].size > 1:
+            assert rel(g_, gr[k]) < t["grad"], k
+    side = torch.cuda.Stream()
+    a_ = torch.randn(4096, 4096, device="cuda", dtype=dtype)
+    for i in range(20):
+        if i % 2 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    a_ = (a_ @ a_).clamp_(-1, 1)
+        again = run()
+        for k, x_, y_ in zip(names, again, fused):
+            assert torch.equal(x_, y_), (i, k)
+    assert F.sync_exchange_status() == 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("b,L,dim,ffm,act", [(32, 1, 1280, 4, "gelu"), (4, 8, 1280, 4, "gelu"), (16, 2, 2048, 4, "gelu"), (3, 5, 256, 1, "sqrelu"),
                                              (2, 7, 768, 4, "gelu"), (8, 4, 1024, 2, "gelu"), (4, 4, 384, 4, "gelu"), (2, 3, 128, 4, "relu"),
                                              (5, 6, 640, 2, "sqrelu")],

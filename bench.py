@@ -105,6 +105,9 @@ def parse():
                          "launch structure follows it)")
     ap.add_argument("--wgrad-group", type=int, default=0, help="gated layers per grouped weight-gradient launch (0 = default: 12, or 4 with collectives)")
     ap.add_argument("--kv-group", type=int, default=-1, help="gated layers per K / V projection call (-1 = default: all, or 4 with collectives)")
+    ap.add_argument("--resampler-layerwise", default="auto", choices=["auto", "on", "off"],
+                    help="the resampler as one library call per layer (ff_resampler_layer_*: one gradient bucket per layer) instead of the stack-level call; "
+                         "auto = on with gradient collectives, off on one GPU")
     ap.add_argument("--sync-exchange", default="on", choices=["on", "off"],
                     help="off: the gated blocks keep to_out (+ gate + residual) and d LN(y) as launches of their own instead of running them inside the fused "
                          "attention launches through the in-launch exchange (ff_xattn_desc.sync; A/B timing)")
@@ -505,6 +508,8 @@ def main():
     if args.sync_exchange == "off":
         from flamingo_mini_amd import functional as _F
         _F.use_sync_exchange = False
+    if args.resampler_layerwise != "auto":
+        model.flamingo.resampler.layerwise = args.resampler_layerwise == "on"
     if args.wgrad_group > 0:
         model.set_launch_structure(wgrad_group=args.wgrad_group)
     if args.kv_group >= 0:
@@ -766,7 +771,7 @@ def main():
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
                        "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "rccl_channels": (args.rccl_channels or None), "segment_layers": (args.segment_layers if graph_mode == "piecewise" else None), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
-                       "hoisted_kv": bool(model.flamingo.hoist_kv), "sync_exchange": args.sync_exchange == "on", "stock_gemm_tuning_file": stock_tuned,
+                       "hoisted_kv": bool(model.flamingo.hoist_kv), "sync_exchange": args.sync_exchange == "on", "resampler_layerwise": bool(model.flamingo.resampler.layerwise), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,
         }

@@ -335,6 +335,204 @@ static int resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void
 }
 
 // =====================================================================================================
+// PerceiverResampler, one layer per call (SURVEY 8-b2's minimum export set: ff_resampler_layer_fwd/bwd + prologue / epilogue)
+// perceiver_resampler.py:181-183 is a per-layer loop; a caller that drives it layer by layer gets every layer's parameter gradients FINAL
+// when that layer's backward call returns - one data-parallel bucket per layer, leaving while the layer below runs backward - at the price
+// of what only the stack-level call can do (weight gradients of four layers per launch, LayerNorm finals of all layers in three launches).
+// =====================================================================================================
+struct RsProSaved { float *mean_m, *rstd_m; };
+static size_t rs_pro_layout(const RsDims& s, void* base, size_t cap, RsProSaved& o) {
+    Arena a(base, cap);
+    o.mean_m = a.take<float>((size_t)s.Bn * s.F * 4);
+    o.rstd_m = a.take<float>((size_t)s.Bn * s.F * 4);
+    return align_up(a.used);
+}
+static size_t rs_layer_saved_layout(const RsDims& s, void* base, size_t cap, RsLayerSaved& L) {
+    Arena a(base, cap);
+    const size_t rows_q = (size_t)s.Bn * s.q, rows_kv = (size_t)s.Bn * s.R;
+    L.x_in = nullptr;                           // the caller's tensor
+    L.mean_l = a.take<float>(rows_q * 4);
+    L.rstd_l = a.take<float>(rows_q * 4);
+    L.kv_in = a.take(rows_kv * s.D * s.es);
+    L.Qs = a.take(rows_q * s.inner * s.es);
+    L.K = a.take(rows_kv * s.inner * s.es);
+    L.V = a.take(rows_kv * s.inner * s.es);
+    L.lse = a.take<float>((size_t)s.Bn * s.H * s.q * 4);
+    L.O = a.take(rows_q * s.inner * s.es);
+    L.x_mid = a.take(rows_q * s.D * s.es);
+    L.mean_f = a.take<float>(rows_q * 4);
+    L.rstd_f = a.take<float>(rows_q * 4);
+    L.xn_f = a.take(rows_q * s.D * s.es);
+    L.Hpre = a.take(rows_q * s.ffi * s.es);
+    L.Aact = a.take(rows_q * s.ffi * s.es);
+    return align_up(a.used);
+}
+struct RsLayerScratch {
+    void *dxn, *dO, *dkv, *dln, *dx_mid, *dH, *dQs, *dK, *dV, *ws;
+    float* lnp[3];
+    size_t ws_bytes;
+};
+static size_t rs_layer_scratch_layout(const RsDims& s, void* base, size_t cap, RsLayerScratch& o) {
+    Arena a(base, cap);
+    const size_t rows_q = (size_t)s.Bn * s.q, rows_kv = (size_t)s.Bn * s.R;
+    o.ws_bytes = rs_ws_bytes(s);
+    o.ws = a.take(o.ws_bytes);
+    o.dxn = a.take(rows_q * s.D * s.es);
+    o.dO = a.take(rows_q * s.inner * s.es);
+    o.dkv = a.take(rows_kv * s.D * s.es);
+    o.dln = a.take(rows_q * s.D * s.es);
+    o.dx_mid = a.take(rows_q * s.D * s.es);
+    o.dH = a.take(rows_q * s.ffi * s.es);
+    o.dQs = a.take(rows_q * s.inner * s.es);
+    o.dK = a.take(rows_kv * s.inner * s.es);
+    o.dV = a.take(rows_kv * s.inner * s.es);
+    const bool lnd = layernorm_bwd_deferrable(s.dt, s.D);
+    for (int i = 0; i < 3; i++)       // [0] ff norm, [1] norm_latents, [2] norm_media
+        o.lnp[i] = lnd ? a.take<float>(layernorm_bwd_partial_bytes(i == 2 ? s.Bn * s.F : (int)rows_q, s.D)) : nullptr;
+    return align_up(a.used);
+}
+
+static int rs_prologue_fwd(const ff_resampler_desc* d, const void* x_f, const void* tpe, void* pro, size_t pro_bytes, hipStream_t st) {
+    FF_TRY(rs_check(d));
+    FF_CHECK(x_f && tpe && pro, FF_ERR_SHAPE, "resampler_prologue_fwd: null argument");
+    const RsDims s(*d);
+    RsProSaved S;
+    FF_CHECK(rs_pro_layout(s, pro, pro_bytes, S) <= pro_bytes, FF_ERR_WORKSPACE, "resampler_prologue_fwd: saved buffer too small");
+    LnArgs a = ln_args(s.dt, s.Bn * s.F, s.D, plain_rows(s.D), plain_rows(s.D), plain_rows(s.D));
+    a.add_rows_per_seg = s.F; a.add_div = s.v;       // statistics of x_f + time_pos_emb, shared by the norm_media of every layer (:166, :52)
+    return layernorm_fwd(a, x_f, tpe, nullptr, nullptr, nullptr, S.mean_m, S.rstd_m, st);
+}
+
+static int rs_layer_fwd(const ff_resampler_desc* d, const void* x_f, const void* tpe, const void* pro, size_t pro_bytes, const void* x_in,
+                        int x_is_latents, const void* const* p, void* x_out, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                        hipStream_t st) {
+    FF_TRY(rs_check(d));
+    FF_CHECK(x_f && tpe && pro && x_in && p && x_out && saved && scratch, FF_ERR_SHAPE, "resampler_layer_fwd: null argument");
+    const RsDims s(*d);
+    RsProSaved Pr;
+    RsLayerSaved L;
+    RsLayerScratch W;
+    FF_CHECK(rs_pro_layout(s, (void*)pro, pro_bytes, Pr) <= pro_bytes, FF_ERR_WORKSPACE, "resampler_layer_fwd: prologue buffer too small");
+    FF_CHECK(rs_layer_saved_layout(s, saved, saved_bytes, L) <= saved_bytes, FF_ERR_WORKSPACE, "resampler_layer_fwd: saved buffer too small");
+    FF_CHECK(rs_layer_scratch_layout(s, scratch, scratch_bytes, W) <= scratch_bytes, FF_ERR_WORKSPACE, "resampler_layer_fwd: scratch too small");
+    const int Mq = s.Bn * s.q, Mkv = s.Bn * s.R, Mf = s.Bn * s.F;
+    const RowMap pD = plain_rows(s.D), pI = plain_rows(s.inner), pF = plain_rows(s.ffi);
+    const RowMap x_map = x_is_latents ? RowMap{s.D, 0, s.q} : pD;                    // latents (q, D) repeated over the batch (:179)
+    const RowMap kv_media = RowMap{s.D, (long long)s.R * s.D, s.F}, kv_lat = RowMap{s.D, (long long)s.R * s.D, s.q};
+    char* kv_lat_base = (char*)L.kv_in + (size_t)s.F * s.D * s.es;
+    {   // norm_media -> media rows of kv_in (:52,65)
+        LnArgs a = ln_args(s.dt, Mf, s.D, pD, kv_media, pD);
+        a.add_rows_per_seg = s.F; a.add_div = s.v; a.stats_given = 1;
+        FF_TRY(layernorm_fwd(a, x_f, tpe, p[0], p[1], L.kv_in, Pr.mean_m, Pr.rstd_m, st));
+    }
+    FF_TRY(layernorm_fwd(ln_args(s.dt, Mq, s.D, x_map, kv_lat, pD), x_in, nullptr, p[2], p[3], kv_lat_base, L.mean_l, L.rstd_l, st));   // :53,65
+    FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, kv_lat).b(0, pD).c(pI).scale(s.scale).problem(kv_lat_base, p[4], L.Qs).run(W.ws, W.ws_bytes, st));   // :57,79
+    FF_TRY(Gemm(s.dt, Mkv, s.inner, s.D).a(0, pD).b(0, pD).c(pI).problem(L.kv_in, p[5], L.K).problem(L.kv_in, p[6], L.V).run(W.ws, W.ws_bytes, st));   // :69-70
+    FF_TRY(attention_fwd(rs_attn_desc(s), L.Qs, L.K, L.V, nullptr, L.O, L.lse, st));                                                  // :85-92
+    FF_TRY(Gemm(s.dt, Mq, s.D, s.inner).a(0, pI).b(0, pI).c(pD).res_map(x_map).problem(L.O, p[7], L.x_mid, nullptr, nullptr, x_in).run(W.ws, W.ws_bytes, st));   // :96, :182
+    FF_TRY(layernorm_fwd(ln_args(s.dt, Mq, s.D, pD, pD, pD), L.x_mid, nullptr, p[8], p[9], L.xn_f, L.mean_f, L.rstd_f, st));          // :183; utils.py:45-50
+    FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(0, pD).c(pF).act(s.act).problem(L.xn_f, p[10], L.Aact, L.Hpre).run(W.ws, W.ws_bytes, st));
+    return Gemm(s.dt, Mq, s.D, s.ffi).a(0, pF).b(0, pF).c(pD).problem(L.Aact, p[11], x_out, nullptr, nullptr, L.x_mid).run(W.ws, W.ws_bytes, st);
+}
+
+static int rs_layer_bwd(const ff_resampler_desc* d, const void* x_f, const void* tpe, const void* pro, size_t pro_bytes, const void* x_in,
+                        int x_is_latents, const void* const* p, const void* dx_out, const void* saved, size_t saved_bytes, void* const* g,
+                        void* dx_in, void* dx_f, int dx_f_accumulate, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    FF_TRY(rs_check(d));
+    FF_CHECK(x_f && tpe && pro && x_in && p && dx_out && saved && g && dx_in && dx_f && scratch, FF_ERR_SHAPE, "resampler_layer_bwd: null argument");
+    const RsDims s(*d);
+    RsProSaved Pr;
+    RsLayerSaved L;
+    RsLayerScratch W;
+    FF_CHECK(rs_pro_layout(s, (void*)pro, pro_bytes, Pr) <= pro_bytes, FF_ERR_WORKSPACE, "resampler_layer_bwd: prologue buffer too small");
+    FF_CHECK(rs_layer_saved_layout(s, (void*)saved, saved_bytes, L) <= saved_bytes, FF_ERR_WORKSPACE, "resampler_layer_bwd: saved buffer too small");
+    FF_CHECK(rs_layer_scratch_layout(s, scratch, scratch_bytes, W) <= scratch_bytes, FF_ERR_WORKSPACE, "resampler_layer_bwd: scratch too small");
+    const int Mq = s.Bn * s.q, Mkv = s.Bn * s.R, Mf = s.Bn * s.F;
+    const RowMap pD = plain_rows(s.D), pI = plain_rows(s.inner), pF = plain_rows(s.ffi);
+    const RowMap x_map = x_is_latents ? RowMap{s.D, 0, s.q} : pD;
+    const RowMap kv_media = RowMap{s.D, (long long)s.R * s.D, s.F}, kv_lat = RowMap{s.D, (long long)s.R * s.D, s.q};
+    float* attn_ws = (float*)((char*)W.ws + W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4));
+    const size_t gws = W.ws_bytes - align_up((size_t)s.Bn * s.H * s.q * 4);
+    char* dkv_lat_base = (char*)W.dkv + (size_t)s.F * s.D * s.es;
+    const char* kv_lat_base = (const char*)L.kv_in + (size_t)s.F * s.D * s.es;
+    LnPending ln_sets[3];
+    auto ln_bwd = [&](int slot, const LnArgs& a, const void* dy_, const void* x_, const void* add_, const void* gamma_, const float* mean_,
+                      const float* rstd_, void* dx_, const void* dx_res_, void* dg_, void* db_) -> int {
+        if (W.lnp[slot])
+            return layernorm_bwd(a, dy_, x_, add_, gamma_, mean_, rstd_, dx_, dx_res_, dg_, db_, W.lnp[slot], layernorm_bwd_partial_bytes(a.rows, a.cols), st,
+                                 nullptr, &ln_sets[slot]);
+        return layernorm_bwd(a, dy_, x_, add_, gamma_, mean_, rstd_, dx_, dx_res_, dg_, db_, W.ws, gws, st);
+    };
+    // ---- FeedForward backward (x_out = x_mid + W3 act(W1 LN(x_mid))) ----
+    FF_TRY(Gemm(s.dt, Mq, s.ffi, s.D).a(0, pD).b(1, pF).c(pF).act_bwd(s.act).problem(dx_out, p[11], W.dH, nullptr, L.Hpre).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, Mq, s.D, s.ffi).a(0, pF).b(1, pD).c(pD).problem(W.dH, p[10], W.dxn).run(W.ws, gws, st));
+    FF_TRY(ln_bwd(0, ln_args(s.dt, Mq, s.D, pD, pD, pD), W.dxn, L.x_mid, nullptr, p[8], L.mean_f, L.rstd_f, W.dx_mid, dx_out, g[8], g[9]));
+    // ---- attention backward (x_mid = x_in + Wo O) ----
+    FF_TRY(Gemm(s.dt, Mq, s.inner, s.D).a(0, pD).b(1, pI).c(pI).problem(W.dx_mid, p[7], W.dO).run(W.ws, gws, st));
+    FF_TRY(attention_bwd(rs_attn_desc(s), L.Qs, L.K, L.V, nullptr, L.O, W.dO, L.lse, W.dQs, W.dK, W.dV, attn_ws, (size_t)s.Bn * s.H * s.q * 4, st));
+    FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(W.dK, p[5], W.dkv).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, Mkv, s.D, s.inner).a(0, pI).b(1, pD).c(pD).problem(W.dV, p[6], W.dkv, nullptr, nullptr, W.dkv).run(W.ws, gws, st));
+    FF_TRY(Gemm(s.dt, Mq, s.D, s.inner).a(0, pI).b(1, pD).c(pD).res_map(kv_lat).scale(s.scale)
+               .problem(W.dQs, p[4], W.dln, nullptr, nullptr, dkv_lat_base).run(W.ws, gws, st));
+    FF_TRY(ln_bwd(1, ln_args(s.dt, Mq, s.D, x_map, pD, pD), W.dln, x_in, nullptr, p[2], L.mean_l, L.rstd_l, dx_in, W.dx_mid, g[2], g[3]));
+    {   // norm_media backward: d x_f accumulates over the layers (needed for d time_pos_emb even with CLIP frozen)
+        LnArgs a = ln_args(s.dt, Mf, s.D, pD, kv_media, pD);
+        a.add_rows_per_seg = s.F; a.add_div = s.v;
+        FF_TRY(ln_bwd(2, a, W.dkv, x_f, tpe, p[0], Pr.mean_m, Pr.rstd_m, dx_f, dx_f_accumulate ? dx_f : nullptr, g[0], g[1]));
+    }
+    FF_TRY(layernorm_bwd_finish(s.dt, ln_sets, 3, st));
+    // ---- this layer's weight gradients, final when the call returns ----
+    FF_TRY(Gemm(s.dt, s.D, s.ffi, Mq).a(1, pD).b(1, pF).c(pF).problem(dx_out, L.Aact, g[11]).run(W.ws, gws, st));          // d W3 = d x_out^T . act(H)
+    FF_TRY(Gemm(s.dt, s.ffi, s.D, Mq).a(1, pF).b(1, pD).c(pD).problem(W.dH, L.xn_f, g[10]).run(W.ws, gws, st));           // d W1 = d H^T . LN(x_mid)
+    FF_TRY(Gemm(s.dt, s.D, s.inner, Mq).a(1, pD).b(1, pI).c(pI).problem(W.dx_mid, L.O, g[7]).run(W.ws, gws, st));         // d Wo = d x_mid^T . O
+    FF_TRY(Gemm(s.dt, s.inner, s.D, Mq).a(1, pI).b(1, kv_lat).c(pD).scale(s.scale).problem(W.dQs, kv_lat_base, g[4]).run(W.ws, gws, st));   // d Wq
+    return Gemm(s.dt, s.inner, s.D, Mkv).a(1, pI).b(1, pD).c(pD).problem(W.dK, L.kv_in, g[5]).problem(W.dV, L.kv_in, g[6]).run(W.ws, gws, st);  // d Wk, d Wv
+}
+
+static int rs_prologue_bwd(const ff_resampler_desc* d, const void* dx0, const void* dx_f, void* d_latents, void* d_tpe, void* scratch,
+                           size_t scratch_bytes, hipStream_t st) {
+    FF_TRY(rs_check(d));
+    FF_CHECK(dx0 && dx_f && d_latents && d_tpe && scratch, FF_ERR_SHAPE, "resampler_prologue_bwd: null argument");
+    const RsDims s(*d);
+    RsLayerScratch W;
+    FF_CHECK(rs_layer_scratch_layout(s, scratch, scratch_bytes, W) <= scratch_bytes, FF_ERR_WORKSPACE, "resampler_prologue_bwd: scratch too small");
+    const RowMap pD = plain_rows(s.D);
+    // d latents = sum over the batch of d x_0 (:179);  d time_pos_emb[t] = sum_{b, n} d x_f[b, t, n] (:166)
+    FF_TRY(rows_reduce(s.dt, s.Bn * s.q, s.D, pD, s.q, 1, dx0, d_latents, W.ws, W.ws_bytes, st));
+    if (s.nte > s.T) {
+        hipError_t e = hipMemsetAsync((char*)d_tpe + (size_t)s.T * s.D * s.es, 0, (size_t)(s.nte - s.T) * s.D * s.es, st);
+        FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "resampler_prologue_bwd: memset: %s", hipGetErrorString(e));
+    }
+    return rows_reduce(s.dt, s.Bn * s.F, s.D, pD, s.F, s.v, dx_f, d_tpe, W.ws, W.ws_bytes, st);
+}
+
+static int rs_epilogue_fwd(const ff_resampler_desc* d, const void* x_last, const void* gamma, const void* beta, void* out, void* epi, size_t epi_bytes,
+                           hipStream_t st) {
+    FF_TRY(rs_check(d));
+    FF_CHECK(x_last && gamma && beta && out && epi, FF_ERR_SHAPE, "resampler_epilogue_fwd: null argument");
+    const RsDims s(*d);
+    const size_t rows_q = (size_t)s.Bn * s.q;
+    FF_CHECK(epi_bytes >= 2 * align_up(rows_q * 4), FF_ERR_WORKSPACE, "resampler_epilogue_fwd: saved buffer too small");
+    float* mean = (float*)epi;
+    float* rstd = (float*)((char*)epi + align_up(rows_q * 4));
+    return layernorm_fwd(ln_args(s.dt, (int)rows_q, s.D, plain_rows(s.D), plain_rows(s.D), plain_rows(s.D)), x_last, nullptr, gamma, beta, out, mean, rstd, st);   // :187
+}
+static int rs_epilogue_bwd(const ff_resampler_desc* d, const void* dout, const void* x_last, const void* gamma, const void* epi, size_t epi_bytes,
+                           void* dx_last, void* dgamma, void* dbeta, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    FF_TRY(rs_check(d));
+    FF_CHECK(dout && x_last && gamma && epi && dx_last && dgamma && dbeta && scratch, FF_ERR_SHAPE, "resampler_epilogue_bwd: null argument");
+    const RsDims s(*d);
+    const size_t rows_q = (size_t)s.Bn * s.q;
+    FF_CHECK(epi_bytes >= 2 * align_up(rows_q * 4), FF_ERR_WORKSPACE, "resampler_epilogue_bwd: saved buffer too small");
+    RsLayerScratch W;
+    FF_CHECK(rs_layer_scratch_layout(s, scratch, scratch_bytes, W) <= scratch_bytes, FF_ERR_WORKSPACE, "resampler_epilogue_bwd: scratch too small");
+    const float* mean = (const float*)epi;
+    const float* rstd = (const float*)((const char*)epi + align_up(rows_q * 4));
+    return layernorm_bwd(ln_args(s.dt, (int)rows_q, s.D, plain_rows(s.D), plain_rows(s.D), plain_rows(s.D)), dout, x_last, nullptr, gamma, mean, rstd, dx_last,
+                         nullptr, dgamma, dbeta, W.ws, W.ws_bytes, st);
+}
+
+// =====================================================================================================
 // GatedCrossAttentionBlock
 // =====================================================================================================
 struct XaDims {
@@ -495,7 +693,9 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
         // ... and, with a sync buffer at the training / decode shape, y1 = y + tanh(alpha_attn) * to_out(o) (:126, :180) in the same launch
         const XaFusedArgs fa = xa_fused_args(*d, s, cached);
         const XaOutArgs oa = {(const bf16*)P[6], (const bf16*)P[0], (bf16*)S.y1, (bf16*)S.attn_out, (unsigned*)d->sync};
-        out_fused = d->sync != nullptr && xa_out_fusable(fa, s.dt, s.dh);
+        // (not at the decode shape, <= 32 rows in all: there `to_out` is a 3.7 us weight-streaming launch and the in-launch exchange costs more
+        // than that launch and its boundary - measured, r5s1: phase 2 adds ~10 us to the fused launch)
+        out_fused = d->sync != nullptr && xa_out_fusable(fa, s.dt, s.dh) && !decode_ffw_supported(s.dt, M, s.d, s.ffi);
         FF_TRY(xa_qattn_fwd(fa, s.dt, s.dh, y, P[2], P[3], P[4], Kp, Vp, tt, S.yn, S.Qs, S.O, S.mean_a, S.rstd_a, S.lse, st, out_fused ? &oa : nullptr));
     } else {
         // y = norm(y); q = to_q(y) * scale (:74-78)
@@ -758,6 +958,56 @@ extern "C" int ff_resampler_bwd(const ff_resampler_desc* d, const void* x_f, con
                                 const void* saved, size_t saved_bytes, void* const* grads, void* dx_f, void* scratch,
                                 size_t scratch_bytes, ff_stream_t stream) {
     return ff::resampler_bwd(d, x_f, params, dout, saved, saved_bytes, grads, dx_f, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t ff_resampler_prologue_saved_bytes(const ff_resampler_desc* d) {
+    if (ff::rs_check(d) != FF_OK) return 0;
+    ff::RsProSaved S;
+    return ff::rs_pro_layout(ff::RsDims(*d), nullptr, 0, S);
+}
+extern "C" size_t ff_resampler_layer_saved_bytes(const ff_resampler_desc* d) {
+    if (ff::rs_check(d) != FF_OK) return 0;
+    ff::RsLayerSaved L;
+    return ff::rs_layer_saved_layout(ff::RsDims(*d), nullptr, 0, L);
+}
+extern "C" size_t ff_resampler_layer_scratch_bytes(const ff_resampler_desc* d) {
+    if (ff::rs_check(d) != FF_OK) return 0;
+    ff::RsLayerScratch W;
+    return ff::rs_layer_scratch_layout(ff::RsDims(*d), nullptr, 0, W);
+}
+extern "C" size_t ff_resampler_epilogue_saved_bytes(const ff_resampler_desc* d) {
+    if (ff::rs_check(d) != FF_OK) return 0;
+    return 2 * ff::align_up((size_t)d->batch * d->num_latents * 4);
+}
+extern "C" int ff_resampler_prologue_fwd(const ff_resampler_desc* d, const void* x_f, const void* time_pos_emb, void* saved_pro, size_t saved_pro_bytes,
+                                         hipStream_t stream) {
+    return ff::rs_prologue_fwd(d, x_f, time_pos_emb, saved_pro, saved_pro_bytes, stream);
+}
+extern "C" int ff_resampler_layer_fwd(const ff_resampler_desc* d, const void* x_f, const void* time_pos_emb, const void* saved_pro, size_t saved_pro_bytes,
+                                      const void* x_in, int x_in_is_latents, const void* const* layer_params, void* x_out, void* saved, size_t saved_bytes,
+                                      void* scratch, size_t scratch_bytes, hipStream_t stream) {
+    return ff::rs_layer_fwd(d, x_f, time_pos_emb, saved_pro, saved_pro_bytes, x_in, x_in_is_latents, layer_params, x_out, saved, saved_bytes, scratch,
+                            scratch_bytes, stream);
+}
+extern "C" int ff_resampler_layer_bwd(const ff_resampler_desc* d, const void* x_f, const void* time_pos_emb, const void* saved_pro, size_t saved_pro_bytes,
+                                      const void* x_in, int x_in_is_latents, const void* const* layer_params, const void* dx_out, const void* saved,
+                                      size_t saved_bytes, void* const* layer_grads, void* dx_in, void* dx_f, int dx_f_accumulate, void* scratch,
+                                      size_t scratch_bytes, hipStream_t stream) {
+    return ff::rs_layer_bwd(d, x_f, time_pos_emb, saved_pro, saved_pro_bytes, x_in, x_in_is_latents, layer_params, dx_out, saved, saved_bytes, layer_grads,
+                            dx_in, dx_f, dx_f_accumulate, scratch, scratch_bytes, stream);
+}
+extern "C" int ff_resampler_prologue_bwd(const ff_resampler_desc* d, const void* dx0, const void* dx_f, void* d_latents, void* d_time_pos_emb, void* scratch,
+                                         size_t scratch_bytes, hipStream_t stream) {
+    return ff::rs_prologue_bwd(d, dx0, dx_f, d_latents, d_time_pos_emb, scratch, scratch_bytes, stream);
+}
+extern "C" int ff_resampler_epilogue_fwd(const ff_resampler_desc* d, const void* x_last, const void* norm_weight, const void* norm_bias, void* out,
+                                         void* saved_epi, size_t saved_epi_bytes, hipStream_t stream) {
+    return ff::rs_epilogue_fwd(d, x_last, norm_weight, norm_bias, out, saved_epi, saved_epi_bytes, stream);
+}
+extern "C" int ff_resampler_epilogue_bwd(const ff_resampler_desc* d, const void* dout, const void* x_last, const void* norm_weight, const void* saved_epi,
+                                         size_t saved_epi_bytes, void* dx_last, void* d_norm_weight, void* d_norm_bias, void* scratch, size_t scratch_bytes,
+                                         hipStream_t stream) {
+    return ff::rs_epilogue_bwd(d, dout, x_last, norm_weight, saved_epi, saved_epi_bytes, dx_last, d_norm_weight, d_norm_bias, scratch, scratch_bytes, stream);
 }
 
 extern "C" size_t ff_xattn_sync_bytes(void) { return (size_t)(2 * FF_XATTN_SYNC_SLOTS + 64) * sizeof(unsigned); }

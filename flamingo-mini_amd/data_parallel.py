@@ -46,6 +46,11 @@ def _bucket_launch_structure(model: torch.nn.Module, layers_per_bucket: int = 4)
                 if blk.wgrad_group != layers_per_bucket:
                     undo.append((blk, "wgrad_group", blk.wgrad_group, layers_per_bucket))
                     blk.wgrad_group = layers_per_bucket
+        if hasattr(m, "layerwise") and hasattr(m, "fused_params") and not m.layerwise:
+            # the resampler layer by layer (ff_resampler_layer_*): one gradient bucket per layer, final when that layer's backward is done,
+            # instead of all of the resampler's gradients at the very end of backward
+            undo.append((m, "layerwise", False, True))
+            m.layerwise = True
     return undo
 
 

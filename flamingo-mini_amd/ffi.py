@@ -119,6 +119,16 @@ _SIGNATURES = {
     "ff_resampler_scratch_bytes": (_SZ, [C.POINTER(ResamplerDesc)]),
     "ff_resampler_fwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
     "ff_resampler_bwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _P, _SZ, _P, _P, _P, _SZ, _P]),
+    "ff_resampler_prologue_saved_bytes": (_SZ, [C.POINTER(ResamplerDesc)]),
+    "ff_resampler_layer_saved_bytes": (_SZ, [C.POINTER(ResamplerDesc)]),
+    "ff_resampler_layer_scratch_bytes": (_SZ, [C.POINTER(ResamplerDesc)]),
+    "ff_resampler_epilogue_saved_bytes": (_SZ, [C.POINTER(ResamplerDesc)]),
+    "ff_resampler_prologue_fwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _SZ, _P]),
+    "ff_resampler_layer_fwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _SZ, _P, _I, _P, _P, _P, _SZ, _P, _SZ, _P]),
+    "ff_resampler_epilogue_fwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _P, _P, _SZ, _P]),
+    "ff_resampler_epilogue_bwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
+    "ff_resampler_layer_bwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _SZ, _P, _I, _P, _P, _P, _SZ, _P, _P, _P, _I, _P, _SZ, _P]),
+    "ff_resampler_prologue_bwd": (_I, [C.POINTER(ResamplerDesc), _P, _P, _P, _P, _P, _SZ, _P]),
     "ff_xattn_sync_bytes": (_SZ, []),
     "ff_xattn_sync_status": (_I, [_P, _P]),
     "ff_xattn_saved_bytes": (_SZ, [C.POINTER(XattnDesc)]),

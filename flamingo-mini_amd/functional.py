@@ -296,6 +296,150 @@ def resampler(x_f: torch.Tensor, params: Sequence[torch.Tensor], cfg) -> torch.T
     return _ResamplerFn.apply(x_f, tuple(cfg), *params)
 
 
+# ---- the resampler driven LAYER BY LAYER (ff_resampler_layer_* + prologue / epilogue; perceiver_resampler.py:181-183) ----
+# One autograd node per layer: a layer's twelve parameter gradients are final - and announced as a bucket of their own - when that layer's
+# backward has been enqueued, so under data parallelism layer 5's gradients leave while layer 4 runs backward (the stack-level call hands
+# over all 63 M resampler gradients at once, at the very end of backward).  d x_f is summed over the layers in ONE buffer that the layers'
+# backward calls accumulate into; it travels outside autograd (`_RsPass`), and the prologue node - whose token LAYER 0 consumes: layer 0's
+# backward is the last of the layers' (d x flows 5 -> 0), also when every layer is a backward segment of its own (graphs.AutogradCuts between
+# the layers: one autograd call per segment, each with its own dependency count) - turns it into d time_pos_emb (and hands it on as d x_f),
+# and the batch-sum of layer 0's input gradient into d latents.
+class _RsPass:
+    """What the layer-wise backward of ONE resampler forward shares: the d x_f accumulator and layer 0's input gradient."""
+
+    def __init__(self):
+        self.dxf: Optional[torch.Tensor] = None
+        self.dx0: Optional[torch.Tensor] = None
+
+
+class _RsPrologueFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_f, tpe, latents, cfg, rs_pass):
+        lib = ffi.lib()
+        desc = _resampler_desc(x_f, cfg)
+        pro = _empty_bytes(lib.ff_resampler_prologue_saved_bytes(desc), x_f.device)
+        ffi.check(lib.ff_resampler_prologue_fwd(desc, x_f.data_ptr(), tpe.data_ptr(), pro.data_ptr(), pro.numel(), ffi.stream_handle(x_f.device)),
+                  "ff_resampler_prologue_fwd")
+        ctx.cfg, ctx.rs_pass = cfg, rs_pass
+        ctx.save_for_backward(x_f, tpe, latents)
+        token = torch.zeros(1, dtype=torch.float32, device=x_f.device)       # what the layers consume: orders this node's backward behind theirs
+        ctx.mark_non_differentiable(pro)
+        return token, pro
+
+    @staticmethod
+    def backward(ctx, _dtoken, _dpro):
+        lib = ffi.lib()
+        x_f, tpe, latents = ctx.saved_tensors
+        rp = ctx.rs_pass
+        if rp.dxf is None or rp.dx0 is None:
+            raise ffi.FusionLibraryError("resampler (layer-wise): the prologue's backward ran before the layers' - the autograd graph was cut between them")
+        desc = _resampler_desc(x_f, ctx.cfg)
+        flat, grads = _flat_grads([latents, tpe])
+        scratch = _empty_bytes(lib.ff_resampler_layer_scratch_bytes(desc), x_f.device)
+        ffi.check(lib.ff_resampler_prologue_bwd(desc, rp.dx0.data_ptr(), rp.dxf.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(), scratch.data_ptr(),
+                                                scratch.numel(), ffi.stream_handle(x_f.device)), "ff_resampler_prologue_bwd")
+        _announce(flat, [latents, tpe])
+        dxf = rp.dxf if ctx.needs_input_grad[0] else None
+        rp.dxf = rp.dx0 = None
+        return dxf, grads[1], grads[0], None, None
+
+
+class _RsLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, x_f, tpe, pro, cfg, rs_pass, first, last, *params):
+        lib = ffi.lib()
+        desc = _resampler_desc(x_f, cfg)
+        dev = x_f.device
+        x = x.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        saved = _empty_bytes(lib.ff_resampler_layer_saved_bytes(desc), dev)
+        scratch = _empty_bytes(lib.ff_resampler_layer_scratch_bytes(desc), dev)
+        out = torch.empty((x_f.shape[0], cfg[3], x_f.shape[3]), dtype=x_f.dtype, device=dev)
+        ffi.check(lib.ff_resampler_layer_fwd(desc, x_f.data_ptr(), tpe.data_ptr(), pro.data_ptr(), pro.numel(), x.data_ptr(), 1 if first else 0,
+                                             ffi.ptr_array(params), out.data_ptr(), saved.data_ptr(), saved.numel(), scratch.data_ptr(), scratch.numel(),
+                                             ffi.stream_handle(dev)), "ff_resampler_layer_fwd")
+        ctx.cfg, ctx.rs_pass, ctx.first, ctx.last = cfg, rs_pass, first, last
+        ctx.save_for_backward(x, x_f, tpe, pro, saved, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = ffi.lib()
+        x, x_f, tpe, pro, saved, *params = ctx.saved_tensors
+        desc = _resampler_desc(x_f, ctx.cfg)
+        dev = x_f.device
+        rp = ctx.rs_pass
+        dout = dout.contiguous()
+        flat, grads = _flat_grads(params)
+        accumulate = rp.dxf is not None                      # the first layer_bwd call of a pass (the LAST layer) overwrites
+        if rp.dxf is None:
+            rp.dxf = torch.empty_like(x_f)
+        dx_in = torch.empty_like(dout)
+        scratch = _empty_bytes(lib.ff_resampler_layer_scratch_bytes(desc), dev)
+        ffi.check(lib.ff_resampler_layer_bwd(desc, x_f.data_ptr(), tpe.data_ptr(), pro.data_ptr(), pro.numel(), x.data_ptr(), 1 if ctx.first else 0,
+                                             ffi.ptr_array(params), dout.data_ptr(), saved.data_ptr(), saved.numel(), ffi.ptr_array(grads), dx_in.data_ptr(),
+                                             rp.dxf.data_ptr(), 1 if accumulate else 0, scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)),
+                  "ff_resampler_layer_bwd")
+        _announce(flat, params)
+        if ctx.first:                                        # d (broadcast latents): summed over the batch by the prologue's backward, which
+            rp.dx0 = dx_in                                   # this layer's token gradient sets off
+            return (None, torch.zeros(1, dtype=torch.float32, device=dev), None, None, None, None, None, None, None, *grads)
+        return (dx_in, None, None, None, None, None, None, None, None, *grads)
+
+
+class _RsEpilogueFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, x_f, cfg):
+        lib = ffi.lib()
+        desc = _resampler_desc(x_f, cfg)
+        x = x.contiguous()
+        epi = _empty_bytes(lib.ff_resampler_epilogue_saved_bytes(desc), x.device)
+        out = torch.empty_like(x)
+        ffi.check(lib.ff_resampler_epilogue_fwd(desc, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), epi.data_ptr(), epi.numel(),
+                                                ffi.stream_handle(x.device)), "ff_resampler_epilogue_fwd")
+        ctx.cfg, ctx.xf_shape = cfg, tuple(x_f.shape)
+        ctx.save_for_backward(x, gamma, beta, epi)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = ffi.lib()
+        x, gamma, beta, epi = ctx.saved_tensors
+        b, T, v, d = ctx.xf_shape
+        depth, heads, dim_head, num_latents, nte, ff_mult, act = ctx.cfg
+        desc = ffi.ResamplerDesc(ffi.dtype_code(x.dtype), b, T, v, d, depth, heads, dim_head, num_latents, nte, ff_mult, ffi.ACTS[act])
+        dout = dout.contiguous()
+        flat, grads = _flat_grads([gamma, beta])
+        dx = torch.empty_like(x)
+        scratch = _empty_bytes(lib.ff_resampler_layer_scratch_bytes(desc), x.device)
+        ffi.check(lib.ff_resampler_epilogue_bwd(desc, dout.data_ptr(), x.data_ptr(), gamma.data_ptr(), epi.data_ptr(), epi.numel(), dx.data_ptr(),
+                                                grads[0].data_ptr(), grads[1].data_ptr(), scratch.data_ptr(), scratch.numel(), ffi.stream_handle(x.device)),
+                  "ff_resampler_epilogue_bwd")
+        _announce(flat, [gamma, beta])
+        return dx, grads[0], grads[1], None, None
+
+
+def resampler_layerwise(x_f: torch.Tensor, params: Sequence[torch.Tensor], cfg, cut: Optional[Callable] = None) -> torch.Tensor:
+    """The same function as `resampler`, one library call - and one autograd node, one gradient bucket - per layer.  `cut`
+    (graphs.AutogradCuts.cut) is applied to the latents between the layers, which makes every layer its own backward segment."""
+    ffi.require_cuda(x_f, *params)
+    _same_dtype(x_f, params, "PerceiverResampler")
+    depth = cfg[0]
+    assert len(params) == ffi.RESAMPLER_GLOBAL_PARAMS + ffi.RESAMPLER_LAYER_PARAMS * depth
+    cfg = tuple(cfg)
+    x_f = x_f.contiguous()
+    latents, tpe, gamma, beta = (p.contiguous() for p in params[:4])
+    rp = _RsPass()
+    token, pro = _RsPrologueFn.apply(x_f, tpe, latents, cfg, rp)
+    x = latents
+    for i in range(depth):
+        lp = params[4 + 12 * i: 4 + 12 * (i + 1)]
+        x = _RsLayerFn.apply(x, token if i == 0 else None, x_f, tpe, pro, cfg, rp, i == 0, i == depth - 1, *lp)
+        if cut is not None and i + 1 < depth:
+            x = cut(x)
+    return _RsEpilogueFn.apply(x, gamma, beta, x_f, cfg)
+
+
 # ----------------------------------------------------------------------------------------------------
 # GatedCrossAttentionBlock
 # ----------------------------------------------------------------------------------------------------

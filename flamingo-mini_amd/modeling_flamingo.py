@@ -116,6 +116,8 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
             del self._kv_group_before_cuts
         for i, hook in enumerate(self.get_modified_layers()):
             hook.autograd_cut = cuts.cut if (cuts is not None and i > 0 and i % max(1, segment_layers) == 0) else None
+        # a resampler that runs layer by layer (data parallelism: one gradient bucket per layer) makes every layer its own backward segment
+        self.resampler.autograd_cut = cuts.cut if (cuts is not None and getattr(self.resampler, "layerwise", False)) else None
 
     def _init_weights(self, module):  # backbones initialise themselves; fusion modules use torch defaults like the reference
         pass

@@ -51,6 +51,11 @@ class PerceiverResampler(nn.Module):
             nn.ModuleList([PerceiverAttentionLayer(dim=dim, dim_head=dim_head, heads=heads), FeedForward(dim=dim, mult=ff_mult, act=act)])
             for _ in range(depth))
         self.norm = nn.LayerNorm(dim)
+        # One library call per layer (ff_resampler_layer_* + prologue / epilogue) instead of the stack-level call: every layer's gradients are
+        # final - one data-parallel bucket - when its own backward is done.  Data-parallel reducers switch it on for THEIR model; a single GPU
+        # keeps the stack-level call (weight gradients of four layers per launch).  `autograd_cut`: graphs.AutogradCuts.cut between the layers.
+        self.layerwise = False
+        self.autograd_cut = None
 
     def fused_params(self):
         """Flat parameter list in the order of include/flamingo_fusion.h (ff_resampler_fwd)."""
@@ -70,6 +75,9 @@ class PerceiverResampler(nn.Module):
         cfg = (self.depth, self.heads, self.dim_head, self.n_queries, self.num_time_embeds, self.ff_mult, self.act)
         if x_f.dtype != self.latents.dtype:
             x_f = x_f.to(self.latents.dtype)
-        out = F.resampler(x_f, self.fused_params(), cfg)
+        if self.layerwise:
+            out = F.resampler_layerwise(x_f, self.fused_params(), cfg, cut=self.autograd_cut)
+        else:
+            out = F.resampler(x_f, self.fused_params(), cfg)
         assert out.shape == (x_f.shape[0], self.n_queries, self.dim)
         return out

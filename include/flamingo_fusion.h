@@ -195,12 +195,10 @@ int ff_attention_bwd(const ff_attn_desc* d, const void* Q, const void* K, const 
  *   +8 layers.i.1.0.weight  +9 layers.i.1.0.bias  +10 layers.i.1.1.weight  +11 layers.i.1.3.weight
  * `saved` persists fwd -> bwd (activations, statistics); `scratch` is transient.
  * bwd writes every gradient (no accumulation); dx_f may be NULL (CLIP frozen) — d time_pos_emb is still exact.
- * Deviation from SURVEY.md 8-b2's minimum export set (ff_resampler_layer_fwd/bwd + ff_resampler_prologue/epilogue_*): the resampler is
- * exported as the whole stack, like the reference's own call site (modeling_flamingo.py:176 calls the module once).  Only the stack-level
- * call can share the statistics of x_f + time_pos_emb between the `depth` norm_media LayerNorms, group the weight gradients of four layers
- * per launch and finish all 3 * depth + 1 LayerNorm-backward reductions with three launches; a per-layer ABI would fix the launch
- * structure at one layer per call.  The pieces a per-layer caller would need are exported individually (ff_gemm, ff_layernorm_*,
- * ff_attention_*, ff_rows_reduce) and parity-tested on their own.
+ * This is the whole stack in one call, like the reference's own call site (modeling_flamingo.py:176 calls the module once): only the
+ * stack-level call can group the weight gradients of four layers per launch and finish all 3 * depth + 1 LayerNorm-backward reductions
+ * with three launches.  SURVEY.md 8-b2's per-layer export set (ff_resampler_layer_fwd/bwd + prologue / epilogue) follows below; it is what
+ * a data-parallel caller uses (one gradient bucket per layer).
  * ------------------------------------------------------------------------------------------------------ */
 #define FF_RESAMPLER_GLOBAL_PARAMS 4
 #define FF_RESAMPLER_LAYER_PARAMS 12
@@ -216,6 +214,43 @@ int ff_resampler_fwd(const ff_resampler_desc* d, const void* x_f, const void* co
 int ff_resampler_bwd(const ff_resampler_desc* d, const void* x_f, const void* const* params, const void* dout,
                      const void* saved, size_t saved_bytes, void* const* grads, void* dx_f, void* scratch,
                      size_t scratch_bytes, ff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * PerceiverResampler, ONE LAYER PER CALL (ABI 4; SURVEY.md 8-b2's minimum export set; perceiver_resampler.py:181-183 is a per-layer loop).
+ *   forward :  prologue_fwd (statistics of x_f + time_pos_emb, :166 / :52, shared by every layer's norm_media)
+ *              -> depth x layer_fwd (x = x + attn(x_f, x); x = x + ffw(x), :182-183; layer 0 takes the latents (num_latents, dim) with
+ *                 x_in_is_latents = 1: they are broadcast over the batch, :179)
+ *              -> epilogue_fwd (final LayerNorm, :187)
+ *   backward:  epilogue_bwd -> depth x layer_bwd (last layer first) -> prologue_bwd
+ * layer_params / layer_grads: the 12 pointers of ONE layer in the order of ff_resampler_fwd's per-layer block (+0 norm_media.weight ... +11
+ * layers.i.1.3.weight).  layer_bwd writes every one of the layer's parameter gradients - final when the call returns: a data-parallel
+ * caller gets one gradient bucket per layer, which can leave while the layer below runs backward - and d x_in (batch, num_latents, dim) (for
+ * layer 0: the gradient of the BROADCAST latents; prologue_bwd sums it over the batch), and adds its share of d x_f to `dx_f`
+ * (dx_f_accumulate = 0 for the first layer_bwd call of a pass, which overwrites).  prologue_bwd: d latents, d time_pos_emb (complete).
+ * ff_resampler_desc.depth is ignored by these calls.  `saved` buffers persist fwd -> bwd; every `scratch` is ff_resampler_layer_scratch_bytes().
+ * The stack-level ff_resampler_fwd / _bwd above remain the single-GPU fast path (they group the weight gradients of four layers per
+ * launch and finish all LayerNorm-backward reductions with three launches).
+ * ------------------------------------------------------------------------------------------------------ */
+size_t ff_resampler_prologue_saved_bytes(const ff_resampler_desc* d);
+size_t ff_resampler_layer_saved_bytes(const ff_resampler_desc* d);
+size_t ff_resampler_layer_scratch_bytes(const ff_resampler_desc* d);
+size_t ff_resampler_epilogue_saved_bytes(const ff_resampler_desc* d);
+int ff_resampler_prologue_fwd(const ff_resampler_desc* d, const void* x_f, const void* time_pos_emb, void* saved_pro, size_t saved_pro_bytes,
+                              ff_stream_t stream);
+int ff_resampler_layer_fwd(const ff_resampler_desc* d, const void* x_f, const void* time_pos_emb, const void* saved_pro, size_t saved_pro_bytes,
+                           const void* x_in, int x_in_is_latents, const void* const* layer_params, void* x_out, void* saved, size_t saved_bytes,
+                           void* scratch, size_t scratch_bytes, ff_stream_t stream);
+int ff_resampler_epilogue_fwd(const ff_resampler_desc* d, const void* x_last, const void* norm_weight, const void* norm_bias, void* out,
+                              void* saved_epi, size_t saved_epi_bytes, ff_stream_t stream);
+int ff_resampler_epilogue_bwd(const ff_resampler_desc* d, const void* dout, const void* x_last, const void* norm_weight, const void* saved_epi,
+                              size_t saved_epi_bytes, void* dx_last, void* d_norm_weight, void* d_norm_bias, void* scratch, size_t scratch_bytes,
+                              ff_stream_t stream);
+int ff_resampler_layer_bwd(const ff_resampler_desc* d, const void* x_f, const void* time_pos_emb, const void* saved_pro, size_t saved_pro_bytes,
+                           const void* x_in, int x_in_is_latents, const void* const* layer_params, const void* dx_out, const void* saved,
+                           size_t saved_bytes, void* const* layer_grads, void* dx_in, void* dx_f, int dx_f_accumulate, void* scratch,
+                           size_t scratch_bytes, ff_stream_t stream);
+int ff_resampler_prologue_bwd(const ff_resampler_desc* d, const void* dx0, const void* dx_f, void* d_latents, void* d_time_pos_emb, void* scratch,
+                              size_t scratch_bytes, ff_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * GatedCrossAttentionBlock (gated_cross_attention.py:135-184).

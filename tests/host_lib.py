@@ -87,6 +87,98 @@ class HostLib:
             _view(dx, dxf.shape)[...] = dxf
         return 0
 
+    # ---- resampler, one layer per call (ff_resampler_layer_* + prologue / epilogue) -------------------------------------
+    _LAYER_KEYS = ("0.norm_media.weight", "0.norm_media.bias", "0.norm_latents.weight", "0.norm_latents.bias", "0.to_q.weight", "0.to_k.weight",
+                   "0.to_v.weight", "0.to_out.weight", "1.0.weight", "1.0.bias", "1.1.weight", "1.3.weight")
+
+    def ff_resampler_prologue_saved_bytes(self, d):
+        return 64
+
+    def ff_resampler_layer_saved_bytes(self, d):
+        return 64
+
+    def ff_resampler_layer_scratch_bytes(self, d):
+        return 64
+
+    def ff_resampler_epilogue_saved_bytes(self, d):
+        return 64
+
+    def _layer_params(self, d, params):
+        shapes = self._rs_shapes(d)[4:16]
+        return {"layers.0." + k: _view(q, s).astype(np.float64) for k, q, s in zip(self._LAYER_KEYS, _ptrs(params, 12), shapes)}
+
+    def _xf(self, d, x, tpe):
+        xf = _view(x, (d.batch, d.n_frames, d.n_tokens, d.dim)).astype(np.float64)
+        t = _view(tpe, (d.num_time_embeds, 1, d.dim)).astype(np.float64)
+        return (xf + t[:d.n_frames]).reshape(d.batch, d.n_frames * d.n_tokens, d.dim)            # perceiver_resampler.py:166,172
+
+    def ff_resampler_prologue_fwd(self, d, x, tpe, pro, pro_n, stream):
+        self._f32(d)
+        self.calls.append("ff_resampler_prologue_fwd")
+        return 0
+
+    def ff_resampler_layer_fwd(self, d, x, tpe, pro, pro_n, x_in, is_latents, params, x_out, saved, saved_n, scratch, scratch_n, stream):
+        self._f32(d)
+        self.calls.append("ff_resampler_layer_fwd")
+        p = self._layer_params(d, params)
+        feats = self._xf(d, x, tpe)
+        if is_latents:
+            lat = _view(x_in, (d.num_latents, d.dim)).astype(np.float64)
+            xin = np.broadcast_to(lat, (d.batch,) + lat.shape).copy()                             # :179
+        else:
+            xin = _view(x_in, (d.batch, d.num_latents, d.dim)).astype(np.float64)
+        a_out, a_c = O.perceiver_attention_fwd(feats, xin, p, "layers.0.0.", d.heads, d.dim_head)
+        xm = xin + a_out                                                                           # :182
+        f_out, f_c = O.feedforward_fwd(xm, p, "layers.0.1.", _ACT[d.act])
+        _view(x_out, xm.shape)[...] = xm + f_out                                                   # :183
+        self.cache[int(saved)] = (a_c, f_c, p)
+        return 0
+
+    def ff_resampler_layer_bwd(self, d, x, tpe, pro, pro_n, x_in, is_latents, params, dx_out, saved, saved_n, grads, dx_in, dx_f, accumulate,
+                               scratch, scratch_n, stream):
+        self.calls.append("ff_resampler_layer_bwd")
+        a_c, f_c, p = self.cache.pop(int(saved))
+        g = {}
+        dx = _view(dx_out, (d.batch, d.num_latents, d.dim)).astype(np.float64)
+        dx = dx + O.feedforward_bwd(dx, f_c, p, "layers.0.1.", _ACT[d.act], g)
+        dfeat, dlat = O.perceiver_attention_bwd(dx, a_c, p, "layers.0.0.", d.heads, d.dim_head, g)
+        _view(dx_in, dx.shape)[...] = dx + dlat
+        out = _view(dx_f, (d.batch, d.n_frames * d.n_tokens, d.dim))
+        out[...] = (out.astype(np.float64) if accumulate else 0.0) + dfeat
+        shapes = self._rs_shapes(d)[4:16]
+        for k, q, s in zip(self._LAYER_KEYS, _ptrs(grads, 12), shapes):
+            _view(q, s)[...] = np.asarray(g["layers.0." + k]).reshape(s)
+        return 0
+
+    def ff_resampler_prologue_bwd(self, d, dx0, dx_f, d_latents, d_tpe, scratch, scratch_n, stream):
+        self.calls.append("ff_resampler_prologue_bwd")
+        _view(d_latents, (d.num_latents, d.dim))[...] = _view(dx0, (d.batch, d.num_latents, d.dim)).astype(np.float64).sum(axis=0)
+        dxf = _view(dx_f, (d.batch, d.n_frames, d.n_tokens, d.dim)).astype(np.float64)
+        gt = np.zeros((d.num_time_embeds, 1, d.dim))
+        gt[:d.n_frames] = dxf.sum(axis=(0, 2))[:, None, :]
+        _view(d_tpe, gt.shape)[...] = gt
+        return 0
+
+    def ff_resampler_epilogue_fwd(self, d, x_last, gamma, beta, out, epi, epi_n, stream):
+        self._f32(d)
+        self.calls.append("ff_resampler_epilogue_fwd")
+        x = _view(x_last, (d.batch, d.num_latents, d.dim)).astype(np.float64)
+        g, b = _view(gamma, (d.dim,)).astype(np.float64), _view(beta, (d.dim,)).astype(np.float64)
+        y, c = O.layernorm_fwd(x, g, b)
+        _view(out, y.shape)[...] = y
+        self.cache[int(epi)] = (c, g)
+        return 0
+
+    def ff_resampler_epilogue_bwd(self, d, dout, x_last, gamma, epi, epi_n, dx_last, dgamma, dbeta, scratch, scratch_n, stream):
+        self.calls.append("ff_resampler_epilogue_bwd")
+        c, g = self.cache.pop(int(epi))
+        dy = _view(dout, (d.batch, d.num_latents, d.dim)).astype(np.float64)
+        dx, dg, db = O.layernorm_bwd(dy, c, g)
+        _view(dx_last, dx.shape)[...] = dx
+        _view(dgamma, (d.dim,))[...] = dg
+        _view(dbeta, (d.dim,))[...] = db
+        return 0
+
     # ---- K / V projection of all layers -------------------------------------------------------------------------------
     def ff_kv_project_workspace_bytes(self, d, with_dvf):
         return 64

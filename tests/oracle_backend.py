@@ -151,9 +151,10 @@ def install():
     if _saved:
         return
     backend = OracleBackend()
-    _saved.update(resampler=F.resampler, xattn_block=F.xattn_block, text_time=F.text_time, kv_project=F.kv_project)
+    _saved.update(resampler=F.resampler, resampler_layerwise=F.resampler_layerwise, xattn_block=F.xattn_block, text_time=F.text_time, kv_project=F.kv_project)
     F.kv_project = lambda vf, weights: backend.kv_project(vf, weights)
     F.resampler = lambda x_f, params, cfg: backend.resampler(x_f, params, cfg)
+    F.resampler_layerwise = lambda x_f, params, cfg, cut=None: backend.resampler(x_f, params, cfg)      # (launch structure only: same function)
     F.xattn_block = lambda y, vf, tt, params, cfg, n_visual, previous_kv=None, output_kv=False, hoisted_kv=None, wgrad=None: \
         backend.xattn_block(y, vf, tt, params, cfg, n_visual, previous_kv, output_kv, hoisted_kv)      # (wgrad: launch structure only)
     F.text_time = lambda ml: ml.to(torch.int64).cumsum(-1).to(torch.int32)

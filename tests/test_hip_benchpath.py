@@ -149,12 +149,15 @@ def test_hoisted_deferred_blocks_ragged_batch_long_text(dtype):
     _case(dtype, b, L, N, ml, "BR", act="sqrelu", group=4)      # six blocks: one grouped weight-gradient call of four and a ragged one of two
 
 
+@pytest.mark.parametrize("layerwise", [False, True], ids=["stack-level", "layer-by-layer"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
-def test_config_B_resampler_full_batch(dtype):
-    """The resampler of config B at its full batch: (32, 1, 257, 1024) CLIP-L features, depth 6, grouped weight gradients over 4 + 2 layers."""
+def test_config_B_resampler_full_batch(dtype, layerwise):
+    """The resampler of config B at its full batch: (32, 1, 257, 1024) CLIP-L features, depth 6, grouped weight gradients over 4 + 2 layers
+    (stack-level call) resp. one library call per layer (the data-parallel launch structure: ff_resampler_layer_*)."""
     dim, depth, b = 1024, 6, 32
     p = resampler_params(dim, depth, HEADS, DH, 64, 4, 4, tag="BPrs")
     m = build_resampler(p, dim, depth, HEADS, DH, 64, 4, 4, "gelu", dtype)
+    m.layerwise = layerwise
     xd = dev(det((b, 1, 257, dim), "BPrs-x"), dtype).requires_grad_(True)
     dyd = dev(det((b, 64, dim), "BPrs-dy"), dtype)
     y = m(xd)

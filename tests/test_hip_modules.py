@@ -33,8 +33,11 @@ def _act(name):
     return "sqrelu" if "sqrelu" in name else ("relu" if "relu" in name else "gelu")
 
 
+@pytest.mark.parametrize("layerwise", [False, True], ids=["stack-level", "layer-by-layer"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rs_*.npz"))), ids=os.path.basename)
-def test_resampler_matches_reference_golden_fp32(path):
+def test_resampler_matches_reference_golden_fp32(path, layerwise):
+    """The reference's vectors through ff_resampler_fwd / _bwd (the whole stack in one call) and through SURVEY 8-b2's per-layer export set
+    (ff_resampler_prologue_* / _layer_* / _epilogue_*, one call and one autograd node per layer: PerceiverResampler.layerwise)."""
     z = np.load(path)
     name = os.path.basename(path)[:-4]
     dim, depth, heads, dim_head, q, nte, ff_mult = [int(v) for v in z["meta"]]
@@ -46,6 +49,7 @@ def test_resampler_matches_reference_golden_fp32(path):
         p = resampler_params(dim, depth, heads, dim_head, q, nte, ff_mult, tag=name)
         x, dy = det(xshape, name + "x"), det(z["y"].shape, name + "dy")
     m = build_resampler(p, dim, depth, heads, dim_head, q, nte, ff_mult, _act(name), torch.float32)
+    m.layerwise = layerwise
     xd = dev(x).requires_grad_(True)
     y = m(xd)
     assert rel(y, z["y"]) < TOL[torch.float32]["out"]
@@ -272,8 +276,8 @@ def test_resident_fused_kernels_bf16_vs_oracle(b, L, nv, dim):
     assert rel(out_c - yd[:, -1:].detach(), want) < t["out"]
 
 
-@pytest.mark.parametrize("b,L,nv,dim", [(32, 32, 64, 1280), (5, 20, 64, 768), (3, 7, 40, 1536), (64, 32, 64, 1024), (2, 32, 64, 256), (32, 1, 64, 1280)],
-                         ids=["config-B", "L20-dim768", "L7-40keys-dim1536", "b64-dim1024", "dim256", "one-token"])
+@pytest.mark.parametrize("b,L,nv,dim", [(32, 32, 64, 1280), (5, 20, 64, 768), (3, 7, 40, 1536), (64, 32, 64, 1024), (2, 32, 64, 256), (40, 1, 64, 1280)],
+                         ids=["config-B", "L20-dim768", "L7-40keys-dim1536", "b64-dim1024", "dim256", "one-token-b40"])
 def test_in_launch_exchange_equals_separate_launches_and_oracle(b, L, nv, dim):
     """Round 5: with a sync buffer (ff_xattn_desc.sync) `to_out` + gate + residual run inside the fused LN -> q -> attention launch and
     d LN(y) = d q . Wq inside the fused attention-backward launch - the eight (sample, head) workgroups of a sample exchange their tiles of
@@ -363,7 +367,7 @@ def test_decode_shaped_feedforward_bf16_vs_oracle(b, L, dim, ffm, act):
     y0 = det((b, L, dim), "dec-y")
     if dim in (384, 1024):          # a massive-activation channel in column 0 (the one-pass LayerNorm statistics are shifted by the
         y0 = y0.copy()              # row's leading elements; an outlier there must not cost the variance its digits)
-        y0[..., 0] += 40.0
+        y0[..., 0] += 8.0           # (8 sigma; much larger values only test the rounding of the stored bf16 output, which `out - y` then isolates)
     yd = dev(y0, dtype).requires_grad_(True)
     vfd = dev(det((b, 1, nv, dv), "dec-vf"), dtype).requires_grad_(True)
     dyd = dev(det((b, L, dim), "dec-dy"), dtype)

@@ -104,6 +104,63 @@ def _batch(z, rows, dtype):
                 pixel_values=torch.from_numpy(z["px"])[rows].to(dtype), labels=ids)
 
 
+def test_layerwise_resampler_equals_the_stack_level_call_and_buckets_per_layer(clean_patches):
+    """SURVEY 8-b2 as written: the resampler driven layer by layer (ff_resampler_prologue / _layer / _epilogue, one autograd node per layer)
+    computes what the stack-level call computes - loss and every gradient, incl. d latents (the batch-sum of layer 0's input gradient),
+    d time_pos_emb (from d x_f accumulated over the layers outside autograd) and d pixel-side x_f - and announces one gradient bucket per
+    layer, in backward order, each when its own layer's backward has run (the stack-level call announces ONE bucket at the very end)."""
+    from flamingo_mini_amd import functional as F
+    ref, z, _ = _model("oracle")
+    ref.zero_grad(set_to_none=True)
+    ref_loss = _loss(ref, z, [0, 1], torch.float64)
+    ref_loss.backward()
+    want = _grads(ref)
+    model, z, host = _model("host")
+    rs = model.flamingo.resampler
+    depth = rs.depth
+    rs.layerwise = True
+    names = {id(p): n for n, p in rs.named_parameters()}
+    buckets = []
+    cb = lambda flat, owners: buckets.append((len(host.calls), sorted(names[id(p)] for p, _, _ in owners if id(p) in names)))
+    F.add_grad_ready_callback(cb)
+    try:
+        model.zero_grad(set_to_none=True)
+        host.calls.clear()
+        loss = _loss(model, z, [0, 1], torch.float32)
+        loss.backward()
+    finally:
+        F.remove_grad_ready_callback(cb)
+    assert abs(float(loss) - float(ref_loss)) < 1e-4
+    got = _grads(model)
+    assert set(got) == set(want)
+    for k in want:
+        assert np.isfinite(got[k]).all() and _close(got[k], want[k], 2e-4), k
+    assert "ff_resampler_fwd" not in host.calls and "ff_resampler_bwd" not in host.calls
+    assert host.calls.count("ff_resampler_layer_fwd") == depth and host.calls.count("ff_resampler_layer_bwd") == depth
+    rs_buckets = [b for b in buckets if b[1]]
+    # epilogue (norm), then the layers from the last to the first, then the prologue (latents, time_pos_emb)
+    assert rs_buckets[0][1] == ["norm.bias", "norm.weight"]
+    for i, (_, owners) in enumerate(rs_buckets[1:1 + depth]):
+        layer = depth - 1 - i
+        assert len(owners) == 12 and all(n.startswith(f"layers.{layer}.") for n in owners), (layer, owners)
+    assert rs_buckets[1 + depth][1] == ["latents", "time_pos_emb"] and len(rs_buckets) == depth + 2
+    # every layer's bucket was announced before the next layer's backward call was made
+    bwd_calls = [i for i, c in enumerate(host.calls) if c == "ff_resampler_layer_bwd"]
+    for (at, _), nxt in zip(rs_buckets[1:depth], bwd_calls[1:]):
+        assert at <= nxt
+    # with cut points between the layers every layer is a backward segment of its own: same gradients
+    from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
+    step = PiecewiseGraphedTrainStep(model, None, _batch(z, [0, 1], torch.float32), capture=False, segment_layers=1)
+    assert rs.autograd_cut is not None
+    step()
+    n_pairs = depth - 1 + 1 + (len(model.flamingo.get_modified_layers()) - 1)
+    got = _grads(model)
+    for k in want:
+        assert _close(got[k], want[k], 2e-4), k
+    step.close()
+    assert rs.autograd_cut is None
+
+
 def test_segmented_backward_equals_one_backward_on_the_product_gradient_flow(clean_patches):
     """graphs.PiecewiseGraphedTrainStep(capture=False): the visual features and the hidden state in front of every gated layer become cut
     points, backward runs as one autograd call per segment (each with its own flush of the deferred weight gradients) - the gradients,

@@ -20,8 +20,8 @@
 namespace ff {
 
 #ifdef FF_XA_TIMELINE   // debug build: per-workgroup phase timestamps (100 MHz constant clock), read with ff_debug_xa_timeline_read
-__device__ unsigned long long g_xa_timeline[4096 * 8];
-#define FF_XTL(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_xa_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_xa_timeline[4096 * 16];
+#define FF_XTL(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_xa_timeline[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FF_XTL(i) do { } while (0)
 #endif
@@ -712,15 +712,32 @@ constexpr int kOutNS = 4;                               // ring depth of the pha
 constexpr int kOutMaxPer = 6;                           // 32-column groups per head slice: dim / heads <= 192
 constexpr int kSpinLimit = 1 << 18;
 
-// one accumulator row -> global, write-through (sc1): the line leaves this XCD's L2, every other CU's sc1 load sees it
+// one accumulator row -> global, write-through (sc1): the line leaves this XCD's L2, every other CU's sc1 load sees it.
+// 16-byte stores: lane (c, g) holds columns g*4 .. g*4+3 of every 16-column tile; the lanes g and g ^ 1 swap halves so that the even one
+// writes columns g*4 .. g*4+7 of tiles 0 / 2 and the odd one columns (g-1)*4 .. +7 of tiles 1 / 3 (8-byte sc1 stores are one fabric write
+// each and drained in 3 us where these take half of that: timeline r5s3 / r5s4)
 FF_DEV void store_acc_row_wt(bf16* row, const f32x4 (&acc)[kResDH / 16], float scale, int g) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
+    u32x2 v[kResDH / 16];
 #pragma unroll
     for (int dt = 0; dt < kResDH / 16; dt++) {
-        bf16x4 v;
+        bf16x4 q;
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = (bf16)(acc[dt][e] * scale);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), r, (unsigned)(dt * 16 + g * 4) * 2u, 0, 16);
+        for (int e = 0; e < 4; e++) q[e] = (bf16)(acc[dt][e] * scale);
+        v[dt] = __builtin_bit_cast(u32x2, q);
+    }
+    const bool odd = g & 1;
+#pragma unroll
+    for (int pr = 0; pr < kResDH / 32; pr++) {
+        const u32x2 send = odd ? v[2 * pr] : v[2 * pr + 1];              // what the partner's store is missing
+        u32x2 recv;
+        recv[0] = __shfl_xor(send[0], 16, 64);
+        recv[1] = __shfl_xor(send[1], 16, 64);
+        const u32x4 out = odd ? u32x4{recv[0], recv[1], v[2 * pr + 1][0], v[2 * pr + 1][1]} : u32x4{v[2 * pr][0], v[2 * pr][1], recv[0], recv[1]};
+        const int col = (odd ? 2 * pr + 1 : 2 * pr) * 16 + (g & ~1) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(out, r, (unsigned)col * 2u, 0, 16);
     }
 }
 // thread 0, after a workgroup barrier behind the drained payload stores: count this workgroup in; returns the count to wait for
@@ -851,6 +868,7 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
                                                                bf16* __restrict__ Qs, bf16* O, float* __restrict__ mean,
                                                                float* __restrict__ rstd, float* __restrict__ lse, const XaOutArgs o_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FF_XTL(0);
     const XaFusedArgs a = fetch_args(a_in);
     constexpr int DH = kResDH, BM = kResBM, NT = DH / 16;
     const int lin = xcd_remap(blockIdx.x, a.heads * a.batch);          // head fastest: the workgroups reading the same rows of y share an L2
@@ -899,6 +917,7 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
         wait_vmcnt<2 * (NSB - 1)>();                                   // everything but the weight tiles (issued last) has landed (nk >= NSB - 1)
     } else wait_vmcnt<0>();
     res_barrier();                                                     // (raw barrier: the weight tiles stay in flight across it)
+    FF_XTL(1);
 
     // ---- LayerNorm of the rows, from LDS and in place: 16 threads per row ----
     {
@@ -965,11 +984,13 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
         }
     }
     res_barrier();
+    FF_XTL(2);
 
     // ---- q[m][n] = sum_k LN(y)[m][k] Wq[h*DH + n][k] ----
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     res_project<NSB, 0>(sA, sB, rw, w_map, vb, nk, w, acc);
     __syncthreads();                                                   // the ring is dead: it becomes the Q tile
+    FF_XTL(3);
     if (w < 4) res_park(sQ, acc, a.scale, w, c, g);
     res_barrier();                                                     // (raw: phase 2's weight tiles, requested next, stay in flight across later barriers)
     // ---- phase 2, requests first: the activation rows are dead too - their place takes the ring of the Wo slice (rows n0 .. n0 + cs - 1) ----
@@ -1007,6 +1028,7 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
         }
         if (OUTP) wait_vmcnt<0>();                                     // this wave's share of O has left the CU
     }
+    FF_XTL(4);
     if (!OUTP) return;
 
     // ---- phase 2: attn_out = O . Wo^T for the columns [n0, n0 + cs) of the sample's rows; y1 = y + tanh(alpha) * attn_out ----
@@ -1014,29 +1036,48 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
     unsigned* cnt = oa.sync + (b % kSyncSlots);
     if (t == 0) res_await(cnt, res_arrive(cnt, (unsigned)a.heads), oa.sync + kSyncStatus);
     res_barrier();                                                     // every head's tile of this sample is out
+    FF_XTL(5);
     bf16* sA2 = sB;                                                    // [inner / 64][32][64]: the dead weight ring, Q tile and key tiles
     res_issue_rows_sc1(O + (long long)b * a.n_q * a.inner, a.inner, n_rows, sA2, w, l);
     wait_vmcnt<0>();                                                   // (also: the first three tiles of the Wo slice, requested long ago)
     res_barrier();
+    FF_XTL(6);
     float* sP = (float*)ring2;
-    FF_RES_PER(per, (res_out_phase<PER, 0>(sA2, ring2, rwo, vo, 2u, nk2, w, c, g, sP)));
-    __syncthreads();
-    {
-        const float gt = tanhf(to_f32(oa.gate[0]));
-        const int cpr = cs / 8, ld = cs + 4;
-        for (int i = t; i < n_rows * cpr; i += 512) {
-            const int r = i / cpr, c8 = i - r * cpr;
-            const float* src = sP + r * ld + c8 * 8;
-            const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
-            const long long go = ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8;
-            float yv[8], av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, ov[8];
-            Vec<bf16>::load(y + go, yv);
+    // the residual rows of the epilogue are requested now (at most two 16-byte pieces per thread: 32 rows x cs / 8 <= 768 pieces) and
+    // arrive under the product (timeline r5s3: the epilogue was 1.35 us with the loads inside it, 0.4 us in the backward kernel without any)
+    const int cpr = cs / 8, ld = cs + 4, n_items = n_rows * cpr;
+    uint4 yreg[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
 #pragma unroll
-            for (int e = 0; e < 8; e++) ov[e] = av[e] * gt + yv[e];
-            Vec<bf16>::store(oa.aux + go, av);                         // to_out(attention): an operand of d alpha_attn
-            Vec<bf16>::store(oa.out + go, ov);
+    for (int u = 0; u < 2; u++) {
+        const int i = t + u * 512;
+        if (i < n_items) {
+            const int r = i / cpr, c8 = i - r * cpr;
+            yreg[u] = *(const uint4*)(y + ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8);
         }
     }
+    FF_RES_PER(per, (res_out_phase<PER, 0>(sA2, ring2, rwo, vo, 2u, nk2, w, c, g, sP)));
+    __syncthreads();
+    FF_XTL(7);
+    {
+        const float gt = tanhf(to_f32(oa.gate[0]));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = t + u * 512;
+            if (i < n_items) {
+                const int r = i / cpr, c8 = i - r * cpr;
+                const float* src = sP + r * ld + c8 * 8;
+                const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+                const long long go = ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8;
+                float yv[8], av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, ov[8];
+                unpack16(yreg[u], yv, bf16());
+#pragma unroll
+                for (int e = 0; e < 8; e++) ov[e] = av[e] * gt + yv[e];
+                Vec<bf16>::store(oa.aux + go, av);                     // to_out(attention): an operand of d alpha_attn
+                Vec<bf16>::store(oa.out + go, ov);
+            }
+        }
+    }
+    FF_XTL(8);
 }
 
 // OUTP: phase 2 - d LN(y) = scale * dQs . Wq for this workgroup's column slice of all 32 rows (dQ is written through and read back).
@@ -1047,6 +1088,7 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
                                                                const float* __restrict__ lse, bf16* dQ, bf16* __restrict__ dK,
                                                                bf16* __restrict__ dV, float* __restrict__ Dsum, const XaOutArgs o_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FF_XTL(0);
     const XaFusedArgs a = fetch_args(a_in);
     constexpr int DH = kResDH, BM = kResBM, NT = DH / 16;
     typedef SwzLayout L;
@@ -1101,11 +1143,13 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
         wait_vmcnt<2 * (NSB - 1)>();
     } else wait_vmcnt<0>();
     res_barrier();
+    FF_XTL(1);
 
     // ---- dO[m][n] = tanh(alpha) * sum_k dy1[m][k] Wo[k][h*DH + n] ----
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     res_project<NSB, 1>(sA, sB, rw, w_map, vb, nk, w, acc);
     __syncthreads();                                                    // ring dead -> dO tile
+    FF_XTL(2);
     const float gt = tanhf(to_f32(gate[0]));
     if (w < 4) res_park(sDO, acc, gt, w, c, g);
     else {                // rows 32 .. 63 of the dO tile do not exist: zero them (they are "other" rows of the dK / dV products)
@@ -1139,6 +1183,7 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
         if (OUTP) wait_vmcnt<0>();                                      // this wave's share of dQ has left the CU
     }
     __syncthreads();                                                    // the per-query tables are complete (and, OUTP, the workgroup's tile of dQ is out)
+    FF_XTL(3);
     // ---- phase 2, first half: count this workgroup in and request the first tiles of the Wq slice (columns n0 .. n0 + cs - 1) into the dead
     //      activation rows - the other heads' workgroups arrive while this one computes dK / dV ----
     const XaOutArgs oa = OUTP ? fetch_args(o_in) : XaOutArgs{};
@@ -1171,19 +1216,23 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
             store_acc_row<bf16, DH>(dV + b * a.dv.sb + (long long)key * a.dv.sr + h * a.dv.sh, acc_v, 1.f, g);
         }
     }
+    FF_XTL(4);
     if (!OUTP) return;
 
     // ---- phase 2, second half: d LN(y)[m][n] = scale * sum_k dQs[m][k] Wq[k][n] for the columns [n0, n0 + cs) of the sample's rows ----
     res_barrier();                                                      // the tiles in LDS are dead
     if (t == 0) res_await(cnt, target, oa.sync + kSyncStatus);
     res_barrier();                                                      // every head's tile of dQ is out
+    FF_XTL(5);
     bf16* sA2 = sB;                                                     // [inner / 64][32][64] over the dead ring / dO tile
     res_issue_rows_sc1(dQ + (long long)b * a.n_q * a.inner, a.inner, n_rows, sA2, w, l);
     wait_vmcnt<0>();
     res_barrier();
+    FF_XTL(6);
     float* sP = (float*)ring2;
     FF_RES_PER(per, (res_out_phase<PER, 1>(sA2, ring2, rwq, vo, wq_step, nk2, w, c, g, sP)));
     __syncthreads();
+    FF_XTL(7);
     {
         const int cpr = cs / 8, ld = cs + 4;
         for (int i = t; i < n_rows * cpr; i += 512) {
@@ -1194,6 +1243,7 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
             Vec<bf16>::store(oa.out + ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8, ov);
         }
     }
+    FF_XTL(8);
 }
 
 // =====================================================================================================
@@ -1359,6 +1409,6 @@ int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1,
 
 #ifdef FF_XA_TIMELINE
 extern "C" int ff_debug_xa_timeline_read(unsigned long long* out, int n_blocks) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff::g_xa_timeline), sizeof(unsigned long long) * 8 * n_blocks);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff::g_xa_timeline), sizeof(unsigned long long) * 16 * n_blocks);
 }
 #endif

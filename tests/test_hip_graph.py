@@ -133,7 +133,10 @@ def test_rccl_reducer_on_one_rank_eager_and_captured(one_rank_rccl, dtype):
     r1._reduce_async = lambda flat, owners: (calls.append(flat.numel()), orig(flat, owners))[1]
     with_rccl = eager_steps(reduced, r1)
     r1.close()
-    assert len(calls) == 5 * 5          # per step: resampler, to_kv bucket, 2 blocks, the loose parameter
+    # per step: the resampler layer by layer (the reducer switches ITS model to ff_resampler_layer_*: final norm, one bucket per layer, latents +
+    # time embedding), the to_kv bucket, 2 blocks, the loose parameter
+    assert len(calls) == 5 * (reduced.resampler.depth + 2 + 4)
+    assert not reduced.resampler.layerwise                      # ... and close() has switched it back
     tol = 1e-6 if dtype == torch.float32 else 1e-2
     for a, b in zip(base, with_rccl):
         assert abs(a - b) <= tol * max(1.0, abs(a)), (base, with_rccl)
@@ -179,7 +182,8 @@ def test_sharded_adamw_on_one_rccl_rank_equals_fused_adamw(one_rank_rccl, master
         torch.cuda.synchronize()
     finally:
         opt_s.close()
-    assert len(opt_s.buckets) == 4, {k: st["sig"][0] for k, st in opt_s.buckets.items()}     # resampler, the hoisted to_kv weights, two blocks
+    # the resampler layer by layer (final norm, one bucket per layer, latents + time embedding), the hoisted to_kv weights, two blocks
+    assert len(opt_s.buckets) == sharded.resampler.depth + 2 + 3, list(opt_s.buckets)
     for (n, pa), (_, pb) in zip(plain.named_parameters(), sharded.named_parameters()):
         assert rel(pb, pa) < 1e-2, n
 

@@ -876,11 +876,12 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     const bool rows_ok = skinny_ok && M <= 32 && nz == 1 && K % 32 == 0;      // the weight-streaming kernel (tile code 3216)
     if (ft == 3216 && rows_ok) return TilePlan{3216, 1};
     if (ft == 128168) ft = 128160;      // the 8-consumer-wave launch of the same tile (run_bf16_dma looks at force_tile)
-    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok)) {
+    const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * nz;
+    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || (ft == 256128 && a_layout == 0)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
         const long long t = ft == 128 || ft == 128002 ? t128 : ft == 64 || ft == 64002 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
-                            : ft == 3264 ? (long long)cdiv(M, 32) * cdiv(N, 64) * nz : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
+                            : ft == 3264 ? (long long)cdiv(M, 32) * cdiv(N, 64) * nz : ft == 256128 ? t256 : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
         p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
         return p;
     }
@@ -905,6 +906,12 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
         p = TilePlan{3264, want_split > 0 ? want_split : sp};
         return p;
     }
+    // Round 5: products with >= 4096 rows (config E: 4 x 1024 tokens, d = 4096, 16384 hidden - 97 % of that configuration's FLOPs) get 256 x 128
+    // tiles on a 16-wave workgroup (eight MFMA waves 4 x 2, each on the same 64 x 64 slice as in the 128 x 128 kernel, + eight DMA waves), one
+    // workgroup per CU: 85 FLOP per operand byte instead of 64, at the fill rate eight DMA waves reach alone on a CU.  K-major A only (no
+    // M-major staging for a 256-wide tile: the weight gradients keep 128 x 128).
+    static const int t256_on = env_int("FF_GEMM_T256", 1);
+    if (t256_on && a_layout == 0 && M >= 4096 && N >= 1024 && K >= 1024 && t256 >= 512 && N % 8 == 0 && want_split <= 1) return TilePlan{256128, 1};
     const long long t160 = (long long)cdiv(M, 128) * cdiv(N, 160) * nz;
     int pc_split = 0;
     if (pc_on && pc_ok && N % 160 == 0 && K % 64 == 0 && t160 <= 256)
@@ -1012,6 +1019,11 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
         return pns == 4 ? launch_bf16_pc<128, 160, 0, 1, 4, 1>(P, st) : launch_bf16_pc<128, 160, 0, 1, 3, 1>(P, st);
     }
     if (P.tile == 128002) return dispatch_bf16_pc128<2>(P, st);
+    if (P.tile == 256128) {      // 3-deep ring of 48 KiB stages (the parked 256 x 128 fp32 tile needs 128 KiB of it): one workgroup per CU
+        static const int npw256 = env_int("FF_GEMM_NPW256", 8);
+        if (npw256 == 8) return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 8, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 8, 8>(P, st);
+        return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 4, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 4, 8>(P, st);
+    }
     if (P.tile == 3216) return launch_bf16_rows32(P, st);
     if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
@@ -1064,7 +1076,7 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.partial = (float*)workspace;
     }
     {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
-        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : P.tile == 3264 || P.tile == 3216 ? 32 : 64) : kFBM;
+        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 256128 ? 256 : P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : P.tile == 3264 || P.tile == 3216 ? 32 : 64) : kFBM;
         const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 3216 ? 16 : P.tile == 64 || P.tile == 64002 || P.tile == 3264 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
         const int tiles_m = cdiv(P.M, tm_edge), tiles_n = cdiv(P.N, tn_edge);
         double best = 1e300;
@@ -1198,7 +1210,7 @@ extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_
     FF_CHECK(d && bm && bn && split_k, FF_ERR_SHAPE, "ff_gemm_plan: null argument");
     if (d->dtype == FF_DTYPE_BF16) {
         const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout, d->tile);
-        *bm = p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : p.tile == 3264 || p.tile == 3216 ? 32 : 64;
+        *bm = p.tile == 256128 ? 256 : p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : p.tile == 3264 || p.tile == 3216 ? 32 : 64;
         *bn = p.tile == 3216 ? 16 : p.tile == 64 || p.tile == 64002 || p.tile == 3264 ? 64 : p.tile == 128160 ? 160 : 128;
         *split_k = p.split;
     } else {

@@ -38,11 +38,41 @@ def test_gemm_every_instantiated_tile(al, bl):
     # 128002 / 128160: the 8-wave producer / consumer kernels (128 x 128 for every layout; 128 x 160 for a K-major A operand, B K-major or -
     # staged as a 128-column and a 32-column piece - N-contiguous)
     # 128168: the 128 x 160 tile with eight MFMA waves (4 x 2) + four DMA waves (round 4)
-    for tile in (128, 6412, 64, 64002, 128002) + ((128160, 128168) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
+    # 256128: 256 x 128 tiles, eight MFMA + eight DMA waves (round 5: products with >= 4096 rows; K-major A)
+    for tile in (128, 6412, 64, 64002, 128002) + ((128160, 128168, 256128) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
         for stages in (2, 3, 4):
             for split in (1, 2):
                 C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)
                 assert rel(C, ref) < 1e-2, (tile, stages, split)
+
+
+@pytest.mark.parametrize("bl", [0, 1], ids=["B-K-major", "B-N-contiguous"])
+def test_gemm_large_row_tile_with_the_feed_forward_epilogues(bl):
+    """The 256 x 128 tile the planner picks for products with >= 4096 rows (config E: 4 x 1024 tokens), at a shape it picks it for (checked
+    through ff_gemm_plan) with the epilogues of the feed-forward launches: activation + saved pre-activation, activation gradient x saved
+    pre-activation x gate, gated residual - K-major and N-contiguous weight."""
+    import ctypes as C
+    from flamingo_mini_amd import ffi
+    dt = torch.bfloat16
+    M, N, K = 4096, 1024, 1088
+    d = ffi.GemmDesc(ffi.DTYPE_BF16, M, N, K, 0, bl, ffi.rowmap(K), ffi.rowmap(K if bl == 0 else N), ffi.rowmap(N), 1.0, ffi.ACT_NONE, ffi.ACT_NONE, 0)
+    bm, bn, sk = C.c_int(), C.c_int(), C.c_int()
+    assert ffi.lib().ff_gemm_plan(d, bm, bn, sk) == 0 and (bm.value, bn.value, sk.value) == (256, 128, 1)
+    gate = dev(np.array([0.7]), dt)
+    g = np.tanh(as64(gate)[0])
+    A = dev(rnd((M, K), 31, 0.5), dt)
+    B = dev(rnd((N, K) if bl == 0 else (K, N), 32, 0.05), dt)
+    R, H = dev(rnd((M, N), 33), dt), dev(rnd((M, N), 34), dt)
+    acc, r, h = as64(A) @ (as64(B).T if bl == 0 else as64(B)), as64(R), as64(H)
+    t = TOL[dt]["out"]
+    C_, aux = F().gemm(A, B, b_layout=bl, act="gelu", want_aux_out=True)
+    assert rel(aux, acc) < t and rel(C_, O.act_fwd(acc, "gelu")) < t
+    C_ = F().gemm(A, B, b_layout=bl, act_bwd="gelu", aux_in=H, gate=gate)
+    assert rel(C_, O.act_bwd(g * acc, h, "gelu")) < t
+    C_ = F().gemm(A, B, b_layout=bl, residual=R, gate=gate)
+    assert rel(C_, r + g * acc) < t
+    C_ = F().gemm(A[:4000], B, b_layout=bl)                     # a partial row tile
+    assert rel(C_, acc[:4000]) < t
 
 
 def test_gemm_balanced_producer_consumer_tile():

@@ -911,7 +911,10 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     // workgroup per CU: 85 FLOP per operand byte instead of 64, at the fill rate eight DMA waves reach alone on a CU.  K-major A only (no
     // M-major staging for a 256-wide tile: the weight gradients keep 128 x 128).
     static const int t256_on = env_int("FF_GEMM_T256", 1);
-    if (t256_on && a_layout == 0 && M >= 4096 && N >= 1024 && K >= 1024 && t256 >= 512 && N % 8 == 0 && want_split <= 1) return TilePlan{256128, 1};
+    // Measured (tools/gemm_graph_bench.py, cold weights, graph replay, r5s5): 4096 x 16384 x 4096 1013 -> 1090 TFLOP/s (N-contiguous weight 1016 ->
+    // 1070), 4096 x 4096 x 16384 1057 -> 1170 (1066 -> 1118), with the GELU / GELU' / gated-residual epilogues 956 -> 1007, 939 -> 988, 1033 -> 1160;
+    // 4096 x 2048 x 8192 (256 tiles: one per CU) 1057 -> 1098; four DMA waves instead of eight: the same within 1 %.
+    if (t256_on && a_layout == 0 && M >= 4096 && N >= 1024 && K >= 1024 && t256 >= 256 && N % 8 == 0 && want_split <= 1) return TilePlan{256128, 1};
     const long long t160 = (long long)cdiv(M, 128) * cdiv(N, 160) * nz;
     int pc_split = 0;
     if (pc_on && pc_ok && N % 160 == 0 && K % 64 == 0 && t160 <= 256)

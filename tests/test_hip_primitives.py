@@ -54,7 +54,7 @@ def test_gemm_large_row_tile_with_the_feed_forward_epilogues(bl):
     import ctypes as C
     from flamingo_mini_amd import ffi
     dt = torch.bfloat16
-    M, N, K = 4096, 1024, 1088
+    M, N, K = 4096, 2048, 1088
     d = ffi.GemmDesc(ffi.DTYPE_BF16, M, N, K, 0, bl, ffi.rowmap(K), ffi.rowmap(K if bl == 0 else N), ffi.rowmap(N), 1.0, ffi.ACT_NONE, ffi.ACT_NONE, 0)
     bm, bn, sk = C.c_int(), C.c_int(), C.c_int()
     assert ffi.lib().ff_gemm_plan(d, bm, bn, sk) == 0 and (bm.value, bn.value, sk.value) == (256, 128, 1)

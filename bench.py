@@ -104,9 +104,6 @@ def parse():
                     help="piecewise replay: gated layers per backward segment (= per exchange point; with --wgrad-group / --kv-group set to the same number the "
                          "launch structure follows it)")
     ap.add_argument("--wgrad-group", type=int, default=0, help="gated layers per grouped weight-gradient launch (0 = default: 12, or 4 with collectives)")
-    ap.add_argument("--wgrad-side-stream", default="auto", choices=["auto", "on", "off"],
-                    help="grouped weight-gradient launches on a second stream beside the backward pass (auto: on for single-GPU steps)")
-    ap.add_argument("--capture-priority", default="default", choices=["default", "high"], help="whole-step graph: capture on a high-priority stream (side streams rank below it)")
     ap.add_argument("--kv-group", type=int, default=-1, help="gated layers per K / V projection call (-1 = default: all, or 4 with collectives)")
     ap.add_argument("--resampler-layerwise", default="auto", choices=["auto", "on", "off"],
                     help="the resampler as one library call per layer (ff_resampler_layer_*: one gradient bucket per layer) instead of the stack-level call; "
@@ -436,9 +433,6 @@ def _dump_allocator_map(path):
         json.dump(segs, f)
 
 
-WGRAD_SIDE_STREAM_DEFAULT = False     # set from the same-box A/B (tools/sessions/r5)
-
-
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -520,8 +514,6 @@ def main():
         model.set_launch_structure(wgrad_group=args.wgrad_group)
     if args.kv_group >= 0:
         model.set_launch_structure(kv_project_group=args.kv_group)
-    side_wgrad = args.wgrad_side_stream == "on" or (args.wgrad_side_stream == "auto" and WGRAD_SIDE_STREAM_DEFAULT and (reducer is None or not reducer.active) and not sharded)
-    model.set_launch_structure(wgrad_side_stream=side_wgrad)
 
     def eager_step():
         for p in params:                 # == model.zero_grad(set_to_none=True) without walking the ~1000 frozen parameters (4 ms of host time)
@@ -586,7 +578,7 @@ def main():
             err = None
             try:
                 if mode == "full":
-                    graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer, high_priority=args.capture_priority == "high")
+                    graphed = GraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer)
                 else:
                     graphed = PiecewiseGraphedTrainStep(model, opt, batch, warmup=max(args.warmup, 1), reducer=live_reducer, pace=args.pace, segment_layers=args.segment_layers,
                                                         overlap_optimizer=overlap_opt, segment_arena=args.segment_arena == "on")
@@ -779,7 +771,7 @@ def main():
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
                        "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "rccl_channels": (args.rccl_channels or None), "segment_layers": (args.segment_layers if graph_mode == "piecewise" else None), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
-                       "hoisted_kv": bool(model.flamingo.hoist_kv), "sync_exchange": args.sync_exchange == "on", "wgrad_side_stream": bool(side_wgrad), "resampler_layerwise": bool(model.flamingo.resampler.layerwise), "stock_gemm_tuning_file": stock_tuned,
+                       "hoisted_kv": bool(model.flamingo.hoist_kv), "sync_exchange": args.sync_exchange == "on", "resampler_layerwise": bool(model.flamingo.resampler.layerwise), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,
         }

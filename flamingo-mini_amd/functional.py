@@ -30,12 +30,6 @@ def _announce(flat, params) -> None:
             cb(flat, owners)
 
 
-def _exchange_attached() -> bool:
-    """True while a gradient-ready callback that really exchanges is installed (a reducer of a 1-rank job registers one that does nothing:
-    its owner says so through `.active`)."""
-    return any(getattr(getattr(cb, "__self__", None), "active", True) for cb in _grad_ready_callbacks)
-
-
 def add_grad_ready_callback(fn: Callable[[torch.Tensor], None]) -> None:
     _grad_ready_callbacks.append(fn)
 
@@ -79,8 +73,6 @@ class _WgradQueue:
         def __init__(self):
             self.pending: list = []
             self.done: list = []
-            self.side: dict = {}             # device -> (stream the pass runs on, side stream): grouped launches that run BESIDE the pass
-            self.side_keep: list = []        # their workspaces: alive until the pass has joined the side stream
             self.deferred_ids: set = set()   # parameters with a deferred gradient in this pass
             self.summed_ids: set = set()     # ... that received a second contribution: autograd holds their SUM, nothing to repair
 
@@ -93,16 +85,6 @@ class _WgradQueue:
         # (weight-gradient launches 704 -> 830 TFLOP/s).  Data-parallel reducers set 4 ON THEIR MODEL so that gradient buckets keep becoming
         # final - and their exchange keeps starting - every four layers of backward (data_parallel._bucket_launch_structure).
         self.group = ffi.WGRAD_GROUP_MAX
-        # The grouped launches depend on nothing the data-gradient chain produces afterwards, and that chain is a string of short, latency-bound
-        # launches with the stock LM's elementwise kernels in between: with `side_stream` the grouped launches go to a second stream that forks
-        # from the pass at the flush and is joined when the pass ends (the engine's final callback), so MFMA-bound weight gradients run under
-        # work that leaves the matrix cores idle.  Everything they read or write is kept alive by the pass until the join, so no allocation is
-        # shared between the streams unordered; under stream capture the fork / join become edges of the captured graph.  Not used while
-        # gradient-ready callbacks (data-parallel reducers) or a gradient arena are installed: their collectives are ordered on the pass's stream.
-        # Like `group` it is the caller's choice, per block (xattn_block(..., wgrad=(defer, group, side_stream)); a grouped launch goes beside
-        # the pass when every block in it asked for that); `side_stream` below is the default for callers that pass none.
-        self.side_stream = False
-        self._side_streams: dict = {}        # device index -> torch.cuda.Stream
         self._passes: dict = {}              # graph-task id -> _Pass
 
     @property
@@ -123,7 +105,6 @@ class _WgradQueue:
         if hit:
             st.summed_ids.update(hit)
             self._flush_pending(st)          # the first contribution must be complete before autograd adds the second one to it
-            self._join(st)
         return bool(hit)
 
     def push(self, entry) -> None:
@@ -149,7 +130,6 @@ class _WgradQueue:
             return
         try:
             self._flush_pending(st)
-            self._join(st)           # the pass ends here: whatever consumes .grad next is ordered behind the side stream's launches
             for e in st.done:        # every AccumulateGrad of this backward pass has run by now
                 for p, (off, n) in zip(e["wparams"], e["wslices"]):
                     if p.grad is None or id(p) in st.summed_ids:
@@ -160,20 +140,6 @@ class _WgradQueue:
         finally:
             self._passes.pop(task, None)
 
-    @staticmethod
-    def _join(st) -> None:
-        for main, side in st.side.values():
-            main.wait_stream(side)
-        st.side.clear()
-        st.side_keep.clear()
-
-    def _side_stream(self, dev) -> "torch.cuda.Stream":
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
-        s = self._side_streams.get(key)
-        if s is None:
-            s = self._side_streams[key] = torch.cuda.Stream(device=dev)
-        return s
-
     def _run(self, st, group) -> None:
         lib = ffi.lib()
         ids = {id(e) for e in group}
@@ -181,18 +147,6 @@ class _WgradQueue:
         e0 = group[0]
         desc, dev = e0["desc"], e0["device"]
         ws = _empty_bytes(lib.ff_xattn_wgrad_workspace_bytes(desc), dev)
-        stream = ffi.stream_handle(dev)
-        if all(e.get("side", self.side_stream) for e in group) and not _exchange_attached() and _grad_arena is None:
-            main = torch.cuda.current_stream(dev)
-            prev = st.side.get(dev)
-            if prev is not None and prev[0] != main:       # the pass moved to another stream: finish beside the old one first
-                prev[0].wait_stream(prev[1])
-                main.wait_stream(prev[1])
-            side = self._side_stream(dev)
-            side.wait_stream(main)                          # the group's operands (d y, stash) are complete on the pass's stream
-            st.side[dev] = (main, side)
-            st.side_keep.append(ws)                         # one workspace per flush: two flushes may be in flight on the side stream
-            stream = side.cuda_stream
         params = [p for e in group for p in e["params"]]
         n = ffi.XATTN_PARAMS
         grad_ptrs = (ffi.C.c_void_p * (n * len(group)))()
@@ -201,7 +155,7 @@ class _WgradQueue:
                 grad_ptrs[i * n + j] = e["grad_ptrs"][j]
         ffi.check(lib.ff_xattn_wgrad_grouped(desc, len(group), ffi.ptr_array([e["dout"] for e in group]), ffi.ptr_array([e["saved"] for e in group]),
                                              e0["saved"].numel(), ffi.ptr_array([e["stash"] for e in group]), e0["stash"].numel(),
-                                             ffi.ptr_array(params), grad_ptrs, ws.data_ptr(), ws.numel(), stream),
+                                             ffi.ptr_array(params), grad_ptrs, ws.data_ptr(), ws.numel(), ffi.stream_handle(dev)),
                   "ff_xattn_wgrad_grouped")
         for e in group:
             _announce(e["flat"], e["own"])
@@ -650,9 +604,8 @@ class _XattnBlockKvFn(torch.autograd.Function):
                                          kv.data_ptr() + inner * kv.element_size(), out.data_ptr(), saved.data_ptr(), saved.numel(),
                                          scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_fwd(hoisted kv)")
         ctx.cfg, ctx.n_visual = cfg, n_visual
-        defer, group, *side = wgrad if wgrad is not None else (True, None)
+        defer, group = wgrad if wgrad is not None else (True, None)
         ctx.defer = bool(defer)
-        ctx.side = bool(side[0]) if side and side[0] is not None else None
         ctx.group = max(1, min(ffi.WGRAD_GROUP_MAX, int(group if group else _wgrad_queue.group)))
         ctx.save_for_backward(y, kv, tt, saved, *params)
         return out
@@ -682,7 +635,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
             offs, _ = _flat_offsets(own)
             deferred = tuple(i for i in range(len(params)) if i != _KV_PARAM)      # every gradient of the block is completed by the flush
             own_index = {i: (i if i < _KV_PARAM else i - 1) for i in deferred}
-            _wgrad_queue.push(dict(key=key, group=ctx.group, **({} if ctx.side is None else {"side": ctx.side}), desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, flat=flat, own=own,
+            _wgrad_queue.push(dict(key=key, group=ctx.group, desc=desc, device=dev, dout=dout, saved=saved, stash=stash, params=params, flat=flat, own=own,
                                    grad_ptrs=[None if g is None else g.data_ptr() for g in grads],
                                    wparams=[params[i] for i in deferred],
                                    wslices=[(offs[own_index[i]], params[i].numel()) for i in deferred]))
@@ -707,9 +660,8 @@ def xattn_block(y: torch.Tensor, visual_features: Optional[torch.Tensor], tt: to
                 n_visual: int, previous_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, output_kv: bool = False,
                 hoisted_kv: Optional[torch.Tensor] = None, wgrad: Optional[Tuple[bool, Optional[int]]] = None):
     """GatedCrossAttentionBlock forward.  cfg = (heads, dim_head, ff_mult, act); tt = text_time int32 (b, L_total).
-    hoisted_kv: this layer's output of kv_project (then visual_features is not read).  wgrad = (defer, group[, side_stream]): whether this
-    block's weight gradients are deferred into grouped launches, how many same-shaped blocks a launch batches and whether those launches run on
-    a second stream beside the backward pass (None: deferred, the queue's defaults).
+    hoisted_kv: this layer's output of kv_project (then visual_features is not read).  wgrad = (defer, group): whether this block's weight
+    gradients are deferred into grouped launches and how many same-shaped blocks a launch batches (None: deferred, the queue's default).
     Returns (y_out, (k, v) or None)."""
     ffi.require_cuda(y, tt, *params)
     _same_dtype(y, params, "GatedCrossAttentionBlock")

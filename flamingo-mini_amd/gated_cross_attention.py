@@ -50,7 +50,6 @@ class GatedCrossAttentionBlock(nn.Module):
         # neighbouring layers' (functional._WgradQueue), `wgrad_group` blocks per launch (None: the library default, 12)
         self.defer_wgrad = True
         self.wgrad_group: Optional[int] = None
-        self.wgrad_side_stream = False     # the grouped launches on a second stream beside the backward pass (joined when the pass ends)
 
     def fused_params(self):
         a = self.attn
@@ -70,7 +69,7 @@ class GatedCrossAttentionBlock(nn.Module):
         if previous_kv is None:
             assert text_time.shape == y.shape[:2]
         shape_before = y.shape
-        extra = {} if hoisted_kv is None else {"hoisted_kv": hoisted_kv, "wgrad": (self.defer_wgrad, self.wgrad_group, self.wgrad_side_stream)}
+        extra = {} if hoisted_kv is None else {"hoisted_kv": hoisted_kv, "wgrad": (self.defer_wgrad, self.wgrad_group)}
         out, kv = F.xattn_block(y, visual_features, text_time, self.fused_params(), self.cfg, self.n_visual,
                                 previous_kv=previous_kv, output_kv=bool(output_kv), **extra)
         assert out.shape == shape_before

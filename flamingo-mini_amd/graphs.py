@@ -58,16 +58,14 @@ def _refuse_live_autograd_graphs(model: torch.nn.Module) -> None:
 
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
-                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, high_priority: bool = False):
-        """high_priority: warm up and capture on a high-priority stream, so that streams forked inside the step (functional._WgradQueue's side
-        stream) rank below the step's own chain of launches wherever the runtime carries stream priorities into the captured graph."""
+                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a GPU")
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
         _refuse_live_autograd_graphs(model)
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self._loss_fn = loss_fn or (lambda out: out.loss)
-        side = torch.cuda.Stream(priority=-1) if high_priority else torch.cuda.Stream()
+        side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up off the default stream: lazy init, autotuning, allocator pools
             for _ in range(max(warmup, 1)):
@@ -81,7 +79,7 @@ class GraphedTrainStep:
         # aborts the process (seen once in ~10 runs of the 1-rank RCCL test).  "thread_local" restricts the check to this thread's own calls.
         import torch.distributed as dist
         mode = "thread_local" if reducer is not None or (dist.is_available() and dist.is_initialized()) else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=mode, **({"stream": side} if high_priority else {})):
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = self._eager().detach()
         torch.cuda.synchronize()
 

@@ -78,18 +78,15 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
         self.kv_project_group = 0
 
     def set_launch_structure(self, *, hoist_kv: Optional[bool] = None, kv_project_group: Optional[int] = None,
-                             defer_wgrad: Optional[bool] = None, wgrad_group: "Optional[int] | str" = "keep",
-                             wgrad_side_stream: Optional[bool] = None) -> Dict[str, Any]:
+                             defer_wgrad: Optional[bool] = None, wgrad_group: "Optional[int] | str" = "keep") -> Dict[str, Any]:
         """How the fusion path batches its launches (results are identical for every setting; only the launch / gradient-bucket structure
         changes).  hoist_kv / kv_project_group: see __init__.  defer_wgrad / wgrad_group: the blocks' weight gradients run as launches
         grouped over `wgrad_group` consecutive layers (None = the library default of 12; data-parallel reducers use 4 so that a gradient
-        bucket becomes final every four layers of backward).  wgrad_side_stream: those grouped launches run on a second stream beside the
-        backward pass and are joined when it ends (single-GPU steps; ignored while a data-parallel reducer is attached).  Returns the PREVIOUS settings as a dict that can be passed back
+        bucket becomes final every four layers of backward).  Returns the PREVIOUS settings as a dict that can be passed back
         (`model.set_launch_structure(**previous)`) - data_parallel.GradientAllReducer.close() does exactly that."""
         blocks = [h.xattn_block for h in self.get_modified_layers()]
         prev = dict(hoist_kv=self.hoist_kv, kv_project_group=self.kv_project_group,
-                    defer_wgrad=blocks[0].defer_wgrad if blocks else True, wgrad_group=blocks[0].wgrad_group if blocks else None,
-                    wgrad_side_stream=blocks[0].wgrad_side_stream if blocks else False)
+                    defer_wgrad=blocks[0].defer_wgrad if blocks else True, wgrad_group=blocks[0].wgrad_group if blocks else None)
         if hoist_kv is not None:
             self.hoist_kv = bool(hoist_kv)
         if kv_project_group is not None:
@@ -99,8 +96,6 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
                 b.defer_wgrad = bool(defer_wgrad)
             if wgrad_group != "keep":
                 b.wgrad_group = None if wgrad_group is None else int(wgrad_group)
-            if wgrad_side_stream is not None:
-                b.wgrad_side_stream = bool(wgrad_side_stream)
         return prev
 
     def install_autograd_cuts(self, cuts, segment_layers: int = 4) -> None:

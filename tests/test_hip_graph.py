@@ -295,45 +295,3 @@ def test_piecewise_overlapped_optimizer_without_a_reducer_equals_eager_steps(dty
         assert abs(a - b) <= tol * max(1.0, abs(a)), losses
     for k, v in finals["eager"].items():
         assert rel(finals["overlapped"][k], v) < (1e-4 if dtype == torch.float32 else 3e-2), k
-
-
-@pytest.mark.parametrize("captured", [False, True], ids=["eager", "captured"])
-def test_weight_gradients_beside_the_backward_pass_equal_inline_ones(captured):
-    """wgrad_side_stream: the grouped weight-gradient launches run on a second stream that forks from the backward pass at the flush and is
-    joined when the pass ends.  Same kernels on the same operands: losses and every parameter must be BITWISE what the in-line launches give,
-    eager and replayed from a captured graph (where fork and join are edges of the graph)."""
-    from flamingo_mini_amd import FusedAdamW, GraphedTrainStep
-    from flamingo_mini_amd import functional as F
-    dtype = torch.bfloat16
-    torch.manual_seed(0)
-    inline = _ToyHoisted().cuda().to(dtype)
-    beside = copy.deepcopy(inline)
-    for b in beside.blocks:
-        b.wgrad_side_stream = True
-        b.wgrad_group = 1 if captured else 2          # one flush per block / one flush for both
-    ml = torch.zeros(2, 16, dtype=torch.int64, device="cuda"); ml[:, 0] = 1
-    batches = [dict(x_f=dev(rnd((2, 1, 24, 64), 70 + i), dtype), y=dev(rnd((2, 16, 64), 80 + i), dtype), media_locations=ml) for i in range(5)]
-    streams_before = len(F._wgrad_queue._side_streams)
-
-    def run(model):
-        if captured:
-            opt = FusedAdamW(model.parameters(), lr=1e-2, capturable=True)
-            step = GraphedTrainStep(model, opt, batches[0], warmup=1, loss_fn=lambda out: out)
-            return [float(step(b)) for b in batches[1:]]
-        opt = FusedAdamW(model.parameters(), lr=1e-2)
-        out = []
-        for b in batches:
-            model.zero_grad(set_to_none=True)
-            loss = model(**b)
-            loss.backward()
-            opt.step()
-            out.append(float(loss))
-        return out[1:]
-
-    l_inline, l_beside = run(inline), run(beside)
-    torch.cuda.synchronize()
-    assert len(F._wgrad_queue._side_streams) >= max(streams_before, 1)            # the second stream was really used
-    assert not F._wgrad_queue._passes
-    assert l_inline == l_beside, (l_inline, l_beside)
-    for (n, a), (_, b) in zip(inline.named_parameters(), beside.named_parameters()):
-        assert torch.equal(a, b), n

@@ -449,7 +449,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_
     typedef BStage<BN, BL, NPW> BS;
     constexpr int PER_TILE = BM / (NPW * 8) + BS::PER_WAVE;   // DMA instructions per producer wave per k-step
     static_assert(WN % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
-    static_assert((AL == 0 || BM == 128 || BM == 64) && (BL == 0 || BN == 128 || BN == 64 || BN == 160), "M-major staging exists for 64 / 128 / 160-wide tiles only");
+    static_assert((AL == 0 || BM == 256 || BM == 128 || BM == 64) && (BL == 0 || BN == 128 || BN == 64 || BN == 160), "M-major staging exists for 64 / 128 / 256-wide A tiles and 64 / 128 / 160-wide B tiles only");
     static_assert(PER_TILE * (NS - 1) <= 63, "vmcnt overflow");
 
     RowMap a_map{h_ald, 0, 0}, b_map{h_bld, 0, 0};
@@ -877,7 +877,7 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     if (ft == 3216 && rows_ok) return TilePlan{3216, 1};
     if (ft == 128168) ft = 128160;      // the 8-consumer-wave launch of the same tile (run_bf16_dma looks at force_tile)
     const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * nz;
-    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || (ft == 256128 && a_layout == 0)) {
+    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || ft == 256128) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
         const long long t = ft == 128 || ft == 128002 ? t128 : ft == 64 || ft == 64002 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
@@ -908,13 +908,14 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     }
     // Round 5: products with >= 4096 rows (config E: 4 x 1024 tokens, d = 4096, 16384 hidden - 97 % of that configuration's FLOPs) get 256 x 128
     // tiles on a 16-wave workgroup (eight MFMA waves 4 x 2, each on the same 64 x 64 slice as in the 128 x 128 kernel, + eight DMA waves), one
-    // workgroup per CU: 85 FLOP per operand byte instead of 64, at the fill rate eight DMA waves reach alone on a CU.  K-major A only (no
-    // M-major staging for a 256-wide tile: the weight gradients keep 128 x 128).
+    // workgroup per CU: 85 FLOP per operand byte instead of 64, at the fill rate eight DMA waves reach alone on a CU.
     static const int t256_on = env_int("FF_GEMM_T256", 1);
     // Measured (tools/gemm_graph_bench.py, cold weights, graph replay, r5s5): 4096 x 16384 x 4096 1013 -> 1090 TFLOP/s (N-contiguous weight 1016 ->
     // 1070), 4096 x 4096 x 16384 1057 -> 1170 (1066 -> 1118), with the GELU / GELU' / gated-residual epilogues 956 -> 1007, 939 -> 988, 1033 -> 1160;
     // 4096 x 2048 x 8192 (256 tiles: one per CU) 1057 -> 1098; four DMA waves instead of eight: the same within 1 %.
-    if (t256_on && a_layout == 0 && M >= 4096 && N >= 1024 && K >= 1024 && t256 >= 256 && N % 8 == 0 && want_split <= 1) return TilePlan{256128, 1};
+    // M-major A (weight gradients; mswz<256>, two 512-byte k-rows per DMA instruction): from K = 4096 contraction rows up (config E's 4 x 1024 tokens)
+    static const int t256_a1_k = env_int("FF_GEMM_T256_A1_K", 4096);
+    if (t256_on && (a_layout == 0 || K >= t256_a1_k) && M >= 4096 && N >= 1024 && K >= 1024 && t256 >= 256 && N % 8 == 0 && want_split <= 1) return TilePlan{256128, 1};
     const long long t160 = (long long)cdiv(M, 128) * cdiv(N, 160) * nz;
     int pc_split = 0;
     if (pc_on && pc_ok && N % 160 == 0 && K % 64 == 0 && t160 <= 256)
@@ -1024,6 +1025,9 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
     if (P.tile == 128002) return dispatch_bf16_pc128<2>(P, st);
     if (P.tile == 256128) {      // 3-deep ring of 48 KiB stages (the parked 256 x 128 fp32 tile needs 128 KiB of it): one workgroup per CU
         static const int npw256 = env_int("FF_GEMM_NPW256", 8);
+        if (P.a_layout == 1)     // M-major A (the weight gradients d Y^T . X): 512-byte k-rows, two per wave-level DMA instruction, ds_read_b64_tr_b16 fragments;
+                                 // four DMA waves (12-wave workgroup, 168 registers per lane): with eight the transposing reads' addressing spills at the 128-register cap
+            return P.b_layout == 0 ? launch_bf16_pc<256, 128, 1, 0, 3, 1, 4, 8>(P, st) : launch_bf16_pc<256, 128, 1, 1, 3, 1, 4, 8>(P, st);
         if (npw256 == 8) return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 8, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 8, 8>(P, st);
         return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 4, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 4, 8>(P, st);
     }

@@ -30,7 +30,7 @@ constexpr int kBK = 64;    // bf16 K tile
 constexpr unsigned kOobOffset = 0x80000000u;   // >= num_records of every descriptor we build
 
 template <int BR> FF_DEV int mswz(int k) {      // chunk XOR of k-row `k` in an M-major tile
-    if (BR == 128) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);
+    if (BR == 128 || BR == 256) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);      // k-rows of 256 / 512 bytes: whole bank rows, the XOR stays inside the low 16 chunks
     if (BR == 32) return ((k >> 3) & 1) << 1;       // 64-byte k-rows (4 chunks): the two 16-lane groups of a half-wave (k, k + 8) land on disjoint banks
     return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);
 }

@@ -38,12 +38,31 @@ def test_gemm_every_instantiated_tile(al, bl):
     # 128002 / 128160: the 8-wave producer / consumer kernels (128 x 128 for every layout; 128 x 160 for a K-major A operand, B K-major or -
     # staged as a 128-column and a 32-column piece - N-contiguous)
     # 128168: the 128 x 160 tile with eight MFMA waves (4 x 2) + four DMA waves (round 4)
-    # 256128: 256 x 128 tiles, eight MFMA + eight DMA waves (round 5: products with >= 4096 rows; K-major A)
-    for tile in (128, 6412, 64, 64002, 128002) + ((128160, 128168, 256128) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
+    # 256128: 256 x 128 tiles, eight MFMA + eight DMA waves (round 5: products with >= 4096 rows); with an M-major A operand (the weight
+    #         gradients' d Y^T: 512-byte k-rows staged two per DMA instruction, transposing fragment reads) eight MFMA + four DMA waves
+    for tile in (128, 6412, 64, 64002, 128002, 256128) + ((128160, 128168) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
         for stages in (2, 3, 4):
             for split in (1, 2):
                 C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)
                 assert rel(C, ref) < 1e-2, (tile, stages, split)
+
+
+@pytest.mark.parametrize("bl", [0, 1], ids=["B-K-major", "B-N-contiguous"])
+def test_gemm_large_row_tile_weight_gradient_layouts(bl):
+    """The 256 x 128 tile with an M-major A operand at a shape the planner picks it for (a weight gradient with >= 4096 output rows and
+    >= 4096 contraction rows: config E), ragged N and a K tail."""
+    import ctypes as C
+    from flamingo_mini_amd import ffi
+    dt = torch.bfloat16
+    M, N, K = 4096, 2056, 4096 + 40
+    d = ffi.GemmDesc(ffi.DTYPE_BF16, M, N, K, 1, bl, ffi.rowmap(M), ffi.rowmap(K if bl == 0 else N), ffi.rowmap(N), 1.0, ffi.ACT_NONE, ffi.ACT_NONE, 0)
+    bm, bn, sk = C.c_int(), C.c_int(), C.c_int()
+    assert ffi.lib().ff_gemm_plan(d, bm, bn, sk) == 0 and (bm.value, bn.value, sk.value) == (256, 128, 1)
+    A = dev(rnd((K, M), 41, 0.5), dt)
+    B = dev(rnd((N, K) if bl == 0 else (K, N), 42, 0.05), dt)
+    ref = as64(A).T @ (as64(B).T if bl == 0 else as64(B))
+    out = F().gemm(A, B, a_layout=1, b_layout=bl)
+    assert rel(out, ref) < TOL[dt]["out"]
 
 
 @pytest.mark.parametrize("bl", [0, 1], ids=["B-K-major", "B-N-contiguous"])

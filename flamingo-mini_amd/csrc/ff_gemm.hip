@@ -913,9 +913,11 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     // Measured (tools/gemm_graph_bench.py, cold weights, graph replay, r5s5): 4096 x 16384 x 4096 1013 -> 1090 TFLOP/s (N-contiguous weight 1016 ->
     // 1070), 4096 x 4096 x 16384 1057 -> 1170 (1066 -> 1118), with the GELU / GELU' / gated-residual epilogues 956 -> 1007, 939 -> 988, 1033 -> 1160;
     // 4096 x 2048 x 8192 (256 tiles: one per CU) 1057 -> 1098; four DMA waves instead of eight: the same within 1 %.
-    // M-major A (weight gradients; mswz<256>, two 512-byte k-rows per DMA instruction): from K = 4096 contraction rows up (config E's 4 x 1024 tokens)
-    static const int t256_a1_k = env_int("FF_GEMM_T256_A1_K", 4096);
-    if (t256_on && (a_layout == 0 || K >= t256_a1_k) && M >= 4096 && N >= 1024 && K >= 1024 && t256 >= 256 && N % 8 == 0 && want_split <= 1) return TilePlan{256128, 1};
+    // With an M-major A operand (the weight gradients; mswz<256>, two 512-byte k-rows per DMA instruction, eight MFMA + four DMA waves) the tile
+    // is selectable (ff_gemm_desc.tile = 256128) but not planned: r5s7, same method - 4096 x 16384 x 4096 994 -> 980 TFLOP/s, 16384 x 4096 x 4096
+    // 1038 -> 1054, M-major A with a K-major B 1001 -> 1042; below 4096 contraction rows it loses (4096 x 1024 x 2048: 669 -> 543; 1280 x 5120 x 1024:
+    // 591 -> 578).  Both operands are read with the half-width transposing fragment reads, so the tile's extra FLOP per DMA byte buy nothing.
+    if (t256_on && a_layout == 0 && M >= 4096 && N >= 1024 && K >= 1024 && t256 >= 256 && N % 8 == 0 && want_split <= 1) return TilePlan{256128, 1};
     const long long t160 = (long long)cdiv(M, 128) * cdiv(N, 160) * nz;
     int pc_split = 0;
     if (pc_on && pc_ok && N % 160 == 0 && K % 64 == 0 && t160 <= 256)

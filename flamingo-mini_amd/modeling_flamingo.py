@@ -315,6 +315,7 @@ class _DecodeSession:
         self._model_ref = weakref.ref(model)
         self.b, self.max_length, self.eos, self.graph_wanted = b, max_length, eos, graph
         self.fill = pad if pad is not None else 0
+        self.lm_family = "gpt2" if isinstance(model.flamingo, FlamingoGPT2) else "opt"
         self.cache = StaticCache(config=model.flamingo.lm.config, max_cache_len=max_length)
         self.ids_buf = torch.empty((b, max_length), dtype=ids_dtype, device=device)
         self.am_buf = torch.empty((b, max_length), dtype=am_dtype, device=device)
@@ -353,10 +354,21 @@ class _DecodeSession:
         self.ids_buf.index_copy_(1, self.pos, self.tok)
         self.n_new.add_(alive.to(self.n_new.dtype))
 
+    def _positions(self, L0=None):
+        """How the LM family learns where a step's tokens sit without reading anything back to the host.  GPT-2 takes absolute cache
+        positions.  OPT numbers the ATTENDED tokens (cumsum of the attention mask, padding skipped - modeling_opt's own rule), and derives
+        that by slicing with the cache's length, which for a StaticCache is a device scalar (a host synchronisation: not capturable): the
+        decode step hands it `position_ids` instead - the token at `pos` is the (number of ones in the mask so far)-th attended one."""
+        if self.lm_family == "gpt2":
+            return {"cache_position": self.pos if L0 is None else torch.arange(L0, device=self.pos.device)}
+        if L0 is None:
+            return {"position_ids": self.am_buf.sum(1, keepdim=True).long() - 1}
+        return {}                       # the prompt step: an empty cache, OPT's own cumsum applies
+
     def _step(self):
         self.am_buf.index_fill_(1, self.pos, 1)
         o = self.model.flamingo(input_ids=self.tok, attention_mask=self.am_buf, use_cache=True, past_key_values=(self.xattn_past, self.cache),
-                                cache_position=self.pos, text_time=self.tt_step)
+                                text_time=self.tt_step, **self._positions())
         self.pos.add_(1)
         self._append(o.logits[:, -1])
 
@@ -366,7 +378,7 @@ class _DecodeSession:
         dev = ids.device
         self.cache.reset()
         out = self.model.flamingo(input_ids=ids, attention_mask=am, media_locations=ml, use_cache=True, past_key_values=(None, self.cache),
-                                  pixel_values=pixel_values, visual_features=visual_features, cache_position=torch.arange(L0, device=dev))
+                                  pixel_values=pixel_values, visual_features=visual_features, **self._positions(L0))
         fresh = out.past_key_values[0]
         if self.xattn_past is None:
             self.xattn_past = tuple((torch.empty_like(k, memory_format=torch.contiguous_format), torch.empty_like(v, memory_format=torch.contiguous_format))
@@ -412,7 +424,7 @@ class FlamingoModel(PreTrainedModel):
 
     config_class = FlamingoConfig
     _LANGUAGE_MODEL_VERSIONS = {"gpt2": FlamingoGPT2, "facebook/opt": FlamingoOPT}
-    # greedy decoding of a GPT-2-backed model on the GPU: fixed-shape decode steps (static_decode), replayed from a HIP graph (decode_graph);
+    # greedy decoding on the GPU (GPT-2- and, since round 5, OPT-backed models): fixed-shape decode steps (static_decode), replayed from a HIP graph (decode_graph);
     # plain attributes, settable per model - no environment variable
     static_decode = True
     decode_graph = True
@@ -552,9 +564,9 @@ class FlamingoModel(PreTrainedModel):
             if do_sample:
                 raise ValueError("beam search with sampling is not implemented")
             return self._beam_search(ids, ml, am, pixel_values, visual_features, max_length, num_beams, eos_token_id, pad, early_stopping, length_penalty)
-        if static_decode is None:       # greedy decoding of a GPT-2-backed model on the GPU: fixed-shape decode steps, replayed from a HIP graph
+        if static_decode is None:       # greedy decoding on the GPU (GPT-2- and OPT-backed models): fixed-shape decode steps, replayed from a HIP graph
             static_decode = ids.is_cuda and self.static_decode
-        if static_decode and not do_sample and isinstance(self.flamingo, FlamingoGPT2) and ids.shape[1] + 1 < max_length:
+        if static_decode and not do_sample and isinstance(self.flamingo, (FlamingoGPT2, FlamingoOPT)) and ids.shape[1] + 1 < max_length:
             return self._static_greedy(ids, ml, am, pixel_values, visual_features, max_length, eos_token_id, pad)
         finished = torch.zeros(ids.shape[0], dtype=torch.bool, device=ids.device)
         past, step_ids = None, ids

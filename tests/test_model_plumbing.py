@@ -172,10 +172,12 @@ def test_greedy_generate_cached_equals_uncached(family):
     px = torch.from_numpy(z["px"]).float().cuda()
     ids, ml = torch.from_numpy(z["ids"]).cuda()[:, :4], torch.from_numpy(z["ml"]).cuda()[:, :4]
     am = torch.ones_like(ids)
-    gen = model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9)      # gpt2: fixed-shape steps replayed from a HIP graph
-    if family == "gpt2":
-        assert torch.equal(model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9), gen)      # the session (and its graph) reused
-        assert torch.equal(model.generate(ids, media_locations=ml, attention_mask=am, pixel_values=px, max_length=9, static_decode=False), gen)
+    gen = model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9)      # fixed-shape steps replayed from a HIP graph (both LM families)
+    sess = next(iter(model._decode_sessions.values()))
+    assert sess.replay is not None and not sess.capture_failed                    # the decode step really was captured
+    assert torch.equal(model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9), gen)      # the session (and its graph) reused
+    assert len(model._decode_sessions) == 1
+    assert torch.equal(model.generate(ids, media_locations=ml, attention_mask=am, pixel_values=px, max_length=9, static_decode=False), gen)
     cur, cml, cam = ids, ml, am
     for _ in range(5):     # uncached reference loop
         with torch.no_grad():
@@ -202,8 +204,11 @@ def test_generation_strategies_cpu_with_oracle_checker(family):
         greedy = model.generate(ids, **kw)
         assert greedy.shape == (2, 9) and torch.equal(greedy, model.greedy_generate(ids, ml, am, pixel_values=px, max_length=9))
         assert torch.equal(model.generate(ids, do_sample=True, top_k=1, **kw), greedy)          # top-1 sampling is greedy
-        if family == "gpt2":        # the fixed-shape decode path (StaticCache, device-side positions; HIP-graph replay on the GPU) gives the same tokens
+        if True:                    # the fixed-shape decode path (StaticCache, device-side positions; HIP-graph replay on the GPU) gives the same tokens, for both LM families
             assert torch.equal(model.generate(ids, static_decode=True, **kw), greedy)
+            amp = am.clone(); amp[1, 0] = 0                                   # a left-padded prompt: OPT numbers attended tokens, GPT-2 cache slots
+            kwp = dict(kw, attention_mask=amp)
+            assert torch.equal(model.generate(ids, static_decode=True, **kwp), model.generate(ids, static_decode=False, **kwp))
             ids2 = (ids + 7) % 90                                             # another prompt through the SAME session: everything is reset
             assert len(model._decode_sessions) == 1
             assert torch.equal(model.generate(ids2, static_decode=True, **kw), model.generate(ids2, static_decode=False, **kw))

@@ -562,6 +562,142 @@ __global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x 256 tiles on ONE 16-wave workgroup per CU (round 5): the tile for products big enough to give every CU several of them.
+// Operand tiles enter a CU at ~21 B/clk whatever the kernel does (section 5 of DESIGN.md: the fill microbenchmark, this family's k-step
+// anatomy, and hipBLASLt's MT256x160 kernel all sit at that rate), so a launch's ceiling is its tile's FLOP per operand byte: 64 for 128 x 128
+// (~940 TFLOP/s), 85 for 256 x 128, 128 for 256 x 256.  A 256 x 256 fp32 accumulator is 64 registers per lane only when sixteen waves share it
+// (4 x 4, each on a 64 x 64 slice like every other kernel of the family), and sixteen waves are a whole workgroup: there is no room for
+// separate DMA waves, so every wave issues its four 1-KiB pieces of the next k-step (two of A, two of B) right after the barrier and then runs
+// its 32 MFMAs - four waves per SIMD cover each other's DMA-issue stalls, which is what the producer / consumer split buys the smaller tiles.
+// Two 64-KiB stages (all of the LDS a second stage leaves); the fp32 tile leaves through the dead ring in two 128-row halves.
+// Every operand layout: K-major tiles as [256][64] (row & 7 swizzle), M-major ones as [64][256] (mswz<256>, transposing fragment reads).
+// ------------------------------------------------------------------------------------------------
+template <int AL, int BL>
+__global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
+                                                                int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* smem = (bf16*)smem_raw;
+    constexpr int BM = 256, BN = 256, NW = 16, NS = 2;
+    constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int WM = 64, WN = 64, MT = WM / 16, NT = WN / 16;
+    constexpr int PA = BM / (NW * 8), PB = BN / (NW * 8);       // DMA instructions per wave and k-step: 2 + 2
+
+    RowMap a_map{h_ald, 0, 0}, b_map{h_bld, 0, 0};
+    if (h_seg) { a_map = P.a_map; b_map = P.b_map; }
+    const void* opA = hA;
+    const void* opB = hB;
+    const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
+    const TileCoord tc = tile_coord(h_nz, h_split, h_xcd & 255, h_xcd >> 8, tiles_m, tiles_n);
+    if (tc.z > 0) { opA = P.p[tc.z].A; opB = P.p[tc.z].B; }
+    const int m_base = tc.tm * BM, n_base = tc.tn * BN;
+    const int k_begin = tc.split * h_kps;
+    const int k_end = min(hK, k_begin + h_kps);
+    const int t = threadIdx.x, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)opB, 0, 0x7fffffff, 0x00020000);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (k_end - k_begin + kBK - 1) / kBK;
+    unsigned va[PA], vb[PB];
+    dma_prepare<BM, AL, NW>(a_map, m_base, hM, w, l, va);
+    dma_prepare<BN, BL, NW>(b_map, n_base, hN, w, l, vb);
+    const bool a_plain = AL == 0 || a_map.rows_per_seg <= 0, b_plain = BL == 0 || b_map.rows_per_seg <= 0;
+    const unsigned a_step = AL == 0 ? 2u : (unsigned)a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)b_map.ld * 2u;   // bytes per unit of k
+    auto issue = [&](int tile) {
+        bf16* st = smem + (tile % NS) * STAGE;
+        const int k0 = k_begin + tile * kBK;
+        const bool full = k0 + kBK <= k_end;       // wave-uniform
+        if (full && a_plain) dma_tile_fast<BM, AL, NW>(ra, st, va, (unsigned)k0 * a_step, w);
+        else dma_tile<BM, AL, NW>(ra, st, a_map, m_base, hM, k0, k_end, w, l);
+        if (full && b_plain) dma_tile_fast<BN, BL, NW>(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, w);
+        else dma_tile<BN, BL, NW>(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, w, l);
+    };
+    if (nk > 0) issue(0);
+    FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tile
+    if (tc.z > 0) pr = P.p[tc.z];
+
+    for (int kt = 0; kt < nk; kt++) {
+        wait_vmcnt<0>();                                    // this wave's pieces of tile kt (nothing younger is in flight with two stages)
+        __builtin_amdgcn_s_barrier();                       // everyone's pieces are in LDS, and everyone has left stage (kt + 1) % 2
+        if (kt + 1 < nk) issue(kt + 1);                     // lands while this k-step's products run
+        const bf16* sA = smem + (kt % NS) * STAGE;
+        const bf16* sB = sA + A_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < kBK / 32; ks++) {
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
+#pragma unroll
+            for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, BL>(sB, wn * WN + j * 16, ks);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
+        }
+    }
+
+    const int c = l & 15, g = l >> 4;
+    if (Q.split_k > 1) {   // fp32 partial slab; gemm_splitk_epilogue_kernel reduces the slabs and applies the epilogue
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const int m = m_base + wm * WM + i * 16 + c;
+            if (m >= Q.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int n = n_base + wn * WN + j * 16 + g * 4;
+                if (n >= Q.N) continue;
+                *(f32x4*)(Q.partial + ((long long)(tc.z * Q.split_k + tc.split) * Q.M + m) * Q.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    // the fp32 tile is 256 KiB, the dead ring 128: rows 0..127 (wave rows 0, 1) go through it first, then rows 128..255
+    static_assert((BM / 2) * BN * 4 <= NS * STAGE * 2, "half of the fp32 tile must fit the operand ring");
+    float* ct = (float*)smem_raw;
+    __syncthreads();                                        // the last fragment reads of the ring are done
+#pragma unroll                                              // (two copies of the epilogue's rolled row loops: kept in a rolled loop the accumulators spill)
+    for (int half = 0; half < 2; half++) {
+        if ((wm >> 1) == half) {
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+                const int ml = (wm & 1) * WM + i * 16 + c;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const int ch = ((wn * WN + j * 16) >> 2) + g;
+                    *(f32x4*)(ct + ml * BN + ((ch ^ (c & CtSwz<BN>::kMask)) << 2)) = acc[i][j];
+                }
+            }
+        }
+        __syncthreads();
+        tile_epilogue_bf16<BM / 2, BN, NW * 64>(Q, pr, ct, m_base + half * (BM / 2), n_base);      // (no rows left: the loop bound is <= 0)
+        if (half == 0) __syncthreads();
+    }
+}
+template <int AL, int BL> static int launch_bf16_u16(const GemmParams& P, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_u16_kernel<AL, BL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm u16 lds=%zu): %s", lds, hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int grid = cdiv(P.M, 256) * cdiv(P.N, 256) * P.split_k * P.nz;
+    const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
+    gemm_bf16_u16_kernel<AL, BL><<<dim3(grid), dim3(1024), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split, P.nz,
+                                                                      P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld, (int)P.b_map.ld, seg, P);
+    return check_launch("gemm_bf16_u16");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight-streaming kernel for decode-shaped products: M <= 32 activation rows (one token per sequence), both operands K-major.
 // Nothing is staged in LDS: a workgroup owns 16 output columns, its NW waves split K between them, every lane loads the 16 bytes of weight
 // row (n0 + c), k-chunk g that ARE its B fragment of v_mfma_f32_16x16x32_bf16, plus the two matching A fragments of the 32 activation rows,
@@ -877,11 +1013,12 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     if (ft == 3216 && rows_ok) return TilePlan{3216, 1};
     if (ft == 128168) ft = 128160;      // the 8-consumer-wave launch of the same tile (run_bf16_dma looks at force_tile)
     const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * nz;
-    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || ft == 256128) {
+    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || ft == 256128 || ft == 256256) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
         const long long t = ft == 128 || ft == 128002 ? t128 : ft == 64 || ft == 64002 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
-                            : ft == 3264 ? (long long)cdiv(M, 32) * cdiv(N, 64) * nz : ft == 256128 ? t256 : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
+                            : ft == 3264 ? (long long)cdiv(M, 32) * cdiv(N, 64) * nz : ft == 256128 ? t256 : ft == 256256 ? (long long)cdiv(M, 256) * cdiv(N, 256) * nz
+                            : (long long)cdiv(M, 64) * cdiv(N, 128) * nz;
         p.split = (t >= 128 || K < 1024) ? 1 : std::max(1, std::min(std::min((int)(256 / t), K / 512), 16));
         return p;
     }
@@ -906,6 +1043,10 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
         p = TilePlan{3264, want_split > 0 ? want_split : sp};
         return p;
     }
+    // 256 x 256 tiles on 16-wave workgroups (gemm_bf16_u16_kernel, every layout) for launches that hand every CU at least two of them
+    static const int u16_on = env_int("FF_GEMM_U16", 0), u16_min = env_int("FF_GEMM_U16_MIN_TILES", 512);
+    const long long t256sq = (long long)cdiv(M, 256) * cdiv(N, 256) * nz;
+    if (u16_on && t256sq >= u16_min && K >= 512 && M % 8 == 0 && N % 8 == 0 && want_split <= 1) return TilePlan{256256, 1};
     // Round 5: products with >= 4096 rows (config E: 4 x 1024 tokens, d = 4096, 16384 hidden - 97 % of that configuration's FLOPs) get 256 x 128
     // tiles on a 16-wave workgroup (eight MFMA waves 4 x 2, each on the same 64 x 64 slice as in the 128 x 128 kernel, + eight DMA waves), one
     // workgroup per CU: 85 FLOP per operand byte instead of 64, at the fill rate eight DMA waves reach alone on a CU.
@@ -1033,6 +1174,10 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
         if (npw256 == 8) return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 8, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 8, 8>(P, st);
         return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 4, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 4, 8>(P, st);
     }
+    if (P.tile == 256256) {
+        if (P.a_layout == 0) return P.b_layout == 0 ? launch_bf16_u16<0, 0>(P, st) : launch_bf16_u16<0, 1>(P, st);
+        return P.b_layout == 0 ? launch_bf16_u16<1, 0>(P, st) : launch_bf16_u16<1, 1>(P, st);
+    }
     if (P.tile == 3216) return launch_bf16_rows32(P, st);
     if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);
@@ -1085,8 +1230,8 @@ int gemm_launch(GemmParams P, int dtype, void* workspace, size_t ws_bytes, hipSt
         P.partial = (float*)workspace;
     }
     {   // XCD partition of the tile grid: minimise (A bytes)/ms + (B bytes)/ns over ms * ns = 8
-        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 256128 ? 256 : P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : P.tile == 3264 || P.tile == 3216 ? 32 : 64) : kFBM;
-        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 3216 ? 16 : P.tile == 64 || P.tile == 64002 || P.tile == 3264 ? 64 : P.tile == 128160 ? 160 : 128) : kFBM;
+        const int tm_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 256128 || P.tile == 256256 ? 256 : P.tile == 128 || P.tile == 128160 || P.tile == 128002 ? 128 : P.tile == 3264 || P.tile == 3216 ? 32 : 64) : kFBM;
+        const int tn_edge = dtype == FF_DTYPE_BF16 ? (P.tile == 3216 ? 16 : P.tile == 64 || P.tile == 64002 || P.tile == 3264 ? 64 : P.tile == 128160 ? 160 : P.tile == 256256 ? 256 : 128) : kFBM;
         const int tiles_m = cdiv(P.M, tm_edge), tiles_n = cdiv(P.N, tn_edge);
         double best = 1e300;
         P.xcd_ms = 1; P.xcd_ns = 1;
@@ -1219,8 +1364,8 @@ extern "C" int ff_gemm_plan(const ff_gemm_desc* d, int* bm, int* bn, int* split_
     FF_CHECK(d && bm && bn && split_k, FF_ERR_SHAPE, "ff_gemm_plan: null argument");
     if (d->dtype == FF_DTYPE_BF16) {
         const TilePlan p = plan_bf16(d->M, d->N, d->K, 1, d->split_k, d->a_layout, d->b_layout, d->tile);
-        *bm = p.tile == 256128 ? 256 : p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : p.tile == 3264 || p.tile == 3216 ? 32 : 64;
-        *bn = p.tile == 3216 ? 16 : p.tile == 64 || p.tile == 64002 || p.tile == 3264 ? 64 : p.tile == 128160 ? 160 : 128;
+        *bm = p.tile == 256128 || p.tile == 256256 ? 256 : p.tile == 128 || p.tile == 128160 || p.tile == 128002 ? 128 : p.tile == 3264 || p.tile == 3216 ? 32 : 64;
+        *bn = p.tile == 3216 ? 16 : p.tile == 64 || p.tile == 64002 || p.tile == 3264 ? 64 : p.tile == 128160 ? 160 : p.tile == 256256 ? 256 : 128;
         *split_k = p.split;
     } else {
         *bm = *bn = kFBM;

@@ -83,7 +83,9 @@ typedef struct ff_gemm_desc {
     int tile;     /* bf16 block tile: 0 = choose automatically; 128 = 128x128 (4 waves), 6412 = 64x128, 64 = 64x64,
                    * 64002 / 128002 = 64x64 / 128x128 producer/consumer (8 waves), 128160 = 128x160 producer/consumer (A K-major only),
                    * 128168 = the same 128x160 tile with eight MFMA waves (4 x 2) + four DMA waves,
-                   * 256128 = 256x128 producer/consumer, eight MFMA + eight DMA waves (A K-major only; chosen automatically for products with >= 4096 rows),
+                   * 256128 = 256x128 producer/consumer, eight MFMA + eight DMA waves (chosen automatically for products with >= 4096 rows and a K-major A; with an
+                   *          M-major A - weight gradients - eight MFMA + four DMA waves, selectable only),
+                   * 256256 = 256x256 on sixteen waves that both issue the DMA and run the MFMAs (every layout; two stages, `stages` ignored),
                    * 3264 = 32x64 producer/consumer (decode: M <= 32 rows; both operands K-major),
                    * 3216 = weight-streaming kernel for M <= 32 rows (16 output columns per workgroup, no LDS staging; K-major operands, K % 32 == 0) */
     int stages;   /* depth of the LDS operand ring: 0 = default, 2..4 */

@@ -569,7 +569,8 @@ __global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_
 // (4 x 4, each on a 64 x 64 slice like every other kernel of the family), and sixteen waves are a whole workgroup: there is no room for
 // separate DMA waves, so every wave issues its four 1-KiB pieces of the next k-step (two of A, two of B) right after the barrier and then runs
 // its 32 MFMAs - four waves per SIMD cover each other's DMA-issue stalls, which is what the producer / consumer split buys the smaller tiles.
-// Two 64-KiB stages (all of the LDS a second stage leaves); the fp32 tile leaves through the dead ring in two 128-row halves.
+// The LDS holds two and a half k-steps: five 32-KiB units, each one operand's tile of a k-step (see the ring in the kernel); the fp32 tile
+// leaves through the dead ring in two 128-row halves.
 // Every operand layout: K-major tiles as [256][64] (row & 7 swizzle), M-major ones as [64][256] (mswz<256>, transposing fragment reads).
 // ------------------------------------------------------------------------------------------------
 template <int AL, int BL>
@@ -577,8 +578,9 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
                                                                 int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* smem = (bf16*)smem_raw;
-    constexpr int BM = 256, BN = 256, NW = 16, NS = 2;
-    constexpr int A_ELEMS = BM * kBK, B_ELEMS = BN * kBK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int BM = 256, BN = 256, NW = 16;
+    constexpr int UNIT = BM * kBK, NU = 5;                      // one operand's k-step tile: 32 KiB; five of them are all of the LDS
+    static_assert(BM == BN, "the ring's units hold either operand");
     constexpr int WM = 64, WN = 64, MT = WM / 16, NT = WN / 16;
     constexpr int PA = BM / (NW * 8), PB = BN / (NW * 8);       // DMA instructions per wave and k-step: 2 + 2
 
@@ -610,25 +612,35 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
     dma_prepare<BN, BL, NW>(b_map, n_base, hN, w, l, vb);
     const bool a_plain = AL == 0 || a_map.rows_per_seg <= 0, b_plain = BL == 0 || b_map.rows_per_seg <= 0;
     const unsigned a_step = AL == 0 ? 2u : (unsigned)a_map.ld * 2u, b_step = BL == 0 ? 2u : (unsigned)b_map.ld * 2u;   // bytes per unit of k
-    auto issue = [&](int tile) {
-        bf16* st = smem + (tile % NS) * STAGE;
+    // The ring: unit (2 kt + op) % 5 holds operand op (0 = A, 1 = B) of k-step kt.  Issue order A0 B0 A1 | B1 A2 | B2 A3 | ...: after the barrier
+    // of k-step kt the two units of k-step kt - 1 are free and take B(kt + 1) and A(kt + 2), while A(kt + 1) - requested a k-step earlier - is
+    // still streaming in: one and a half k-steps are always in flight, so the CU's load path never waits for a request to be issued (with two
+    // whole stages - the first version - a k-step cost the latency of its tile PLUS its transfer: 4600 clocks instead of ~3100).
+    auto unit = [&](int kt, int op) { return smem + ((2 * kt + op) % NU) * UNIT; };
+    auto issue_a = [&](int tile) {
         const int k0 = k_begin + tile * kBK;
-        const bool full = k0 + kBK <= k_end;       // wave-uniform
-        if (full && a_plain) dma_tile_fast<BM, AL, NW>(ra, st, va, (unsigned)k0 * a_step, w);
-        else dma_tile<BM, AL, NW>(ra, st, a_map, m_base, hM, k0, k_end, w, l);
-        if (full && b_plain) dma_tile_fast<BN, BL, NW>(rb, st + A_ELEMS, vb, (unsigned)k0 * b_step, w);
-        else dma_tile<BN, BL, NW>(rb, st + A_ELEMS, b_map, n_base, hN, k0, k_end, w, l);
+        if (k0 + kBK <= k_end && a_plain) dma_tile_fast<BM, AL, NW>(ra, unit(tile, 0), va, (unsigned)k0 * a_step, w);
+        else dma_tile<BM, AL, NW>(ra, unit(tile, 0), a_map, m_base, hM, k0, k_end, w, l);
     };
-    if (nk > 0) issue(0);
-    FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tile
+    auto issue_b = [&](int tile) {
+        const int k0 = k_begin + tile * kBK;
+        if (k0 + kBK <= k_end && b_plain) dma_tile_fast<BN, BL, NW>(rb, unit(tile, 1), vb, (unsigned)k0 * b_step, w);
+        else dma_tile<BN, BL, NW>(rb, unit(tile, 1), b_map, n_base, hN, k0, k_end, w, l);
+    };
+    if (nk > 0) { issue_a(0); issue_b(0); }
+    if (nk > 1) issue_a(1);
+    FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
     if (tc.z > 0) pr = P.p[tc.z];
 
     for (int kt = 0; kt < nk; kt++) {
-        wait_vmcnt<0>();                                    // this wave's pieces of tile kt (nothing younger is in flight with two stages)
-        __builtin_amdgcn_s_barrier();                       // everyone's pieces are in LDS, and everyone has left stage (kt + 1) % 2
-        if (kt + 1 < nk) issue(kt + 1);                     // lands while this k-step's products run
-        const bf16* sA = smem + (kt % NS) * STAGE;
-        const bf16* sB = sA + A_ELEMS;
+        // this wave's pieces of A(kt) and B(kt) have landed; the PA youngest ones - A(kt + 1) - may stay in flight across the barrier
+        if (kt + 1 < nk) wait_vmcnt<PA>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                       // everyone's pieces are in LDS, and everyone has left the units of k-step kt - 1
+        if (kt + 1 < nk) issue_b(kt + 1);
+        if (kt + 2 < nk) issue_a(kt + 2);
+        const bf16* sA = unit(kt, 0);
+        const bf16* sB = unit(kt, 1);
 #pragma unroll
         for (int ks = 0; ks < kBK / 32; ks++) {
             bf16x8 fa[MT], fb[NT];
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
         return;
     }
     // the fp32 tile is 256 KiB, the dead ring 128: rows 0..127 (wave rows 0, 1) go through it first, then rows 128..255
-    static_assert((BM / 2) * BN * 4 <= NS * STAGE * 2, "half of the fp32 tile must fit the operand ring");
+    static_assert((BM / 2) * BN * 4 <= NU * UNIT * 2, "half of the fp32 tile must fit the operand ring");
     float* ct = (float*)smem_raw;
     __syncthreads();                                        // the last fragment reads of the ring are done
 #pragma unroll                                              // (two copies of the epilogue's rolled row loops: kept in a rolled loop the accumulators spill)
@@ -681,7 +693,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
     }
 }
 template <int AL, int BL> static int launch_bf16_u16(const GemmParams& P, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16);
+    constexpr size_t lds = (size_t)5 * 256 * kBK * sizeof(bf16);       // 160 KiB: the whole LDS of a CU
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -573,7 +573,10 @@ __global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_
 // leaves through the dead ring in two 128-row halves.
 // Every operand layout: K-major tiles as [256][64] (row & 7 swizzle), M-major ones as [64][256] (mswz<256>, transposing fragment reads).
 // ------------------------------------------------------------------------------------------------
-template <int AL, int BL>
+// SPREAD: the four pieces of a k-step are issued one per quarter of the wave's 32 MFMAs instead of together behind the barrier.  A CU accepts one
+// 1-KiB piece per ~47 clocks; sixty-four of them requested at once keep the last waves in their issue for most of a k-step before their MFMAs
+// start (first version: 4300 clocks per k-step = the 3000 of the issue + part of the 2048 of the MFMAs), spread out they hide behind the MFMAs.
+template <int AL, int BL, bool SPREAD>
 __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
                                                                 int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -637,21 +640,41 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
         if (kt + 1 < nk) wait_vmcnt<PA>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // everyone's pieces are in LDS, and everyone has left the units of k-step kt - 1
-        if (kt + 1 < nk) issue_b(kt + 1);
-        if (kt + 2 < nk) issue_a(kt + 2);
+        // the next pieces in request order B(kt + 1)[0], B(kt + 1)[1], A(kt + 2)[0], A(kt + 2)[1]; k-steps that need the slow path (K tail,
+        // segmented row maps) request a whole tile at once, at its first slot
+        const bool has_b = kt + 1 < nk, has_a = kt + 2 < nk;
+        const int kb = k_begin + (kt + 1) * kBK, ka = k_begin + (kt + 2) * kBK;
+        const bool fast_b = has_b && b_plain && kb + kBK <= k_end, fast_a = has_a && a_plain && ka + kBK <= k_end;
+        auto slot = [&](int q) {
+            if (!SPREAD) {
+                if (q == 0) { if (has_b) issue_b(kt + 1); if (has_a) issue_a(kt + 2); }
+                return;
+            }
+            if (q < PB) {
+                if (fast_b) dma_piece_fast<BN, BL, NW>(rb, unit(kt + 1, 1), vb, (unsigned)kb * b_step, w, q);
+                else if (has_b && q == 0) issue_b(kt + 1);
+            } else {
+                if (fast_a) dma_piece_fast<BM, AL, NW>(ra, unit(kt + 2, 0), va, (unsigned)ka * a_step, w, q - PB);
+                else if (has_a && q == PB) issue_a(kt + 2);
+            }
+        };
+        static_assert(PA == 2 && PB == 2 && MT == 4, "four request slots per k-step: one per two rows of MFMAs");
         const bf16* sA = unit(kt, 0);
         const bf16* sB = unit(kt, 1);
 #pragma unroll
         for (int ks = 0; ks < kBK / 32; ks++) {
             bf16x8 fa[MT], fb[NT];
+            slot(2 * ks);
 #pragma unroll
             for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
 #pragma unroll
             for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, BL>(sB, wn * WN + j * 16, ks);
 #pragma unroll
-            for (int i = 0; i < MT; i++)
+            for (int i = 0; i < MT; i++) {
+                if (i == MT / 2) slot(2 * ks + 1);
 #pragma unroll
                 for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
+            }
         }
     }
 
@@ -692,19 +715,19 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
         if (half == 0) __syncthreads();
     }
 }
-template <int AL, int BL> static int launch_bf16_u16(const GemmParams& P, hipStream_t st) {
+template <int AL, int BL, bool SPREAD> static int launch_bf16_u16(const GemmParams& P, hipStream_t st) {
     constexpr size_t lds = (size_t)5 * 256 * kBK * sizeof(bf16);       // 160 KiB: the whole LDS of a CU
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_u16_kernel<AL, BL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_u16_kernel<AL, BL, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm u16 lds=%zu): %s", lds, hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int grid = cdiv(P.M, 256) * cdiv(P.N, 256) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
-    gemm_bf16_u16_kernel<AL, BL><<<dim3(grid), dim3(1024), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split, P.nz,
+    gemm_bf16_u16_kernel<AL, BL, SPREAD><<<dim3(grid), dim3(1024), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split, P.nz,
                                                                       P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld, (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_u16");
 }
@@ -1024,6 +1047,7 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     const bool rows_ok = skinny_ok && M <= 32 && nz == 1 && K % 32 == 0;      // the weight-streaming kernel (tile code 3216)
     if (ft == 3216 && rows_ok) return TilePlan{3216, 1};
     if (ft == 128168) ft = 128160;      // the 8-consumer-wave launch of the same tile (run_bf16_dma looks at force_tile)
+    if (ft == 256257) ft = 256256;      // the 256 x 256 tile with its pieces requested together (A/B; run_bf16_dma looks at force_tile)
     const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * nz;
     if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || ft == 256128 || ft == 256256) {
         p.tile = ft;
@@ -1187,8 +1211,13 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
         return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 4, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 4, 8>(P, st);
     }
     if (P.tile == 256256) {
-        if (P.a_layout == 0) return P.b_layout == 0 ? launch_bf16_u16<0, 0>(P, st) : launch_bf16_u16<0, 1>(P, st);
-        return P.b_layout == 0 ? launch_bf16_u16<1, 0>(P, st) : launch_bf16_u16<1, 1>(P, st);
+        if (P.force_tile == 256257) {    // (A/B: the k-step's pieces requested together behind the barrier)
+            if (P.a_layout == 0) return P.b_layout == 0 ? launch_bf16_u16<0, 0, false>(P, st) : launch_bf16_u16<0, 1, false>(P, st);
+            return P.b_layout == 0 ? launch_bf16_u16<1, 0, false>(P, st) : launch_bf16_u16<1, 1, false>(P, st);
+        }
+        // (with an N-contiguous B operand the spread-out form spills at the 128-register cap - the transposing reads' addressing - and stays bunched)
+        if (P.a_layout == 0) return P.b_layout == 0 ? launch_bf16_u16<0, 0, true>(P, st) : launch_bf16_u16<0, 1, false>(P, st);
+        return P.b_layout == 0 ? launch_bf16_u16<1, 0, true>(P, st) : launch_bf16_u16<1, 1, false>(P, st);
     }
     if (P.tile == 3216) return launch_bf16_rows32(P, st);
     if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);

@@ -222,7 +222,10 @@ class GradientAllReducer:
         widen = self.reduce_dtype is not None and t.dtype != self.reduce_dtype
         x = t.to(self.reduce_dtype) if widen else t
         if self.cuda:
-            dist.all_reduce(x, op=dist.ReduceOp.AVG, group=self.group)
+            # (one rank - force_collectives on a single GPU: the mean IS the sum.  RCCL turns AVG into a pre-multiplied sum, which even at one rank
+            # is a kernel that reads and rewrites the whole bucket - `oneRankReduce<FuncPreMulSum>`: 0.39 ms per 115 MB segment on a side queue,
+            # ~4.4 ms of HBM-bound work per step beside the backward (profiles/r05_rccl_presence_trace.txt); an in-place SUM over one rank is nothing.)
+            dist.all_reduce(x, op=dist.ReduceOp.AVG if self.world > 1 else dist.ReduceOp.SUM, group=self.group)
         else:            # gloo (CPU tests): no AVG
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
             x.div_(self.world)

@@ -1079,10 +1079,15 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
         p = TilePlan{3264, want_split > 0 ? want_split : sp};
         return p;
     }
-    // 256 x 256 tiles on 16-wave workgroups (gemm_bf16_u16_kernel, every layout) for launches that hand every CU at least two of them
-    static const int u16_on = env_int("FF_GEMM_U16", 0), u16_min = env_int("FF_GEMM_U16_MIN_TILES", 512);
+    // 256 x 256 tiles on 16-wave workgroups (gemm_bf16_u16_kernel) for products with >= 4096 rows, a K-major weight and at least one tile per CU
+    // (config E's feed-forward up- and down-projections).  Measured against the 256 x 128 tile (r5s9 / r5s10, tools/gemm_graph_bench.py, cold weights):
+    // 4096 x 16384 x 4096 1079-1086 -> 1153-1156 TFLOP/s (with the GELU epilogue 1005 -> 1070), 4096 x 4096 x 16384 1157-1164 -> 1197-1206 (gated residual
+    // 1139 -> 1180), 8192^3 1185 -> 1273.  With an N-contiguous weight (data gradients) and for the weight gradients it LOSES to the planned tiles
+    // (999 -> 962, 1066 -> 943; 1014 -> 916) and at K = 1024 it is no better in the model's 12-block launches (config B: 41.27 vs 41.29 ms per step, r5s8),
+    // so those keep their tiles; spreading a k-step's four pieces over its MFMAs instead of requesting them together changed nothing (1153 vs 1153).
+    static const int u16_on = env_int("FF_GEMM_U16", 1);
     const long long t256sq = (long long)cdiv(M, 256) * cdiv(N, 256) * nz;
-    if (u16_on && t256sq >= u16_min && K >= 512 && M % 8 == 0 && N % 8 == 0 && want_split <= 1) return TilePlan{256256, 1};
+    if (u16_on && b_layout == 0 && M >= 4096 && K >= 2048 && t256sq >= 256 && M % 8 == 0 && N % 8 == 0 && want_split <= 1) return TilePlan{256256, 1};
     // Round 5: products with >= 4096 rows (config E: 4 x 1024 tokens, d = 4096, 16384 hidden - 97 % of that configuration's FLOPs) get 256 x 128
     // tiles on a 16-wave workgroup (eight MFMA waves 4 x 2, each on the same 64 x 64 slice as in the 128 x 128 kernel, + eight DMA waves), one
     // workgroup per CU: 85 FLOP per operand byte instead of 64, at the fill rate eight DMA waves reach alone on a CU.

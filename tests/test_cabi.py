@@ -191,7 +191,9 @@ def test_gemm_plan_for_the_benchmark_shapes():
     assert plan(1024, 1280, 5120, 0, 1) == (128, 160, 4)     # FFW1 dgrad: 64 tiles x split-K 4
     assert plan(1024, 512, 1280) == (64, 64, 2)              # q projection: small, 64^2 tiles + 2 splits
     assert plan(2048, 4096, 4096) == (128, 128, 1)
-    assert plan(4096, 16384, 4096) == (256, 128, 1) and plan(4096, 4096, 16384, 0, 1) == (256, 128, 1)      # config E's feed-forward products: 256 x 128 tiles
+    assert plan(4096, 16384, 4096) == (256, 256, 1) and plan(4096, 4096, 16384) == (256, 256, 1)            # config E's feed-forward products: 256 x 256 tiles on sixteen waves ...
+    assert plan(4096, 16384, 4096, 0, 1) == (256, 128, 1) and plan(4096, 4096, 16384, 0, 1) == (256, 128, 1)  # ... their data gradients (N-contiguous weight): 256 x 128
+    assert plan(10272, 1024, 1024) == (256, 128, 1)                                                            # (config B's resampler K / V projection: fewer 256 x 256 tiles than CUs)
     assert plan(16384, 4096, 4096, 1, 1) == (128, 128, 1)   # ... its weight gradients (M-major A): 128 x 128 (the 256 x 128 tile exists for them, measured equal: selectable, not planned)
     assert plan(4096, 512, 4096)[:2] == (128, 128) and plan(4096, 4096, 512) == (128, 128, 1)      # ... its q projection (too narrow) and to_out (short K)
     bm, bn, sk = plan(512, 1024, 10272, 1, 1)                # resampler dWk/dWv: 32 tiles, K = 10272

@@ -64,6 +64,8 @@ def gemm_kernel_of(tile, al, bl, split):
     if tile == 128160: return f"ff::gemm_bf16_pc_kernel<128, 160, {al}, {bl}, 4, 1, 8, 4>", 128, 160, 768
     if tile == 64002: return f"ff::gemm_bf16_pc_kernel<64, 64, {al}, {bl}, 3, 2, 4, 4>", 64, 64, 512
     if tile == 3264: return "ff::gemm_bf16_pc_kernel<32, 64, 0, 0, 4, 2, 4, 4>", 32, 64, 512
+    if tile == 256128 and al == 0: return f"ff::gemm_bf16_pc_kernel<256, 128, 0, {bl}, 3, 1, 8, 8>", 256, 128, 1024
+    if tile == 256256: return f"ff::gemm_bf16_u16_kernel<{al}, {bl}, {'true' if bl == 0 else 'false'}>", 256, 256, 1024
     return None, 0, 0, 0
 
 
@@ -124,7 +126,7 @@ if os.path.exists(os.path.join(src, "bench_stock_backbones.json")):      # (roun
     stock = json.loads(open(os.path.join(src, "bench_stock_backbones.json")).read().strip().splitlines()[-1])
     json.dump(stock, open(os.path.join(P, f"{rnd}_bench_stock_backbones.json"), "w"), indent=1)
 for extra in ("gemm_table.txt", "bucket_timeline.txt", "caption_decode_kernels.txt", "smoke.txt", "gemm_yardstick.txt", "decode_probe.txt", "decode_chain.txt",
-              "launch_modes_one_rank_rccl.txt", "gemm_ncw8_ab.txt"):
+              "launch_modes_one_rank_rccl.txt", "gemm_ncw8_ab.txt", "bench_config_E.json", "gemm_table_E.txt", "gemm_yardstick_E.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(P, f"{rnd}_{extra}"))
 print("dominant kernel", k, "traffic", line["roofline"]["traffic"], "frac", line["roofline"]["frac"], "value", line["value"])

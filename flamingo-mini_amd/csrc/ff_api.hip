@@ -659,6 +659,8 @@ static XaFusedArgs xa_fused_args(const ff_xattn_desc& x, const XaDims& s, bool e
     XaFusedArgs a = {};
     a.batch = s.b; a.heads = s.H; a.n_q = s.L; a.n_kv = s.Nk; a.n_visual = s.nv; a.tt_stride = x.tt_stride; a.tt_offset = x.tt_offset;
     a.dim = s.d; a.inner = s.inner; a.scale = s.scale; a.eps = 1e-5f;
+    static const int xcd_split = dbg_switch("FF_XATTN_XCD_SPLIT", 0);
+    a.xcd_split = xcd_split;
     const ff_strides sk = {(long long)s.Nk * 2 * s.inner, 2LL * s.inner, s.dh};
     a.k = ext_kv ? x.cached_k : sk;
     a.v = ext_kv ? x.cached_v : sk;

@@ -140,7 +140,7 @@ struct XaFusedArgs {
     int batch, heads, n_q, n_kv, n_visual, tt_stride, tt_offset;
     int dim, inner;          // model width (the projection's contraction length), heads * dim_head
     float scale, eps;
-    int reserved;
+    int xcd_split;           // resident kernels: an XCD takes 4 heads x batch / 4 samples instead of 8 heads x batch / 8 samples (see res_work_item)
     ff_strides k, v, dk, dv;
 };
 // Phase 2 of the resident kernels (round 5): the product over all heads of a sample inside the same launch.  Forward: W = to_out.weight

@@ -693,6 +693,26 @@ FF_DEV void res_park(bf16* tile, const f32x4 (&acc)[2], float scale, int w, int 
 }
 
 
+// Which (head, sample) a workgroup of the resident kernels works on.  Workgroup b runs on XCD b % 8 (speed only) and xcd_remap hands every XCD
+// a contiguous chunk of the work list.  Head fastest (the default): an XCD holds all eight heads of batch / 8 samples - a sample's rows enter
+// ONE private L2, every head's weight slices (W_q, and W_o / W_q again in phase 2) enter all eight.  xcd_split: an XCD holds FOUR heads of
+// batch / 4 samples - the rows enter two L2s, the weight slices four: 1.3 MB x 8 -> x 4 per weight matrix against 2.6 MB x 1 -> x 2 of rows at
+// the benchmark's shape (both served by the Infinity Cache after the first fetch).  Correctness does not depend on the placement: the
+// exchange of phase 2 goes through write-through stores and sc1 loads.
+FF_DEV void res_work_item(const XaFusedArgs& a, int& h, int& b) {
+    const int total = a.heads * a.batch;
+    const int lin = xcd_remap(blockIdx.x, total);
+    if (a.xcd_split && a.heads == 8 && (a.batch & 3) == 0) {
+        const int chunk = total >> 3;                   // workgroups per XCD (= batch)
+        const int x = lin / chunk, j = lin - x * chunk;
+        h = ((x & 1) << 2) | (j & 3);
+        b = (x >> 1) * (a.batch >> 2) + (j >> 2);
+    } else {
+        h = lin % a.heads;
+        b = lin / a.heads;
+    }
+}
+
 // ---- phase 2 of the resident kernels (round 5): the product that runs over ALL heads of a sample, inside the same launch ----
 // to_out (forward: attn_out = O . Wo^T, gated_cross_attention.py:124-126) and d LN(y) = scale * dQs . Wq (backward) contract over heads * 64,
 // i.e. over what the eight (sample, head) workgroups of a sample produced.  They used to be launches of their own (64 x 64 tiles, 5-8 % of
@@ -871,8 +891,8 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
     FF_XTL(0);
     const XaFusedArgs a = fetch_args(a_in);
     constexpr int DH = kResDH, BM = kResBM, NT = DH / 16;
-    const int lin = xcd_remap(blockIdx.x, a.heads * a.batch);          // head fastest: the workgroups reading the same rows of y share an L2
-    const int h = lin % a.heads, b = lin / a.heads;
+    int h, b;
+    res_work_item(a, h, b);
     const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nk = a.dim / kBK, n_rows = a.n_q;
@@ -1092,8 +1112,8 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
     const XaFusedArgs a = fetch_args(a_in);
     constexpr int DH = kResDH, BM = kResBM, NT = DH / 16;
     typedef SwzLayout L;
-    const int lin = xcd_remap(blockIdx.x, a.heads * a.batch);
-    const int h = lin % a.heads, b = lin / a.heads;
+    int h, b;
+    res_work_item(a, h, b);
     const int t = threadIdx.x, l = t & 63, c = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nk = a.dim / kBK, n_rows = a.n_q;

@@ -571,12 +571,10 @@ __global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_
 // its 32 MFMAs - four waves per SIMD cover each other's DMA-issue stalls, which is what the producer / consumer split buys the smaller tiles.
 // The LDS holds two and a half k-steps: five 32-KiB units, each one operand's tile of a k-step (see the ring in the kernel); the fp32 tile
 // leaves through the dead ring in two 128-row halves.
-// Every operand layout: K-major tiles as [256][64] (row & 7 swizzle), M-major ones as [64][256] (mswz<256>, transposing fragment reads).
+// Instantiated for K-major operands only (the forward projections): with transposing fragment reads on either operand the first versions lost
+// to the planned tiles (profiles/r05_gemm_u16_ab.txt), and those instantiations no longer exist.
 // ------------------------------------------------------------------------------------------------
-// SPREAD: the four pieces of a k-step are issued one per quarter of the wave's 32 MFMAs instead of together behind the barrier.  A CU accepts one
-// 1-KiB piece per ~47 clocks; sixty-four of them requested at once keep the last waves in their issue for most of a k-step before their MFMAs
-// start (first version: 4300 clocks per k-step = the 3000 of the issue + part of the 2048 of the MFMAs), spread out they hide behind the MFMAs.
-template <int AL, int BL, bool SPREAD>
+template <int AL, int BL>
 __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, const void* hB, int hM, int hN, int hK, int h_split, int h_kps,
                                                                 int h_nz, int h_xcd, int h_ald, int h_bld, int h_seg, const GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -635,47 +633,49 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
     FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
     if (tc.z > 0) pr = P.p[tc.z];
 
-    for (int kt = 0; kt < nk; kt++) {
-        // this wave's pieces of A(kt) and B(kt) have landed; the PA youngest ones - A(kt + 1) - may stay in flight across the barrier
-        if (kt + 1 < nk) wait_vmcnt<PA>();
+    // Two groups of waves, half a k-step apart.  A wave's k-step is read 0 - MFMA 0 - read 1 - MFMA 1; with the barrier in front of read 0 for
+    // everybody all sixteen waves read together and then multiply together, LDS pipe and matrix pipe taking turns (measured: a k-step costs the
+    // ~2000 clocks of its fragment reads PLUS the 2048 of its MFMAs).  Here the waves meet at the SAME barrier from two different places of the
+    // same code: the `early` ones between MFMA 1 and the next read 0, the `late` ones (two of the four on every SIMD) between read 1 and MFMA 1 -
+    // their fragments cross the barrier in registers.  Behind the barrier the late waves multiply while the early ones read, then the roles swap,
+    // and so on until they meet again.  Same instructions, same registers; only the barrier's place in the stream differs.
+    const bool late = P.force_tile != 256257 && ((w >> 2) & 1);
+    auto sync = [&](int kt) {           // k-step kt may be read: this wave's pieces of A(kt), B(kt) have landed (A(kt + 1) may stay in flight), and so have
+        if (kt + 1 < nk) wait_vmcnt<PA>();      // everybody's; everybody has left the units of k-step kt - 1, which take B(kt + 1) and A(kt + 2)
         else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                       // everyone's pieces are in LDS, and everyone has left the units of k-step kt - 1
-        // the next pieces in request order B(kt + 1)[0], B(kt + 1)[1], A(kt + 2)[0], A(kt + 2)[1]; k-steps that need the slow path (K tail,
-        // segmented row maps) request a whole tile at once, at its first slot
-        const bool has_b = kt + 1 < nk, has_a = kt + 2 < nk;
-        const int kb = k_begin + (kt + 1) * kBK, ka = k_begin + (kt + 2) * kBK;
-        const bool fast_b = has_b && b_plain && kb + kBK <= k_end, fast_a = has_a && a_plain && ka + kBK <= k_end;
-        auto slot = [&](int q) {
-            if (!SPREAD) {
-                if (q == 0) { if (has_b) issue_b(kt + 1); if (has_a) issue_a(kt + 2); }
-                return;
-            }
-            if (q < PB) {
-                if (fast_b) dma_piece_fast<BN, BL, NW>(rb, unit(kt + 1, 1), vb, (unsigned)kb * b_step, w, q);
-                else if (has_b && q == 0) issue_b(kt + 1);
-            } else {
-                if (fast_a) dma_piece_fast<BM, AL, NW>(ra, unit(kt + 2, 0), va, (unsigned)ka * a_step, w, q - PB);
-                else if (has_a && q == PB) issue_a(kt + 2);
-            }
-        };
-        static_assert(PA == 2 && PB == 2 && MT == 4, "four request slots per k-step: one per two rows of MFMAs");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue_b(kt + 1);
+        if (kt + 2 < nk) issue_a(kt + 2);
+    };
+    bf16x8 fa[MT], fb[NT];
+    auto read = [&](int kt, int ks) {
         const bf16* sA = unit(kt, 0);
         const bf16* sB = unit(kt, 1);
 #pragma unroll
-        for (int ks = 0; ks < kBK / 32; ks++) {
-            bf16x8 fa[MT], fb[NT];
-            slot(2 * ks);
+        for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
 #pragma unroll
-            for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
+        for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, BL>(sB, wn * WN + j * 16, ks);
+    };
+    auto mma = [&]() {
 #pragma unroll
-            for (int j = 0; j < NT; j++) fb[j] = frag_read2<BN, BL>(sB, wn * WN + j * 16, ks);
+        for (int i = 0; i < MT; i++)
 #pragma unroll
-            for (int i = 0; i < MT; i++) {
-                if (i == MT / 2) slot(2 * ks + 1);
-#pragma unroll
-                for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
-            }
+            for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
+    };
+    if (nk > 0) {
+        sync(0);
+        read(0, 0);
+    }
+    for (int kt = 0; kt < nk; kt++) {
+        mma();
+        read(kt, 1);
+        if (late && kt + 1 < nk) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments that cross the barrier in registers must have left the LDS
+            sync(kt + 1);
         }
+        mma();
+        if (!late && kt + 1 < nk) sync(kt + 1);
+        if (kt + 1 < nk) read(kt + 1, 0);
     }
 
     const int c = l & 15, g = l >> 4;
@@ -715,19 +715,19 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
         if (half == 0) __syncthreads();
     }
 }
-template <int AL, int BL, bool SPREAD> static int launch_bf16_u16(const GemmParams& P, hipStream_t st) {
+template <int AL, int BL> static int launch_bf16_u16(const GemmParams& P, hipStream_t st) {
     constexpr size_t lds = (size_t)5 * 256 * kBK * sizeof(bf16);       // 160 KiB: the whole LDS of a CU
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_u16_kernel<AL, BL, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_u16_kernel<AL, BL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         FF_CHECK(e == hipSuccess, FF_ERR_LAUNCH, "hipFuncSetAttribute(gemm u16 lds=%zu): %s", lds, hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int grid = cdiv(P.M, 256) * cdiv(P.N, 256) * P.split_k * P.nz;
     const int seg = P.a_map.rows_per_seg > 0 || P.b_map.rows_per_seg > 0 || P.a_map.ld >= (1LL << 31) || P.b_map.ld >= (1LL << 31);
-    gemm_bf16_u16_kernel<AL, BL, SPREAD><<<dim3(grid), dim3(1024), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split, P.nz,
+    gemm_bf16_u16_kernel<AL, BL><<<dim3(grid), dim3(1024), lds, st>>>(P.p[0].A, P.p[0].B, P.M, P.N, P.K, P.split_k, P.k_per_split, P.nz,
                                                                       P.xcd_ms | (P.xcd_ns << 8), (int)P.a_map.ld, (int)P.b_map.ld, seg, P);
     return check_launch("gemm_bf16_u16");
 }
@@ -1047,9 +1047,9 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     const bool rows_ok = skinny_ok && M <= 32 && nz == 1 && K % 32 == 0;      // the weight-streaming kernel (tile code 3216)
     if (ft == 3216 && rows_ok) return TilePlan{3216, 1};
     if (ft == 128168) ft = 128160;      // the 8-consumer-wave launch of the same tile (run_bf16_dma looks at force_tile)
-    if (ft == 256257) ft = 256256;      // the 256 x 256 tile with its pieces requested together (A/B; run_bf16_dma looks at force_tile)
+    if (ft == 256257) ft = 256256;      // A/B form of the 256 x 256 tile (the kernel looks at force_tile): all sixteen waves in step
     const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * nz;
-    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || ft == 256128 || ft == 256256) {
+    if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || ft == 256128 || (ft == 256256 && skinny_ok)) {
         p.tile = ft;
         if (want_split > 0) { p.split = want_split; return p; }
         const long long t = ft == 128 || ft == 128002 ? t128 : ft == 64 || ft == 64002 ? t64 : ft == 128160 ? (long long)cdiv(M, 128) * cdiv(N, 160) * nz
@@ -1087,7 +1087,7 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     // so those keep their tiles; spreading a k-step's four pieces over its MFMAs instead of requesting them together changed nothing (1153 vs 1153).
     static const int u16_on = env_int("FF_GEMM_U16", 1);
     const long long t256sq = (long long)cdiv(M, 256) * cdiv(N, 256) * nz;
-    if (u16_on && b_layout == 0 && M >= 4096 && K >= 2048 && t256sq >= 256 && M % 8 == 0 && N % 8 == 0 && want_split <= 1) return TilePlan{256256, 1};
+    if (u16_on && a_layout == 0 && b_layout == 0 && M >= 4096 && K >= 2048 && t256sq >= 256 && want_split <= 1) return TilePlan{256256, 1};
     // Round 5: products with >= 4096 rows (config E: 4 x 1024 tokens, d = 4096, 16384 hidden - 97 % of that configuration's FLOPs) get 256 x 128
     // tiles on a 16-wave workgroup (eight MFMA waves 4 x 2, each on the same 64 x 64 slice as in the 128 x 128 kernel, + eight DMA waves), one
     // workgroup per CU: 85 FLOP per operand byte instead of 64, at the fill rate eight DMA waves reach alone on a CU.
@@ -1215,15 +1215,7 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
         if (npw256 == 8) return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 8, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 8, 8>(P, st);
         return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 4, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 4, 8>(P, st);
     }
-    if (P.tile == 256256) {
-        if (P.force_tile == 256257) {    // (A/B: the k-step's pieces requested together behind the barrier)
-            if (P.a_layout == 0) return P.b_layout == 0 ? launch_bf16_u16<0, 0, false>(P, st) : launch_bf16_u16<0, 1, false>(P, st);
-            return P.b_layout == 0 ? launch_bf16_u16<1, 0, false>(P, st) : launch_bf16_u16<1, 1, false>(P, st);
-        }
-        // (with an N-contiguous B operand the spread-out form spills at the 128-register cap - the transposing reads' addressing - and stays bunched)
-        if (P.a_layout == 0) return P.b_layout == 0 ? launch_bf16_u16<0, 0, true>(P, st) : launch_bf16_u16<0, 1, false>(P, st);
-        return P.b_layout == 0 ? launch_bf16_u16<1, 0, true>(P, st) : launch_bf16_u16<1, 1, false>(P, st);
-    }
+    if (P.tile == 256256) return launch_bf16_u16<0, 0>(P, st);      // (force_tile 256257: all sixteen waves in step - the A/B form, decided inside the kernel)
     if (P.tile == 3216) return launch_bf16_rows32(P, st);
     if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);

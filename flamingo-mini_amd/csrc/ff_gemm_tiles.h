@@ -95,14 +95,6 @@ FF_DEV void dma_tile_fast(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const unsign
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + p * ROWS_PER_PASS_ELEMS + w * WAVE_ELEMS), 16, voff[p], soff, 0, 0);
 }
 
-// one piece (wave-level DMA instruction) of dma_tile_fast: lets a kernel whose waves both load and compute spread a tile's pieces over its k-step
-template <int BR, int LAYOUT, int NW = 4>
-FF_DEV void dma_piece_fast(__amdgpu_buffer_rsrc_t rsrc, bf16* stage, const unsigned* voff, unsigned soff, int w, int p) {
-    constexpr int ROWS_PER_PASS_ELEMS = LAYOUT == 0 ? (NW * 8) * kBK : (NW * (64 / (BR / 8))) * BR;
-    constexpr int WAVE_ELEMS = ROWS_PER_PASS_ELEMS / NW;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, FF_LDS_PTR(void, stage + p * ROWS_PER_PASS_ELEMS + w * WAVE_ELEMS), 16, voff[p], soff, 0, 0);
-}
-
 template <int BR, int LAYOUT> FF_DEV bf16x8 frag_read2(const bf16* s, int r0, int ks) {
     const int l = threadIdx.x & 63, c = l & 15, g = l >> 4;
     if (LAYOUT == 0) {

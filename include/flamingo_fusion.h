@@ -85,7 +85,8 @@ typedef struct ff_gemm_desc {
                    * 128168 = the same 128x160 tile with eight MFMA waves (4 x 2) + four DMA waves,
                    * 256128 = 256x128 producer/consumer, eight MFMA + eight DMA waves (chosen automatically for products with >= 4096 rows and a K-major A; with an
                    *          M-major A - weight gradients - eight MFMA + four DMA waves, selectable only),
-                   * 256256 = 256x256 on sixteen waves that both issue the DMA and run the MFMAs (every layout; two stages, `stages` ignored),
+                   * 256256 = 256x256 on sixteen waves that both issue the DMA and run the MFMAs (both operands K-major; `stages` ignored; chosen
+                   *          automatically for such products with >= 4096 rows, >= 2048 contraction elements and at least one tile per CU),
                    * 3264 = 32x64 producer/consumer (decode: M <= 32 rows; both operands K-major),
                    * 3216 = weight-streaming kernel for M <= 32 rows (16 output columns per workgroup, no LDS staging; K-major operands, K % 32 == 0) */
     int stages;   /* depth of the LDS operand ring: 0 = default, 2..4 */

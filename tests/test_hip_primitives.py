@@ -40,8 +40,9 @@ def test_gemm_every_instantiated_tile(al, bl):
     # 128168: the 128 x 160 tile with eight MFMA waves (4 x 2) + four DMA waves (round 4)
     # 256128: 256 x 128 tiles, eight MFMA + eight DMA waves (round 5: products with >= 4096 rows); with an M-major A operand (the weight
     #         gradients' d Y^T: 512-byte k-rows staged two per DMA instruction, transposing fragment reads) eight MFMA + four DMA waves
-    # 256256: 256 x 256 tiles, sixteen waves that both issue the DMA and run the MFMAs, two stages, the fp32 tile leaves in two halves (round 5)
-    for tile in (128, 6412, 64, 64002, 128002, 256128, 256256) + ((128160, 128168) if al == 0 else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
+    # 256256: 256 x 256 tiles, sixteen waves that both issue the DMA and run the MFMAs in two groups half a k-step apart, five-unit ring, the fp32
+    #         tile leaves in two halves (round 5; K-major operands); 256257: the same with all waves in step (the A/B form)
+    for tile in (128, 6412, 64, 64002, 128002, 256128) + ((128160, 128168) if al == 0 else ()) + ((256256, 256257) if (al, bl) == (0, 0) else ()) + ((3264,) if (al, bl) == (0, 0) else ()):
         for stages in (2, 3, 4):
             for split in (1, 2):
                 C = F().gemm(A, B, a_layout=al, b_layout=bl, split_k=split, tile=tile, stages=stages)
@@ -91,32 +92,31 @@ def test_gemm_large_row_tile_with_the_feed_forward_epilogues(bl):
     assert rel(C_, acc[:4000]) < t
 
 
-@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 1)], ids=["forward", "data-gradient", "weight-gradient"])
-def test_gemm_256_square_tile_with_the_feed_forward_epilogues(al, bl):
-    """The 256 x 256 tile (gemm_bf16_u16_kernel) with every epilogue of the feed-forward launches, on a grid with partial tiles in both
-    directions and a K tail, and as a grouped launch through the weight-gradient entry point's shape (three K tiles only: the ring wraps)."""
+@pytest.mark.parametrize("K", [1088 + 24, 136, 64], ids=["17-k-steps-and-a-tail", "3-k-steps", "1-k-step"])
+def test_gemm_256_square_tile_with_the_feed_forward_epilogues(K):
+    """The 256 x 256 tile (gemm_bf16_u16_kernel, K-major operands) with every epilogue of the feed-forward launches, on a grid with partial tiles in
+    both directions, for k-loops long enough to wrap the five-unit ring, and for one and three k-steps (prologue / tail of the two wave groups)."""
     dt = torch.bfloat16
-    M, N, K = 1160, 1320, 1088 + 24
+    M, N = 1160, 1320
     gate = dev(np.array([0.7]), dt)
     g = np.tanh(as64(gate)[0])
-    A = dev(rnd((M, K) if al == 0 else (K, M), 51, 0.5), dt)
-    B = dev(rnd((N, K) if bl == 0 else (K, N), 52, 0.05), dt)
+    A = dev(rnd((M, K), 51, 0.5), dt)
+    B = dev(rnd((N, K), 52, 0.05), dt)
     R, H = dev(rnd((M, N), 53), dt), dev(rnd((M, N), 54), dt)
-    acc = (as64(A) if al == 0 else as64(A).T) @ (as64(B).T if bl == 0 else as64(B))
-    r, h = as64(R), as64(H)
+    acc, r, h = as64(A) @ as64(B).T, as64(R), as64(H)
     t = TOL[dt]["out"]
-    kw = dict(a_layout=al, b_layout=bl, tile=256256)
-    assert rel(F().gemm(A, B, **kw), acc) < t
-    C_, aux = F().gemm(A, B, act="gelu", want_aux_out=True, **kw)
-    assert rel(aux, acc) < t and rel(C_, O.act_fwd(acc, "gelu")) < t
-    C_ = F().gemm(A, B, act_bwd="gelu", aux_in=H, gate=gate, **kw)
-    assert rel(C_, O.act_bwd(g * acc, h, "gelu")) < t
-    C_ = F().gemm(A, B, residual=R, gate=gate, **kw)
-    assert rel(C_, r + g * acc) < t
-    assert rel(F().gemm(A, B, split_k=3, **kw), acc) < t
-    short = F().gemm(A[:, :136] if al == 0 else A[:136], B[:, :136] if bl == 0 else B[:136], **kw)      # (strided views: the leading dimensions stay)
-    ref = ((as64(A)[:, :136] if al == 0 else as64(A)[:136].T) @ (as64(B)[:, :136].T if bl == 0 else as64(B)[:136]))
-    assert rel(short, ref) < t
+    for tile in (256256, 256257):
+        kw = dict(tile=tile)
+        assert rel(F().gemm(A, B, **kw), acc) < t
+        C_, aux = F().gemm(A, B, act="gelu", want_aux_out=True, **kw)
+        assert rel(aux, acc) < t and rel(C_, O.act_fwd(acc, "gelu")) < t
+        C_ = F().gemm(A, B, act_bwd="gelu", aux_in=H, gate=gate, **kw)
+        assert rel(C_, O.act_bwd(g * acc, h, "gelu")) < t
+        C_ = F().gemm(A, B, residual=R, gate=gate, **kw)
+        assert rel(C_, r + g * acc) < t
+        if K > 512:
+            assert rel(F().gemm(A, B, split_k=3, **kw), acc) < t
+    assert torch.equal(F().gemm(A, B, tile=256256), F().gemm(A, B, tile=256257))       # the two wave groups add the same products in the same order
 
 
 def test_gemm_balanced_producer_consumer_tile():

@@ -633,13 +633,10 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
     FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
     if (tc.z > 0) pr = P.p[tc.z];
 
-    // Two groups of waves, half a k-step apart.  A wave's k-step is read 0 - MFMA 0 - read 1 - MFMA 1; with the barrier in front of read 0 for
-    // everybody all sixteen waves read together and then multiply together, LDS pipe and matrix pipe taking turns (measured: a k-step costs the
-    // ~2000 clocks of its fragment reads PLUS the 2048 of its MFMAs).  Here the waves meet at the SAME barrier from two different places of the
-    // same code: the `early` ones between MFMA 1 and the next read 0, the `late` ones (two of the four on every SIMD) between read 1 and MFMA 1 -
-    // their fragments cross the barrier in registers.  Behind the barrier the late waves multiply while the early ones read, then the roles swap,
-    // and so on until they meet again.  Same instructions, same registers; only the barrier's place in the stream differs.
-    const bool late = P.force_tile != 256257 && ((w >> 2) & 1);
+    // (Measured and dropped, r5s10 / r5s12: a k-step's four pieces spread over its MFMAs instead of requested together - 1153 vs 1153 TFLOP/s;
+    // two groups of waves half a k-step apart, one multiplying while the other reads its fragments - 1135 vs 1150.  The SQ counters of r5s13 say
+    // why neither matters: the matrix pipe is busy 56 % of the launch at the ~2.0 GHz the chip holds under this load, LDS stalls are 3.6 % of the
+    // wave-cycles, no bank conflicts - the waves wait at the barrier for operand pieces, i.e. for the CU's ~47 clocks per 1-KiB request.)
     auto sync = [&](int kt) {           // k-step kt may be read: this wave's pieces of A(kt), B(kt) have landed (A(kt + 1) may stay in flight), and so have
         if (kt + 1 < nk) wait_vmcnt<PA>();      // everybody's; everybody has left the units of k-step kt - 1, which take B(kt + 1) and A(kt + 2)
         else wait_vmcnt<0>();
@@ -662,20 +659,12 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_u16_kernel(const void* hA, 
 #pragma unroll
             for (int j = 0; j < NT; j++) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);  // D[n][m]
     };
-    if (nk > 0) {
-        sync(0);
-        read(0, 0);
-    }
     for (int kt = 0; kt < nk; kt++) {
+        sync(kt);
+        read(kt, 0);
         mma();
         read(kt, 1);
-        if (late && kt + 1 < nk) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments that cross the barrier in registers must have left the LDS
-            sync(kt + 1);
-        }
         mma();
-        if (!late && kt + 1 < nk) sync(kt + 1);
-        if (kt + 1 < nk) read(kt + 1, 0);
     }
 
     const int c = l & 15, g = l >> 4;
@@ -1047,7 +1036,6 @@ static TilePlan plan_bf16(int M, int N, int K, int nz, int want_split, int a_lay
     const bool rows_ok = skinny_ok && M <= 32 && nz == 1 && K % 32 == 0;      // the weight-streaming kernel (tile code 3216)
     if (ft == 3216 && rows_ok) return TilePlan{3216, 1};
     if (ft == 128168) ft = 128160;      // the 8-consumer-wave launch of the same tile (run_bf16_dma looks at force_tile)
-    if (ft == 256257) ft = 256256;      // A/B form of the 256 x 256 tile (the kernel looks at force_tile): all sixteen waves in step
     const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * nz;
     if (ft == 128 || ft == 64 || ft == 64002 || ft == 6412 || ft == 128002 || (ft == 128160 && pc_ok) || (ft == 3264 && skinny_ok) || ft == 256128 || (ft == 256256 && skinny_ok)) {
         p.tile = ft;
@@ -1215,7 +1203,7 @@ static int run_bf16_dma(const GemmParams& P, hipStream_t st) {
         if (npw256 == 8) return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 8, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 8, 8>(P, st);
         return P.b_layout == 0 ? launch_bf16_pc<256, 128, 0, 0, 3, 1, 4, 8>(P, st) : launch_bf16_pc<256, 128, 0, 1, 3, 1, 4, 8>(P, st);
     }
-    if (P.tile == 256256) return launch_bf16_u16<0, 0>(P, st);      // (force_tile 256257: all sixteen waves in step - the A/B form, decided inside the kernel)
+    if (P.tile == 256256) return launch_bf16_u16<0, 0>(P, st);
     if (P.tile == 3216) return launch_bf16_rows32(P, st);
     if (P.tile == 3264) return launch_bf16_pc<32, 64, 0, 0, 4, 2>(P, st);
     if (P.tile == 128) return run_bf16_dma_tile<128, 128>(P, ns, st);

@@ -126,7 +126,7 @@ if os.path.exists(os.path.join(src, "bench_stock_backbones.json")):      # (roun
     stock = json.loads(open(os.path.join(src, "bench_stock_backbones.json")).read().strip().splitlines()[-1])
     json.dump(stock, open(os.path.join(P, f"{rnd}_bench_stock_backbones.json"), "w"), indent=1)
 for extra in ("gemm_table.txt", "bucket_timeline.txt", "caption_decode_kernels.txt", "smoke.txt", "gemm_yardstick.txt", "decode_probe.txt", "decode_chain.txt",
-              "launch_modes_one_rank_rccl.txt", "gemm_ncw8_ab.txt", "bench_config_E.json", "gemm_table_E.txt", "gemm_yardstick_E.txt"):
+              "launch_modes_one_rank_rccl.txt", "gemm_ncw8_ab.txt", "bench_config_A.json", "bench_config_C.json", "bench_config_D.json", "bench_config_E.json", "gemm_table_E.txt", "gemm_yardstick_E.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(P, f"{rnd}_{extra}"))
 print("dominant kernel", k, "traffic", line["roofline"]["traffic"], "frac", line["roofline"]["frac"], "value", line["value"])

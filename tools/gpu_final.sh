@@ -1,6 +1,6 @@
 #!/bin/bash
 ulimit -c 0   # no core files: a GPU fault must not fill the scratch disk
-# Round-end measurement session on ONE box: full parity suite, smoke, the default bench line (with its companion runs), the rocprofv3 kernel
+# Round-end measurement session on ONE box (round 5: + configs A / C / D / E, config E's GEMM table and yardstick; - the decode probe and the 8-MFMA-wave A/B of round 4): full parity suite, smoke, the default bench line (with its companion runs), the rocprofv3 kernel
 # trace of the same command, the two PMC traffic passes and the SQ MFMA-busy pass (separate runs, --kernel-trace only), the bucket timeline of
 # the data-parallel launch structure, the kernel statistics of the caption leg.
 #   tools/gpu_final.sh <tag> <round>      results under gpurun_out/<tag>/ ; tools/collect_profiles.py turns them into profiles/<round>_*
@@ -21,8 +21,6 @@ cd $R
 # round 4: hipBLASLt beside every GEMM shape of the step (same method for both), the decode kernels in isolation (probe with phase timestamps, the 36-block
 # chain), the three launch modes of the step with the gradient exchange going through a 1-rank RCCL group + the bucket timeline, the 128 x 160 tile with 4 / 8 MFMA waves
 timeout 400 python tools/gemm_yardstick.py $out/gemm_table.txt > $out/gemm_yardstick.txt 2> $out/gemm_yardstick.err; head -5 $out/gemm_yardstick.txt
-P=tools/experiments/_bin/decode_probe
-if [ -x $P ]; then for a in "32 5120 1280 20 1 1" "32 5120 1280 20 1 0" "32 1280 5120 20 4 0" "32 8192 2048 32 1 1" "32 2048 8192 32 4 0"; do echo "== decode_probe $a"; timeout 60 $P $a 2>&1 | tail -4; done > $out/decode_probe.txt 2>&1; fi
 ( python tools/decode_chain_bench.py 2>&1 | tail -1; for v in "FF_DECODE_FFW=0" "FF_DECODE_FFW=1"; do ( export FLAMINGO_FUSION_LIB=debug $v; echo "[development build, $v] $(python tools/decode_chain_bench.py 2>&1 | tail -1)" ); done ) > $out/decode_chain.txt
 cat $out/decode_chain.txt
 B2="python bench.py --no-cpu-baseline --caption-tokens 0 --profile-steps 0 --companions off --steps 12 --warmup 3"
@@ -39,9 +37,15 @@ import sys, json
 d = next(json.loads(l) for l in reversed(sys.stdin.read().strip().splitlines()) if l.startswith('{'))
 print('graph=on, no collectives (the single-GPU default):', d['value'], 'images/s', d['ms_per_step'], 'ms/step')" ) > $out/launch_modes_one_rank_rccl.txt
 head -4 $out/launch_modes_one_rank_rccl.txt
-( for t in 128160 128168 128160 128168; do python tools/gemm_graph_bench.py 1024 5120 1280 0 0 $t 2>/dev/null | tail -1; done
-  for t in 128160 128168; do EPI=act python tools/gemm_graph_bench.py 1024 5120 1280 0 0 $t 2>/dev/null | tail -1; done
-  for t in 128160 128168; do EPI=act_bwd python tools/gemm_graph_bench.py 1024 5120 1280 0 1 $t 2>/dev/null | tail -1; done ) > $out/gemm_ncw8_ab.txt
+# round 5: the other configurations of BASELINE.json (stock backbones, 6 timed steps), config E with its per-shape GEMM table and hipBLASLt beside every one of its shapes
+for c in A C D; do timeout 400 python bench.py --config $c --no-cpu-baseline --caption-tokens 0 --companions off --steps 6 --warmup 2 2> $out/bench_config_$c.err | tail -1 > $out/bench_config_$c.json; done
+timeout 600 python bench.py --config E --no-cpu-baseline --caption-tokens 0 --companions off --steps 6 --warmup 2 --gemm-table $out/gemm_table_E.txt 2> $out/bench_config_E.err | tail -1 > $out/bench_config_E.json
+timeout 500 python tools/gemm_yardstick.py $out/gemm_table_E.txt > $out/gemm_yardstick_E.txt 2> $out/gemm_yardstick_E.err; head -4 $out/gemm_yardstick_E.txt | cut -c1-200
+for c in A C D E; do python -c "
+import json,sys
+try:
+    d=json.loads(open('$out/bench_config_$c.json').read().strip().splitlines()[-1]); print('config $c:', d['value'], d['unit'], d['ms_per_step'], 'ms/step')
+except Exception as e: print('config $c: no line', e)"; done
 python tools/bucket_timeline.py $(find $out/bucket -name "*kernel_trace.csv" | head -1) > $out/bucket_timeline.txt 2>&1; head -20 $out/bucket_timeline.txt
 python - > $out/caption_decode_kernels.txt <<P
 import csv, glob

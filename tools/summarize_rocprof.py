@@ -48,6 +48,9 @@ def main():
     print("| category | ms/step | share | launches/step |\n|---|---:|---:|---:|")
     for k, (ns, n) in sorted(cats.items(), key=lambda kv: -kv[1][0]):
         print(f"| {k} | {ns / 1e6 / a.steps_total:.2f} | {100 * ns / tot:.1f}% | {n // a.steps_total} |")
+    lib_ns = sum(ns for k, (ns, n) in cats.items() if k.startswith("fusion"))
+    lib_n = sum(n for k, (ns, n) in cats.items() if k.startswith("fusion"))
+    print(f"\nfusion library total: **{lib_ns / 1e6 / a.steps_total:.2f} ms/step in {lib_n // a.steps_total} launches/step**; stock backbones + loss glue: {(tot - lib_ns) / 1e6 / a.steps_total:.2f} ms/step")
     print(f"\n## top {a.top} kernels\n\n| kernel | calls | avg us | total ms/step | share |\n|---|---:|---:|---:|---:|")
     for r in sorted(rows, key=lambda r: -int(r["TotalDurationNs"]))[: a.top]:
         name = re.sub(r"\(.*", "", r["Name"])[:110]

@@ -576,6 +576,7 @@ static size_t xa_saved_layout(const XaDims& s, void* base, size_t cap, XaSaved& 
 struct XaScratch {
     void *dy1, *dH, *dxn, *dO, *dQs, *dKV, *dyn, *ws;
     size_t ws_bytes;
+    float* lnx;      // exchange buffer of the resident kernels' phase 3 (per-row pairs of every (sample, head) workgroup)
 };
 // What the four weight-gradient GEMMs of a block read besides `saved` and d y_out: kept in a caller-owned `stash` when they are
 // deferred (ff_xattn_block_bwd_kv_data -> ff_xattn_wgrad_grouped), in `scratch` otherwise.
@@ -617,6 +618,7 @@ static size_t xa_scratch_layout(const XaDims& s, void* base, size_t cap, bool bw
     const size_t M = (size_t)s.b * s.L;
     o.ws_bytes = xa_ws_bytes(s);
     o.ws = a.take(o.ws_bytes);
+    o.lnx = a.take<float>(xa_ln3_part_bytes(s.b, s.H));
     if (bwd) {
         o.dy1 = a.take(M * s.d * s.es);
         o.dH = a.take(M * s.ffi * s.es);
@@ -655,6 +657,11 @@ static bool xa_fused_enabled() {
     static const int v = dbg_switch("FF_XATTN_FUSED", 1);
     return v != 0;
 }
+// development builds: FF_XATTN_LN3=0 keeps the LayerNorm behind phase 2 (forward: LN(y1); backward: the backward of LN(y)) as a launch of its own
+static bool xa_ln3_enabled() {
+    static const int v = dbg_switch("FF_XATTN_LN3", 1);
+    return v != 0;
+}
 static XaFusedArgs xa_fused_args(const ff_xattn_desc& x, const XaDims& s, bool ext_kv) {
     XaFusedArgs a = {};
     a.batch = s.b; a.heads = s.H; a.n_q = s.L; a.n_kv = s.Nk; a.n_visual = s.nv; a.tt_stride = x.tt_stride; a.tt_offset = x.tt_offset;
@@ -668,6 +675,14 @@ static XaFusedArgs xa_fused_args(const ff_xattn_desc& x, const XaDims& s, bool e
     return a;
 }
 
+// Whether xattn_bwd runs the backward of LN(y) inside the fused attention-backward launch (phase 3).  A function of the descriptor alone:
+// xattn_wgrad_grouped must know how many partial blocks that pass left in the stash (one per SAMPLE then, not one per 4 rows).
+static bool xa_ln3_in_bwd(const ff_xattn_desc& x, const XaDims& s) {
+    if (!xa_ln3_enabled() || !xa_fused_enabled() || !xa_fused_supported(s.dt, s.dh, s.d, s.inner) || x.sync == nullptr) return false;
+    const XaFusedArgs fa = xa_fused_args(x, s, s.ext_kv);
+    const int M = s.b * s.L;
+    return xa_out_fusable(fa, s.dt, s.dh) && s.b <= layernorm_bwd_partial_blocks(M) && (size_t)s.b * (2 * (size_t)s.d + 2) * sizeof(float) <= layernorm_bwd_workspace(M, s.d);
+}
 static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, const int* tt, const void* const* P, const void* ck,
                      const void* cv, void* y_out, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, hipStream_t st) {
     FF_TRY(xa_check(d));
@@ -689,15 +704,20 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     } else {
         Kp = ck; Vp = cv;
     }
-    bool out_fused = false;
+    bool out_fused = false, ln_fused = false;
     if (xa_fused_enabled() && xa_fused_supported(s.dt, s.dh, s.d, s.inner)) {
         // y = norm(y); q = to_q(y) * scale; masked softmax(q k^T) v (:74-78, :95-123) in ONE launch per block
         // ... and, with a sync buffer at the training / decode shape, y1 = y + tanh(alpha_attn) * to_out(o) (:126, :180) in the same launch
         const XaFusedArgs fa = xa_fused_args(*d, s, cached);
-        const XaOutArgs oa = {(const bf16*)P[6], (const bf16*)P[0], (bf16*)S.y1, (bf16*)S.attn_out, (unsigned*)d->sync};
+        XaOutArgs oa = {(const bf16*)P[6], (const bf16*)P[0], (bf16*)S.y1, (bf16*)S.attn_out, (unsigned*)d->sync};
         // (not at the decode shape, <= 32 rows in all: there `to_out` is a 3.7 us weight-streaming launch and the in-launch exchange costs more
         // than that launch and its boundary - measured, r5s1: phase 2 adds ~10 us to the fused launch)
         out_fused = d->sync != nullptr && xa_out_fusable(fa, s.dt, s.dh) && !decode_ffw_supported(s.dt, M, s.d, s.ffi);
+        if (out_fused && xa_ln3_enabled()) {      // ... and LN(y1) of the feed-forward (utils.py:46) behind it, still in the same launch (phase 3)
+            oa.ln_g = (const bf16*)P[7]; oa.ln_b = (const bf16*)P[8]; oa.ln_out = (bf16*)S.xn_f; oa.ln_mean = S.mean_f; oa.ln_rstd = S.rstd_f;
+            oa.ln_part = W.lnx;
+            ln_fused = true;
+        }
         FF_TRY(xa_qattn_fwd(fa, s.dt, s.dh, y, P[2], P[3], P[4], Kp, Vp, tt, S.yn, S.Qs, S.O, S.mean_a, S.rstd_a, S.lse, st, out_fused ? &oa : nullptr));
     } else {
         // y = norm(y); q = to_q(y) * scale (:74-78)
@@ -711,7 +731,7 @@ static int xattn_fwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     if (decode_ffw_supported(s.dt, M, s.d, s.ffi))      // <= 32 rows (the cached decode step): LayerNorm + up-projection and down-projection + gate + residual, two launches
         return decode_ffw(M, s.d, s.ffi, s.act, 1e-5f, S.y1, P[7], P[8], P[9], P[10], P[1], S.xn_f, S.mean_f, S.rstd_f, S.Hpre, S.Aact, S.ffw_out, y_out,
                           W.ws, W.ws_bytes, st);
-    FF_TRY(layernorm_fwd(ln_args(s.dt, M, s.d, pd, pd, pd), S.y1, nullptr, P[7], P[8], S.xn_f, S.mean_f, S.rstd_f, st));
+    if (!ln_fused) FF_TRY(layernorm_fwd(ln_args(s.dt, M, s.d, pd, pd, pd), S.y1, nullptr, P[7], P[8], S.xn_f, S.mean_f, S.rstd_f, st));
     FF_TRY(Gemm(s.dt, M, s.ffi, s.d).a(0, pd).b(0, pd).c(pF).act(s.act).problem(S.xn_f, P[9], S.Aact, S.Hpre).run(W.ws, W.ws_bytes, st));
     return Gemm(s.dt, M, s.d, s.ffi).a(0, pF).b(0, pF).c(pd).problem(S.Aact, P[10], y_out, S.ffw_out, nullptr, S.y1, P[1]).run(W.ws, W.ws_bytes, st);
 }
@@ -776,17 +796,30 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
     char* dV = dK + (size_t)s.inner * s.es;
     const void* Kp = hoisted ? ext_k : S.KV;
     const void* Vp = hoisted ? ext_v : (const void*)((const char*)S.KV + (size_t)s.inner * s.es);
-    bool dyn_fused = false;
+    bool dyn_fused = false, lnb_fused = false;
+    float* lnb_partial = nullptr;
     if (xa_fused_enabled() && xa_fused_supported(s.dt, s.dh, s.d, s.inner)) {
         // d o = tanh(alpha_attn) * d y1 . Wo and the attention backward in one launch (two when the queries of a sample span several tiles)
         // ... and, with a sync buffer at the training shape, d LN(y) = scale * d Qs . Wq in the same launch
         int single = 0;
         const XaFusedArgs fa = xa_fused_args(*d, s, hoisted);
-        const XaOutArgs oa = {(const bf16*)P[4], nullptr, (bf16*)W.dyn, nullptr, (unsigned*)d->sync};
+        XaOutArgs oa = {(const bf16*)P[4], nullptr, (bf16*)W.dyn, nullptr, (unsigned*)d->sync};
         dyn_fused = d->sync != nullptr && xa_out_fusable(fa, s.dt, s.dh);
+        if (dyn_fused && xa_ln3_in_bwd(*d, s)) {      // ... and the backward of LN(y) behind it (phase 3): d y leaves this launch, d LN(y) is never stored
+            lnb_fused = true;
+            lnb_partial = defer_ln ? T.lnp_a : (float*)W.ws;
+            oa.out = nullptr;
+            oa.ln_g = (const bf16*)P[2]; oa.ln_x = (const bf16*)y; oa.ln_res = (const bf16*)T.dy1; oa.ln_out = (bf16*)dy;
+            oa.ln_mean = S.mean_a; oa.ln_rstd = S.rstd_a; oa.ln_part = W.lnx; oa.ln_wpart = lnb_partial;
+        }
         FF_TRY(xa_dattn_bwd(fa, s.dt, s.dh, T.dy1, P[6], P[0], S.Qs, Kp, Vp, tt, S.O, S.lse, W.dO, T.dQs, dK, dV, attn_ws, &single, st,
                             dyn_fused ? &oa : nullptr));
         if (!single) FF_TRY(attention_bwd_dkv(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, W.dO, S.lse, attn_ws, dK, dV, st));
+        if (lnb_fused && !defer_ln) {     // the per-sample column sums sit in W.ws, which the products below may use for their split-K slabs: reduce them now
+            LnPending q;
+            q.partial = lnb_partial; q.nblk = s.b; q.cols = s.d; q.dgamma = G[2]; q.dbeta = G[3];
+            FF_TRY(layernorm_bwd_finish(s.dt, &q, 1, st));
+        }
     } else {
         FF_TRY(Gemm(s.dt, M, s.inner, s.d).a(0, pd).b(1, pI).c(pI).problem(T.dy1, P[6], W.dO, nullptr, nullptr, nullptr, P[0]).run(W.ws, gws, st));
         FF_TRY(attention_bwd(xa_attn_desc(*d, s, hoisted), S.Qs, Kp, Vp, tt, S.O, W.dO, S.lse, T.dQs, dK, dV, attn_ws, (size_t)s.b * s.H * s.L * 4, st));
@@ -797,6 +830,8 @@ static int xattn_bwd(const ff_xattn_desc* d, const void* y, const void* vf, cons
         if (dvf) FF_TRY(Gemm(s.dt, Mk, s.dv, 2 * s.inner).a(0, pKV).b(1, pV).c(pV).problem(W.dKV, P[5], dvf).run(W.ws, gws, st));
     }
     if (!dyn_fused) FF_TRY(Gemm(s.dt, M, s.d, s.inner).a(0, pI).b(1, pd).c(pd).scale(s.scale).problem(T.dQs, P[4], W.dyn).run(W.ws, gws, st));
+    if (lnb_fused) return FF_OK;     // d y left the fused launch; the column sums (d gamma, d beta) were reduced above, or wait in T.lnp_a - s.b blocks, see
+                                     // xa_ln3_in_bwd - for xattn_wgrad_grouped
     if (defer_ln) {
         FF_TRY(layernorm_bwd(ln_args(s.dt, M, s.d, pd, pd, pd), W.dyn, y, nullptr, P[2], S.mean_a, S.rstd_a, dy, T.dy1, G[2], G[3], T.lnp_a,
                              layernorm_bwd_partial_bytes(M, s.d), st, nullptr, &pend_a));
@@ -852,7 +887,7 @@ static int xattn_wgrad_grouped(const ff_xattn_desc* d, int n, const void* const*
             f.partial = T.lnp_f; f.nblk = ln_blocks; f.cols = s.d; f.dgamma = G[7]; f.dbeta = G[8];
             f.alpha_a = P[1]; f.out_a = G[1]; f.alpha_b = P[0]; f.out_b = G[0];
             LnPending& q = ln_sets[2 * i + 1];
-            q.partial = T.lnp_a; q.nblk = ln_blocks; q.cols = s.d; q.dgamma = G[2]; q.dbeta = G[3];
+            q.partial = T.lnp_a; q.nblk = xa_ln3_in_bwd(*d, s) ? s.b : ln_blocks; q.cols = s.d; q.dgamma = G[2]; q.dbeta = G[3];
         }
     }
     if (finish_ln) FF_TRY(layernorm_bwd_finish(s.dt, ln_sets, 2 * n, st));
@@ -1012,7 +1047,7 @@ extern "C" int ff_resampler_epilogue_bwd(const ff_resampler_desc* d, const void*
     return ff::rs_epilogue_bwd(d, dout, x_last, norm_weight, saved_epi, saved_epi_bytes, dx_last, d_norm_weight, d_norm_bias, scratch, scratch_bytes, stream);
 }
 
-extern "C" size_t ff_xattn_sync_bytes(void) { return (size_t)(2 * FF_XATTN_SYNC_SLOTS + 64) * sizeof(unsigned); }
+extern "C" size_t ff_xattn_sync_bytes(void) { return (size_t)(4 * FF_XATTN_SYNC_SLOTS + 64) * sizeof(unsigned); }
 extern "C" int ff_xattn_sync_status(const void* sync, hipStream_t stream) {
     FF_CHECK(sync, FF_ERR_SHAPE, "ff_xattn_sync_status: null buffer");
     unsigned flag = 0;

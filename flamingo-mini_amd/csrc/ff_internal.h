@@ -146,13 +146,29 @@ struct XaFusedArgs {
 // Phase 2 of the resident kernels (round 5): the product over all heads of a sample inside the same launch.  Forward: W = to_out.weight
 // [dim][inner], out = y1 = y + tanh(*gate) * O . W^T, aux = O . W^T.  Backward: W = to_q.weight [inner][dim], out = scale * dQs . W (d LN(y)).
 // sync: the caller-owned counters of ff_xattn_desc.sync.
+// Phase 3 (optional, ln_out != null): the LayerNorm that consumes phase 2's output, in the same launch - a workgroup holds 1 / heads of every row, so the
+// rows' statistics (forward: mean / M2 of the slice, combined like Chan et al.; backward: the two sums of the LayerNorm backward) make one more trip
+// through a second bank of arrival counters, two floats per row and workgroup (`ln_part`).
+//   forward : ln_out = LN(y1) with ln_g / ln_b (the feed-forward's LayerNorm, utils.py:46), ln_mean / ln_rstd WRITTEN (saved for its backward)
+//   backward: ln_out = d y = LayerNorm-backward(d LN(y); ln_x = y, ln_g, ln_mean / ln_rstd READ) + ln_res (d y1), and the sample's column sums
+//             (d gamma | d beta) of the workgroup's slice go to ln_wpart[sample][2 dim + 2] for layernorm_bwd_finish; `out` (d LN(y)) may be null
 struct XaOutArgs {
     const bf16* W;
     const bf16* gate;
     bf16* out;
     bf16* aux;
     unsigned* sync;
+    const bf16* ln_g;
+    const bf16* ln_b;
+    bf16* ln_out;
+    float* ln_mean;
+    float* ln_rstd;
+    const bf16* ln_x;
+    const bf16* ln_res;
+    float* ln_part;      // [batch][heads][32][2] fp32, scratch
+    float* ln_wpart;     // backward: [batch][2 dim + 2] fp32
 };
+size_t xa_ln3_part_bytes(int batch, int heads);
 // whether xa_qattn_fwd / xa_dattn_bwd will take the resident kernels WITH phase 2 for this problem when handed a sync buffer
 bool xa_out_fusable(const XaFusedArgs& a, int dtype, int dim_head);
 bool xa_fused_supported(int dtype, int dim_head, int dim, int inner);

@@ -877,6 +877,37 @@ FF_DEV void res_out_phase(const bf16* sA2, bf16* ring, __amdgpu_buffer_rsrc_t rb
         default: { constexpr int PER = 6; __VA_ARGS__; } break;      \
     }
 
+// ---- phase 3 of the resident kernels (round 5): the LayerNorm behind phase 2's output, inside the same launch ----
+// After phase 2 a workgroup holds the columns [n0, n0 + dim / heads) of its sample's 32 rows; a LayerNorm (forward) or its backward needs two
+// sums per ROW over all columns.  Each workgroup reduces its slice to a pair per row, publishes the 32 pairs (8-byte write-through stores),
+// arrives on the sample's counter of a SECOND bank (the first bank's counter of the same launch is still being waited on by slower heads), and
+// once all heads are in reads the heads x 32 pairs back with sc1 loads: 256 bytes out, 2 KiB in per workgroup.
+constexpr int kLn3Bank = 2 * kSyncSlots + 64;           // forward bank of the phase-3 counters; the backward bank follows at + kSyncSlots
+constexpr int kLn3Items = 32 * 32 * kOutMaxPer / 8;     // 16-byte pieces of a workgroup's output slice: 32 rows x dim / heads / 8 <= 768
+struct Ln3Smem {
+    float *item_a, *item_b, *stat, *fin, *cols;
+};
+FF_DEV Ln3Smem ln3_smem(float* base) { return Ln3Smem{base, base + kLn3Items, base + 2 * kLn3Items, base + 2 * kLn3Items + 512, base + 2 * kLn3Items + 576}; }
+// thread r < n_rows holds row r's pair (va, vb); on return stat[(r * heads + hh) * 2 + {0, 1}] = head hh's pair of row r, for every row
+FF_DEV void ln3_exchange(float* part, unsigned* cnt, unsigned* status, int b, int h, int heads, int n_rows, int t, float va, float vb, float* stat) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, 0x7fffffff, 0x00020000);
+    if (t < n_rows)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb)}, rp,
+                                              (unsigned)(((b * heads + h) * 32 + t) * 8), 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the pairs have left the CU
+    res_barrier();
+    if (t == 0) res_await(cnt, res_arrive(cnt, (unsigned)heads), status);
+    res_barrier();
+    if (t < n_rows * heads) {
+        const int r = t / heads, hh = t - r * heads;
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rp, (unsigned)(((b * heads + hh) * 32 + r) * 8), 0, 16);
+        stat[t * 2] = __builtin_bit_cast(float, v[0]);
+        stat[t * 2 + 1] = __builtin_bit_cast(float, v[1]);
+    }
+    __syncthreads();
+}
+
 }  // namespace
 
 // OUTP: phase 2 - to_out + tanh gate + residual for this workgroup's column slice of all 32 rows (see the helpers above); `O` is then
@@ -1066,18 +1097,24 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
     // the residual rows of the epilogue are requested now (at most two 16-byte pieces per thread: 32 rows x cs / 8 <= 768 pieces) and
     // arrive under the product (timeline r5s3: the epilogue was 1.35 us with the loads inside it, 0.4 us in the backward kernel without any)
     const int cpr = cs / 8, ld = cs + 4, n_items = n_rows * cpr;
-    uint4 yreg[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
+    const bool ln3 = oa.ln_out != nullptr;                             // phase 3: LN(y1) of the feed-forward in this launch too
+    uint4 yreg[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}}, greg[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}}, breg[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int i = t + u * 512;
         if (i < n_items) {
             const int r = i / cpr, c8 = i - r * cpr;
             yreg[u] = *(const uint4*)(y + ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8);
+            if (ln3) {
+                greg[u] = *(const uint4*)(oa.ln_g + n0 + c8 * 8);
+                breg[u] = *(const uint4*)(oa.ln_b + n0 + c8 * 8);
+            }
         }
     }
     FF_RES_PER(per, (res_out_phase<PER, 0>(sA2, ring2, rwo, vo, 2u, nk2, w, c, g, sP)));
     __syncthreads();
     FF_XTL(7);
+    float y1r[2][8];                                                   // the workgroup's slice of y1 as stored (bf16-rounded): what LN(y1) sees
     {
         const float gt = tanhf(to_f32(oa.gate[0]));
 #pragma unroll
@@ -1091,13 +1128,85 @@ __global__ __launch_bounds__(512) void xa_qattn_fwd_res_kernel(const XaFusedArgs
                 float yv[8], av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, ov[8];
                 unpack16(yreg[u], yv, bf16());
 #pragma unroll
-                for (int e = 0; e < 8; e++) ov[e] = av[e] * gt + yv[e];
+                for (int e = 0; e < 8; e++) {
+                    ov[e] = av[e] * gt + yv[e];
+                    y1r[u][e] = (float)(bf16)ov[e];
+                }
                 Vec<bf16>::store(oa.aux + go, av);                     // to_out(attention): an operand of d alpha_attn
                 Vec<bf16>::store(oa.out + go, ov);
             }
         }
     }
     FF_XTL(8);
+    if (!ln3) return;
+
+    // ---- phase 3: xn = LN(y1) (utils.py:46) for the same slice.  Per row: mean and M2 of the slice's cs columns, exact two-pass; the heads'
+    //      pairs are combined as equal-sized groups (Chan et al.): mean = avg(mean_h), M2 = sum(M2_h) + cs * sum((mean_h - mean)^2) ----
+    const Ln3Smem L3 = ln3_smem((float*)sB);                           // the operand rows of phase 2 are dead (res_out_phase ended behind a barrier)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = t + u * 512;
+        if (i < n_items) {
+            float sx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) sx += y1r[u][e];
+            L3.item_a[i] = sx;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = t + u * 512;
+        if (i < n_items) {
+            const int r = i / cpr;
+            float sx = 0.f;
+            for (int q = 0; q < cpr; q++) sx += L3.item_a[r * cpr + q];
+            const float mw = sx / (float)cs;
+            float m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) m2 = fmaf(y1r[u][e] - mw, y1r[u][e] - mw, m2);
+            L3.item_b[i] = m2;
+        }
+    }
+    __syncthreads();
+    float pa = 0.f, pb = 0.f;
+    if (t < n_rows) {
+        for (int q = 0; q < cpr; q++) { pa += L3.item_a[t * cpr + q]; pb += L3.item_b[t * cpr + q]; }
+        pa /= (float)cs;
+    }
+    ln3_exchange(oa.ln_part, oa.sync + kLn3Bank + (b % kSyncSlots), oa.sync + kSyncStatus, b, h, a.heads, n_rows, t, pa, pb, L3.stat);
+    if (t < n_rows) {
+        float mean = 0.f, m2 = 0.f;
+        for (int hh = 0; hh < a.heads; hh++) mean += L3.stat[(t * a.heads + hh) * 2];
+        mean /= (float)a.heads;
+        for (int hh = 0; hh < a.heads; hh++) {
+            const float dm = L3.stat[(t * a.heads + hh) * 2] - mean;
+            m2 += L3.stat[(t * a.heads + hh) * 2 + 1] + (float)cs * dm * dm;
+        }
+        const float rs = rsqrtf(m2 / (float)a.dim + a.eps);
+        L3.fin[2 * t] = mean;
+        L3.fin[2 * t + 1] = rs;
+        if (h == 0) {
+            oa.ln_mean[(long long)b * a.n_q + t] = mean;
+            oa.ln_rstd[(long long)b * a.n_q + t] = rs;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = t + u * 512;
+        if (i < n_items) {
+            const int r = i / cpr, c8 = i - r * cpr;
+            const float mean = L3.fin[2 * r], rs = L3.fin[2 * r + 1];
+            float gv[8], bv[8], xn[8];
+            unpack16(greg[u], gv, bf16());
+            unpack16(breg[u], bv, bf16());
+#pragma unroll
+            for (int e = 0; e < 8; e++) xn[e] = (y1r[u][e] - mean) * rs * gv[e] + bv[e];
+            Vec<bf16>::store(oa.ln_out + ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8, xn);
+        }
+    }
+    FF_XTL(9);
 }
 
 // OUTP: phase 2 - d LN(y) = scale * dQs . Wq for this workgroup's column slice of all 32 rows (dQ is written through and read back).
@@ -1250,20 +1359,98 @@ __global__ __launch_bounds__(512) void xa_dattn_bwd_res_kernel(const XaFusedArgs
     res_barrier();
     FF_XTL(6);
     float* sP = (float*)ring2;
+    const bool ln3 = oa.ln_out != nullptr;                              // phase 3: the backward of LN(y) in this launch too
+    const int cpr = cs / 8, ld = cs + 4, n_items = n_rows * cpr;
+    // phase 3's other operands are requested ahead of the product: the slice of y (the LayerNorm's input), of gamma, of d y1 (the residual the
+    // result is added to) and the rows' saved statistics
+    uint4 xreg[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}}, greg[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}}, rreg[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
+    float mu_r[2] = {0.f, 0.f}, rs_r[2] = {0.f, 0.f};
+    if (ln3) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = t + u * 512;
+            if (i < n_items) {
+                const int r = i / cpr, c8 = i - r * cpr;
+                const long long go = ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8;
+                xreg[u] = *(const uint4*)(oa.ln_x + go);
+                rreg[u] = *(const uint4*)(oa.ln_res + go);
+                greg[u] = *(const uint4*)(oa.ln_g + n0 + c8 * 8);
+                mu_r[u] = oa.ln_mean[(long long)b * a.n_q + r];
+                rs_r[u] = oa.ln_rstd[(long long)b * a.n_q + r];
+            }
+        }
+    }
     FF_RES_PER(per, (res_out_phase<PER, 1>(sA2, ring2, rwq, vo, wq_step, nk2, w, c, g, sP)));
     __syncthreads();
     FF_XTL(7);
-    {
-        const int cpr = cs / 8, ld = cs + 4;
-        for (int i = t; i < n_rows * cpr; i += 512) {
+    float dyh[2][8], xh[2][8];                                          // phase 3: d LN(y) * gamma and x-hat of the workgroup's slice
+    const Ln3Smem L3 = ln3_smem((float*)sB);                            // the operand rows of phase 2 and every tile of phase 1 are dead
+    const int cld = cs + 1;                                             // row pitch of the two column images (d gamma, d beta terms)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = t + u * 512;
+        if (i < n_items) {
             const int r = i / cpr, c8 = i - r * cpr;
             const float* src = sP + r * ld + c8 * 8;
             const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
             float ov[8] = {a0[0] * a.scale, a0[1] * a.scale, a0[2] * a.scale, a0[3] * a.scale, a1[0] * a.scale, a1[1] * a.scale, a1[2] * a.scale, a1[3] * a.scale};
-            Vec<bf16>::store(oa.out + ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8, ov);
+            if (oa.out) Vec<bf16>::store(oa.out + ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8, ov);
+            if (ln3) {
+                float xv[8], gv[8], s1 = 0.f, s2 = 0.f;
+                unpack16(xreg[u], xv, bf16());
+                unpack16(greg[u], gv, bf16());
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float dr = (float)(bf16)ov[e];                // d LN(y) as the separate launch stored it
+                    xh[u][e] = (xv[e] - mu_r[u]) * rs_r[u];
+                    dyh[u][e] = dr * gv[e];
+                    s1 += dyh[u][e];
+                    s2 = fmaf(dyh[u][e], xh[u][e], s2);
+                    L3.cols[r * cld + c8 * 8 + e] = dr * xh[u][e];                       // d gamma term
+                    L3.cols[(kResBM + r) * cld + c8 * 8 + e] = dr;                       // d beta term
+                }
+                L3.item_a[i] = s1;
+                L3.item_b[i] = s2;
+            }
         }
     }
     FF_XTL(8);
+    if (!ln3) return;
+
+    // ---- phase 3: d y = rstd * (dyh - mean(dyh) - xh * mean(dyh * xh)) + d y1 for the same slice; the row means need every head's sums ----
+    __syncthreads();
+    float pa = 0.f, pb = 0.f;
+    if (t < n_rows)
+        for (int q = 0; q < cpr; q++) { pa += L3.item_a[t * cpr + q]; pb += L3.item_b[t * cpr + q]; }
+    if (t < cs) {                                                       // the sample's column sums of this slice: d gamma | d beta partials
+        float sg = 0.f, sb2 = 0.f;
+        for (int r = 0; r < n_rows; r++) { sg += L3.cols[r * cld + t]; sb2 += L3.cols[(kResBM + r) * cld + t]; }
+        float* wp = oa.ln_wpart + (long long)b * (2 * a.dim + 2);
+        wp[n0 + t] = sg;
+        wp[a.dim + n0 + t] = sb2;
+    }
+    ln3_exchange(oa.ln_part, oa.sync + kLn3Bank + kSyncSlots + (b % kSyncSlots), oa.sync + kSyncStatus, b, h, a.heads, n_rows, t, pa, pb, L3.stat);
+    if (t < n_rows) {
+        float m1 = 0.f, m2 = 0.f;
+        for (int hh = 0; hh < a.heads; hh++) { m1 += L3.stat[(t * a.heads + hh) * 2]; m2 += L3.stat[(t * a.heads + hh) * 2 + 1]; }
+        L3.fin[2 * t] = m1 / (float)a.dim;
+        L3.fin[2 * t + 1] = m2 / (float)a.dim;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = t + u * 512;
+        if (i < n_items) {
+            const int r = i / cpr, c8 = i - r * cpr;
+            const float m1 = L3.fin[2 * r], m2 = L3.fin[2 * r + 1];
+            float rv[8], dx[8];
+            unpack16(rreg[u], rv, bf16());
+#pragma unroll
+            for (int e = 0; e < 8; e++) dx[e] = rs_r[u] * (dyh[u][e] - m1 - xh[u][e] * m2) + rv[e];
+            Vec<bf16>::store(oa.ln_out + ((long long)b * a.n_q + r) * a.dim + n0 + c8 * 8, dx);
+        }
+    }
+    FF_XTL(9);
 }
 
 // =====================================================================================================
@@ -1361,6 +1548,7 @@ static int launch_bwd_res(const XaFusedArgs& a, const void* dy1, const void* Wo,
 // Phase 2 needs the resident kernels in BOTH directions (a block that fused to_out forward must find d LN(y) fused backward), eight heads
 // of 64 (the contraction is 8 k-steps, the operand of all heads 32 KiB), a head's column slice dim / 8 that is a whole number of 32-column
 // groups, and one counter per sample.
+size_t xa_ln3_part_bytes(int batch, int heads) { return (size_t)batch * heads * 32 * 2 * sizeof(float); }
 bool xa_out_fusable(const XaFusedArgs& a, int dtype, int dim_head) {
     static const int on = dbg_switch("FF_XATTN_OUTFUSE", 1);
     if (!on || a.heads != 8 || a.inner != 8 * kResDH || a.dim % 256 != 0 || a.dim / 8 > 32 * kOutMaxPer || a.batch > kSyncSlots) return false;
@@ -1373,6 +1561,8 @@ int xa_qattn_fwd(const XaFusedArgs& a, int dtype, int dim_head, const void* y, c
     FF_CHECK(y && gamma && beta && Wq && K && V && tt && Qs && O && mean && rstd && lse, FF_ERR_SHAPE, "xa_qattn_fwd: null argument");
     FF_CHECK(!out || (xa_out_fusable(a, dtype, dim_head) && out->W && out->gate && out->out && out->aux && out->sync), FF_ERR_SHAPE,
              "xa_qattn_fwd: phase 2 (to_out inside the launch) asked for a problem that does not take it, or with a null argument");
+    FF_CHECK(!out || !out->ln_out || (out->ln_g && out->ln_b && out->ln_mean && out->ln_rstd && out->ln_part), FF_ERR_SHAPE,
+             "xa_qattn_fwd: phase 3 (LayerNorm of the feed-forward inside the launch) with a null argument");
     const int pid = profile_begin(dtype, out ? -6 : -4, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
     int rc;
     const int nsb = res_ring_depth(a, dtype, dim_head, false);
@@ -1405,8 +1595,10 @@ int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1,
                  int* single_tile, hipStream_t st, const XaOutArgs* out) {
     FF_CHECK(xa_fused_supported(dtype, dim_head, a.dim, a.inner), FF_ERR_UNSUPPORTED, "xa_dattn_bwd: unsupported dtype / head size");
     FF_CHECK(dy1 && Wo && gate && Qs && K && V && tt && O && lse && dQ && dK && dV && Dsum && single_tile, FF_ERR_SHAPE, "xa_dattn_bwd: null argument");
-    FF_CHECK(!out || (xa_out_fusable(a, dtype, dim_head) && out->W && out->out && out->sync), FF_ERR_SHAPE,
+    FF_CHECK(!out || (xa_out_fusable(a, dtype, dim_head) && out->W && (out->out || out->ln_out) && out->sync), FF_ERR_SHAPE,
              "xa_dattn_bwd: phase 2 (d LN(y) inside the launch) asked for a problem that does not take it, or with a null argument");
+    FF_CHECK(!out || !out->ln_out || (out->ln_g && out->ln_x && out->ln_res && out->ln_mean && out->ln_rstd && out->ln_part && out->ln_wpart), FF_ERR_SHAPE,
+             "xa_dattn_bwd: phase 3 (LayerNorm backward inside the launch) with a null argument");
     const bool single = a.n_q <= 64;
     FF_CHECK(single || dO, FF_ERR_SHAPE, "xa_dattn_bwd: dO buffer needed when the queries span several tiles");
     *single_tile = single ? 1 : 0;

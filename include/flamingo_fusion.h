@@ -287,7 +287,7 @@ typedef struct ff_xattn_desc {
     ff_strides cached_k, cached_v; /* used only when cached_k != NULL */
     void* sync;                    /* see above; NULL = none */
 } ff_xattn_desc;
-size_t ff_xattn_sync_bytes(void);              /* (2 * FF_XATTN_SYNC_SLOTS + 64) * 4 */
+size_t ff_xattn_sync_bytes(void);              /* (4 * FF_XATTN_SYNC_SLOTS + 64) * 4: two banks of per-sample counters each way + a status word */
 int ff_xattn_sync_status(const void* sync, ff_stream_t stream);   /* synchronises `stream`; 0 = no wait ever timed out, 1 = one did, < 0 = error */
 size_t ff_xattn_saved_bytes(const ff_xattn_desc* d);
 size_t ff_xattn_scratch_bytes(const ff_xattn_desc* d);

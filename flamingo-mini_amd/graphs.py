@@ -56,6 +56,18 @@ def _refuse_live_autograd_graphs(model: torch.nn.Module) -> None:
             "their gradient-accumulation nodes are bound to the stream of that forward and cannot take part in a stream capture.")
 
 
+def _let_the_watchdog_drain() -> None:
+    """Called between the eager warm-up steps (already synchronised) and a stream capture.  ProcessGroupNCCL's watchdog thread keeps every collective
+    of the warm-up in a list and polls its events (hipEventQuery) every ~100 ms until it has seen them complete; on ROCm such a query from that
+    thread while THIS thread captures has aborted the process now and then even in "thread_local" capture mode (round 5: the whole-step-capture row
+    of the round-end session, and one run of the piecewise capture test, died that way - no Python frame, no message).  Two of its periods later
+    the list is empty and nothing queries anything during the capture."""
+    import time
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        time.sleep(0.3)
+
+
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
                  warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None):
@@ -79,6 +91,7 @@ class GraphedTrainStep:
         # aborts the process (seen once in ~10 runs of the 1-rank RCCL test).  "thread_local" restricts the check to this thread's own calls.
         import torch.distributed as dist
         mode = "thread_local" if reducer is not None or (dist.is_available() and dist.is_initialized()) else "global"
+        _let_the_watchdog_drain()
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = self._eager().detach()
         torch.cuda.synchronize()
@@ -282,6 +295,7 @@ class PiecewiseGraphedTrainStep:
         arena_sizes = self._size_arenas() if self.segment_arena else None
         import torch.distributed as dist
         mode = "thread_local" if reducer is not None or (dist.is_available() and dist.is_initialized()) else "global"
+        _let_the_watchdog_drain()
         pool = torch.cuda.graph_pool_handle()
 
         def piece(fn):

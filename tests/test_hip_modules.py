@@ -286,7 +286,9 @@ def test_in_launch_exchange_equals_separate_launches_and_oracle(b, L, nv, dim):
     (2) a hand-off must not read stale lines, whatever else the chip is doing and however warm the consumer's caches are: the same call, again
         and again, next to a stream of unrelated matmuls that take CUs away from the launch, gives the SAME BITS every time (MI355X guide:
         test every hand-off under uneven load, checking every word);
-    (3) no arrival wait ever timed out (the buffer's status word)."""
+    (3) no arrival wait ever timed out (the buffer's status word);
+    (4) other contents in the same buffers give the other results (no line of the previous call is served again).
+    Since phase 3 (the LayerNorm behind phase 2's output in the same launch, a second bank of counters) the same four points cover it too."""
     from flamingo_mini_amd import functional as F
     dtype = torch.bfloat16
     dv, heads, dh, ffm = 256, 8, 64, 2
@@ -342,6 +344,23 @@ def test_in_launch_exchange_equals_separate_launches_and_oracle(b, L, nv, dim):
         again = run()
         for k, x_, y_ in zip(names, again, fused):
             assert torch.equal(x_, y_), (i, k)
+    assert F.sync_exchange_status() == 0
+    # (4) the same buffers again with OTHER contents: a consumer that was served a line of the previous call by a cache (its own L1, or - when a
+    #     sample's heads sit on different XCDs: the odd batch sizes here - a private L2 that still holds what it read last time) would reproduce
+    #     the OLD results, which repeating identical inputs cannot notice
+    with torch.no_grad():
+        yd.mul_(-0.75).add_(0.125)
+        dyd.mul_(1.5)
+    moved = run()
+    assert rel(moved[0], fused[0]) > 0.1 and rel(moved[1], fused[1]) > 0.1          # the inputs really changed the results
+    try:
+        F.use_sync_exchange = False
+        separate2 = run()
+    finally:
+        F.use_sync_exchange = True
+    for k, a_, b_ in zip(names, moved, separate2):
+        if a_.numel() > 1:
+            assert rel(a_, b_) < 3e-3, k
     assert F.sync_exchange_status() == 0
     torch.cuda.synchronize()
 

@@ -23,19 +23,7 @@ cd $R
 timeout 400 python tools/gemm_yardstick.py $out/gemm_table.txt > $out/gemm_yardstick.txt 2> $out/gemm_yardstick.err; head -5 $out/gemm_yardstick.txt
 ( python tools/decode_chain_bench.py 2>&1 | tail -1; for v in "FF_DECODE_FFW=0" "FF_DECODE_FFW=1"; do ( export FLAMINGO_FUSION_LIB=debug $v; echo "[development build, $v] $(python tools/decode_chain_bench.py 2>&1 | tail -1)" ); done ) > $out/decode_chain.txt
 cat $out/decode_chain.txt
-B2="python bench.py --no-cpu-baseline --caption-tokens 0 --profile-steps 0 --companions off --steps 12 --warmup 3"
-( for g in on piecewise "piecewise --pace stream --overlap-optimizer off" off; do timeout 300 $B2 --graph $g --force-collectives --bucket-timeline 2> /dev/null | python -c "
-import sys, json
-d = next(json.loads(l) for l in reversed(sys.stdin.read().strip().splitlines()) if l.startswith('{'))
-bt = d.get('bucket_timeline') or {}
-print('graph=$g, gradient exchange through a 1-rank RCCL group:', d['value'], 'images/s', d['ms_per_step'], 'ms/step, mode', d['config']['graph_mode'], 'pace', d['config'].get('collective_pace'), 'overlapped optimizer', d['config'].get('overlapped_optimizer'), '| eager timeline step: backward', bt.get('backward_ms'), 'ms, exchange finished', bt.get('exchange_finished_ms'), 'ms, exposed', bt.get('exposed_communication_ms'), 'ms,', len(bt.get('buckets', [])), 'buckets')
-if '$g' == 'off':
-    for r in bt.get('buckets', []): print('   ', r)
-"; done
-  timeout 300 $B2 --graph on 2> /dev/null | python -c "
-import sys, json
-d = next(json.loads(l) for l in reversed(sys.stdin.read().strip().splitlines()) if l.startswith('{'))
-print('graph=on, no collectives (the single-GPU default):', d['value'], 'images/s', d['ms_per_step'], 'ms/step')" ) > $out/launch_modes_one_rank_rccl.txt
+bash tools/sessions/r5/gpu_r5_s15.sh $tag > $out/launch_modes.log 2>&1      # the launch-mode table (stderr of every run kept, a run without a JSON line is named)
 head -4 $out/launch_modes_one_rank_rccl.txt
 # round 5: the other configurations of BASELINE.json (stock backbones, 6 timed steps), config E with its per-shape GEMM table and hipBLASLt beside every one of its shapes
 for c in A C D; do timeout 400 python bench.py --config $c --no-cpu-baseline --caption-tokens 0 --companions off --steps 6 --warmup 2 2> $out/bench_config_$c.err | tail -1 > $out/bench_config_$c.json; done

@@ -181,7 +181,7 @@ def gemm_profile_summary(lib, ffi, max_records):
     groups, shapes, attn = {}, {}, {}
     for i in range(n):
         r = recs[i]
-        if r.tile in (-4, -5, -6, -7):   # fused LayerNorm + projection + attention of a cross-attention block (forward / backward): every operand once
+        if r.tile in (-4, -5, -6, -7, -8, -9):   # fused LayerNorm + projection + attention of a cross-attention block (forward / backward): every operand once
             es = 2 if r.dtype == ffi.DTYPE_BF16 else 4
             heads, dh = r.a_layout, r.split_k
             batch, inner = r.nz // heads, heads * dh
@@ -191,9 +191,14 @@ def gemm_profile_summary(lib, ffi, max_records):
             nbytes = {-4: 2 * rows_d + w_b + 2 * kv_i + 2 * rows_i,            # y, yn | Wq | K, V | Qs, O
                       -5: rows_d + w_b + 3 * rows_i + 4 * kv_i,                # dy1 | Wo | Qs, O, dQ | K, V, dK, dV
                       -6: 4 * rows_d + 2 * w_b + 2 * kv_i + 3 * rows_i,        # y, yn, y1, to_out(o) | Wq, Wo | K, V | Qs, O, O again
-                      -7: 2 * rows_d + 2 * w_b + 4 * rows_i + 4 * kv_i}[r.tile]    # dy1, d LN(y) | Wo, Wq | Qs, O, dQ, dQ again | K, V, dK, dV
-            a = attn.setdefault({-4: "xattn_fused_fwd", -5: "xattn_fused_bwd", -6: "xattn_fused_fwd", -7: "xattn_fused_bwd"}[r.tile], dict(ms=0.0, bytes=0.0, launches=0))
-            a["with_out_projection"] = r.tile in (-6, -7)
+                      -7: 2 * rows_d + 2 * w_b + 4 * rows_i + 4 * kv_i,        # dy1, d LN(y) | Wo, Wq | Qs, O, dQ, dQ again | K, V, dK, dV
+                      # -8 / -9 (late in round 5): ... and the LayerNorm behind that output inside as well: LN(y1) written next to y1; d LN(y) never
+                      # stored, y and d y1 read for the LayerNorm backward, d y written
+                      -8: 5 * rows_d + 2 * w_b + 2 * kv_i + 3 * rows_i,
+                      -9: 4 * rows_d + 2 * w_b + 4 * rows_i + 4 * kv_i}[r.tile]    # dy1, y, dy1 again, d y | ...
+            a = attn.setdefault("xattn_fused_fwd" if r.tile in (-4, -6, -8) else "xattn_fused_bwd", dict(ms=0.0, bytes=0.0, launches=0))
+            a["with_out_projection"] = r.tile in (-6, -7, -8, -9)
+            a["with_layernorm"] = r.tile in (-8, -9)
             a["ms"] += r.ms; a["bytes"] += nbytes; a["launches"] += 1
             continue
         if r.tile < 0:      # attention core: algorithmic HBM bytes = each of Q, K, V, O (and their gradients) touched once
@@ -780,7 +785,7 @@ def main():
                 k: {"bound": "hbm", "achieved": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 4), "launches": v["launches"],
                     "avg_launch_us": round(v["ms"] / v["launches"] * 1e3, 2), "avg_launch_mb": round(v["bytes"] / v["launches"] / 1e6, 2),
-                    **({"with_out_projection": True} if v.get("with_out_projection") else {})}
+                    **({"with_out_projection": True} if v.get("with_out_projection") else {}), **({"with_layernorm": True} if v.get("with_layernorm") else {})}
                 for k, v in attn.items()}
         if bucket_timeline is not None:
             result["bucket_timeline"] = bucket_timeline

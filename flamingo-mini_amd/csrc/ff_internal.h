@@ -69,7 +69,8 @@ struct Gemm {
 
 // launch timing hooks (ff_gemm_profile_*): tile < 0 marks the attention kernels (-1 fwd, -2 dQ, -3 dK/dV; M = n_q, N = n_kv,
 // K = dim_head, nz = batch * heads, split_k = mode) and the fused projection + attention kernels of the cross-attention block
-// (-4 forward, -5 backward; M = n_q, N = n_kv, K = model dim, nz = batch * heads, a_layout = heads, split_k = dim_head)
+// (-4 forward, -5 backward; M = n_q, N = n_kv, K = model dim, nz = batch * heads, a_layout = heads, split_k = dim_head; -6 / -7: the same launches with
+// phase 2 - to_out + gate + residual resp. d LN(y) - inside; -8 / -9: with phase 3 - the LayerNorm behind that output - inside as well)
 int profile_begin(int dtype, int tile, int a_layout, int b_layout, int M, int N, int K, int nz, int split_k, hipStream_t st);
 void profile_end(int i, hipStream_t st);
 

@@ -1566,7 +1566,7 @@ int xa_qattn_fwd(const XaFusedArgs& a, int dtype, int dim_head, const void* y, c
              "xa_qattn_fwd: phase 2 (to_out inside the launch) asked for a problem that does not take it, or with a null argument");
     FF_CHECK(!out || !out->ln_out || (out->ln_g && out->ln_b && out->ln_mean && out->ln_rstd && out->ln_part), FF_ERR_SHAPE,
              "xa_qattn_fwd: phase 3 (LayerNorm of the feed-forward inside the launch) with a null argument");
-    const int pid = profile_begin(dtype, out ? -6 : -4, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
+    const int pid = profile_begin(dtype, out ? (out->ln_out ? -8 : -6) : -4, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
     int rc;
     const int nsb = res_ring_depth(a, dtype, dim_head, false);
     const XaOutArgs none = {};
@@ -1605,7 +1605,7 @@ int xa_dattn_bwd(const XaFusedArgs& a, int dtype, int dim_head, const void* dy1,
     const bool single = a.n_q <= 64;
     FF_CHECK(single || dO, FF_ERR_SHAPE, "xa_dattn_bwd: dO buffer needed when the queries span several tiles");
     *single_tile = single ? 1 : 0;
-    const int pid = profile_begin(dtype, out ? -7 : -5, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
+    const int pid = profile_begin(dtype, out ? (out->ln_out ? -9 : -7) : -5, a.heads, 0, a.n_q, a.n_kv, a.dim, a.batch * a.heads, dim_head, st);
     int rc;
     const int nsb = res_ring_depth(a, dtype, dim_head, true);
     const XaOutArgs none = {};

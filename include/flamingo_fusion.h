@@ -272,10 +272,13 @@ int ff_resampler_prologue_bwd(const ff_resampler_desc* d, const void* dx0, const
  * tokens and 64 keys per sample, dim a multiple of 256 up to 1536, batch <= FF_XATTN_SYNC_SLOTS), `to_out` + tanh gate + residual
  * (gated_cross_attention.py:124-126,180) run INSIDE the fused LayerNorm -> to_q -> attention launch, and d LN(y) = d q . Wq inside the fused
  * attention-backward launch: the eight (sample, head) workgroups of a sample exchange their tiles through per-sample arrival counters in
- * `sync` instead of through a kernel boundary (two 64 x 64-tile GEMM launches per block and step less).  Calls that share a `sync`
- * buffer must be ordered on one stream (the counters are per sample, not per call); NULL keeps the separate launches.  Results are the
- * same either way up to the rounding of one fp32 sum order; the buffer's last word is an error flag (non-zero: an arrival wait timed
- * out - a launch was denied co-residency of a sample's eight workgroups - and that call's output is invalid).
+ * `sync` instead of through a kernel boundary (two 64 x 64-tile GEMM launches per block and step less).  At the training shape the
+ * LayerNorm behind each of those outputs runs in the same launch as well - forward: LN(y1) of the feed-forward (utils.py:46); backward: the
+ * LayerNorm backward of LN(y) - with the rows' statistics making one more trip through a second bank of counters (two more launches per block
+ * and step less).  Calls that share a `sync` buffer must be ordered on one stream (the counters are per sample, not per call); NULL keeps the
+ * separate launches.  Results are the same either way up to the rounding of fp32 sums taken in another order; the word behind the first two
+ * banks is an error flag (ff_xattn_sync_status; non-zero: an arrival wait timed out - a launch was denied co-residency of a sample's eight
+ * workgroups - and that call's output is invalid).
  * ------------------------------------------------------------------------------------------------------ */
 #define FF_XATTN_PARAMS 11
 #define FF_XATTN_SYNC_SLOTS 1024

@@ -143,6 +143,60 @@ def parse():
     return args
 
 
+def hot_path_flops(args, dim, dim_visual, clip_tokens, n_blocks) -> float:
+    """ALGORITHMIC fwd+bwd FLOPs of the fusion path per step and GPU, SURVEY.md section 8 row d3 (FLOP = 2 MAC, GEMM + attention contractions
+    only, fwd+bwd = 3 x fwd; the flamingo defaults: 64 latents, 8 heads of 64, ff_mult 4, resampler depth 6): 1591.7 GF fwd = 4.78 TF at config B."""
+    q, h, dh, inner, depth, ffm = 64, 8, 64, 512, 6, 4
+    T = max(args.frames, 1)
+    f = T * clip_tokens
+    dv, d, L, N = dim_visual, dim, args.seq_len, args.images
+    rs = depth * (2 * q * dv * inner + 4 * (f + q) * dv * inner + 4 * h * q * (f + q) * dh + 2 * q * inner * dv + 4 * q * dv * (ffm * dv))
+    xa = 2 * L * d * inner + 4 * (N * q) * dv * inner + 4 * h * L * (N * q) * dh + 2 * L * inner * d + 4 * L * d * (ffm * d)
+    return 3.0 * (args.batch * N * rs + args.batch * n_blocks * xa)
+
+
+TOLERANCE = ("bf16 kernels: 8e-3 (outputs) / 1.2e-2 (gradients) rel-L2 per module vs the fp64 oracle, 1.5e-2 / 2.5e-2 whole model "
+             "(tests/util.py; the reference's own bf16-vs-fp32 drift is 6.6e-3); fp32 kernels: logits <= 1e-4 rel of the reference "
+             "(north star: 1e-3), tests/test_model_plumbing.py")
+
+
+def _tile_name(code: int) -> str:
+    return {128160: "128x160", 128002: "128x128 (producer/consumer)", 64002: "64x64 (producer/consumer)", 256128: "256x128", 256256: "256x256",
+            3264: "32x64 (decode rows)", 3216: "32 rows x 16 columns (decode rows, weight-streaming)", 6412: "64x128"}.get(code, f"{code}x{code}" if code < 1000 else str(code))
+
+
+def hot_path_summary(args, cfg, model, gemm_flops_step, gemm_ms_step, attn, prof_steps):
+    """The whole fusion path against the MFMA peak: ALGORITHMIC flops per step over the library's GPU time per step.  The library
+    time of a step is a rocprofv3 figure (every kernel of the library, incl. LayerNorm / reductions / AdamW / loss, which the in-process HIP-event
+    log does not bracket): it is read from the latest committed summary of the same command and tagged with its source; what this run measures
+    itself - the event-bracketed GEMM and attention launches - is reported next to it."""
+    import glob, re
+    fl = model.flamingo
+    n_blocks = len(fl.get_modified_layers())
+    from flamingo_mini_amd.backbones import CLIP_VISION
+    patch, image = CLIP_VISION[args.clip][4:6]
+    clip_tokens = (image // patch) ** 2 + 1                 # 257 for ViT-L/14 at 224, 50 for ViT-B/32
+    flops = hot_path_flops(args, cfg.dim, cfg.dim_visual, clip_tokens, n_blocks)
+    attn_ms = sum(v["ms"] for v in attn.values()) / max(prof_steps, 1)
+    out = {"algorithmic_flops_per_step": flops, "event_bracketed_gemm_and_attention_ms": round(gemm_ms_step + attn_ms, 3),
+           "frac_of_mfma_peak_over_event_bracketed_ms": round(flops / ((gemm_ms_step + attn_ms) * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+           "library_ms": None, "frac": None, "library_ms_source": "no profiles/r*_bench_b32_bf16_summary.md in the tree"}
+    if args.config == "B":
+        try:
+            path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b32_bf16_summary.md")))[-1]
+            m = re.search(r"fusion library total: \*\*([0-9.]+) ms/step", open(path).read())
+            if m:
+                lib_ms = float(m.group(1))
+                out.update(library_ms=lib_ms, frac=round(flops / (lib_ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                           library_ms_source=f"{os.path.relpath(path, ROOT)}: rocprofv3 --kernel-trace --stats of this command, all kernels of the fusion "
+                                             "library incl. LayerNorm / reductions / AdamW / loss; not collected by this run")
+        except Exception as e:
+            out["library_ms_source"] = f"unreadable summary: {e!r}"[:160]
+    else:
+        out["library_ms_source"] = "rocprofv3 summaries are committed for config B only"
+    return out
+
+
 def build_model(args, device, dtype):
     from flamingo_mini_amd import FlamingoConfig, FlamingoModel
     from flamingo_mini_amd.backbones import CLIP_VISION, GPT2, OPT
@@ -178,7 +232,7 @@ def gemm_profile_summary(lib, ffi, max_records):
     recs = (ffi.GemmProfileRecord * max_records)()
     n = lib.ff_gemm_profile_read(recs, max_records)
     lib.ff_gemm_profile_enable(0)
-    groups, shapes, attn = {}, {}, {}
+    groups, shapes, attn, families = {}, {}, {}, {}
     for i in range(n):
         r = recs[i]
         if r.tile in (-4, -5, -6, -7, -8, -9):   # fused LayerNorm + projection + attention of a cross-attention block (forward / backward): every operand once
@@ -209,11 +263,12 @@ def gemm_profile_summary(lib, ffi, max_records):
             a["ms"] += r.ms; a["bytes"] += nbytes; a["launches"] += 1
             continue
         key = (r.dtype, r.tile, r.a_layout, r.b_layout)
-        for table, k in ((groups, key), (shapes, (r.M, r.N, r.K, r.nz, r.a_layout, r.b_layout, r.tile, r.split_k))):
+        for table, k in ((groups, key), (shapes, (r.M, r.N, r.K, r.nz, r.a_layout, r.b_layout, r.tile, r.split_k)), (families, (r.dtype, r.tile))):
             g = table.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
             g["ms"] += r.ms
             g["flops"] += 2.0 * r.M * r.N * r.K * r.nz
             g["launches"] += 1
+    attn["_families"] = families
     return groups, shapes, attn
 
 
@@ -633,6 +688,10 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # the error word of the fused cross-attention kernels' in-launch hand-offs (a timed-out arrival wait = a launch computed on garbage): read
+    # after the timed region and again after the instrumented steps; a non-zero word is printed in `config` and fails the run
+    from flamingo_mini_amd import functional as _Fs
+    sync_timeouts = int(_Fs.sync_exchange_status()) if getattr(_Fs, "_sync_buffers", None) else 0
     piecewise_host = None
     if graph_mode == "piecewise" and hasattr(step, "host_timing"):      # host seconds by kind of call over 5 more steps (launch-bound or not, and by what)
         step.host_timing = {}
@@ -692,11 +751,17 @@ def main():
             loss = eager_step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t1) / prof_steps * 1e3
+    sync_timeouts |= int(_Fs.sync_exchange_status()) if getattr(_Fs, "_sync_buffers", None) else 0
+    if world > 1:
+        flag = torch.tensor([sync_timeouts], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        sync_timeouts = int(flag.item())
     loss_val = float(loss.float().item())
     loss_first_val, loss_last_val = float(loss_first.float().item()), float(loss_last.float().item())
 
     if rank == 0:
         groups, shapes, attn = gemm_profile_summary(lib, ffi, max_rec) if prof_steps else ({}, {}, {})
+        families = attn.pop("_families", {})
         if args.gemm_table:
             with open(args.gemm_table, "w") as f:
                 f.write("M N K nz aL bL tile splitK launches/step us/launch TF/s ms/step\n")
@@ -707,7 +772,12 @@ def main():
         images = args.batch * args.images * world * args.steps        # a video clip counts as one image (its frames share one set of 64 latents)
         roofline = None
         if groups:
-            key, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+            # The dominant kernel is chosen by tile FAMILY (all launches of one tile, whatever the operand layouts), not by (tile, layouts):
+            # grouping by layout split the 128 x 160 feed-forward family four ways and made the weight-gradient instantiation - the
+            # best-performing GEMM of the step - "dominant" (VERDICT r05).  Within the dominant family the layout group with the most time is
+            # the kernel the line's achieved / peak / frac / traffic describe; `family` and `hot_path` put the honest totals next to it.
+            fam_key, fam = max(families.items(), key=lambda kv: kv[1]["ms"])
+            key, g = max(((k, v) for k, v in groups.items() if (k[0], k[1]) == fam_key), key=lambda kv: kv[1]["ms"])
             is_bf16 = key[0] == ffi.DTYPE_BF16
             peak = MFMA_BF16_DENSE_PEAK_TFLOPS if is_bf16 else MFMA_F32_PEAK_TFLOPS
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
@@ -750,6 +820,15 @@ def main():
                         "traffic": traffic, "traffic_source": traffic_source, "kernel": name, "launches": g["launches"],
                         "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
                         "avg_launch_gflop": round(g["flops"] / g["launches"] / 1e9, 3),
+                        "family": {"tile": _tile_name(fam_key[1]), "tflops": round(fam["flops"] / (fam["ms"] * 1e-3) / 1e12, 2),
+                                   "frac": round(fam["flops"] / (fam["ms"] * 1e-3) / 1e12 / peak, 4), "launches_per_step": round(fam["launches"] / prof_steps, 1),
+                                   "ms_per_step": round(fam["ms"] / prof_steps, 3)},
+                        "by_family": [{"tile": _tile_name(k[1]), "dtype": "bf16" if k[0] == ffi.DTYPE_BF16 else "f32",
+                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                       "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / (MFMA_BF16_DENSE_PEAK_TFLOPS if k[0] == ffi.DTYPE_BF16 else MFMA_F32_PEAK_TFLOPS), 4),
+                                       "launches_per_step": round(v["launches"] / prof_steps, 1), "ms_per_step": round(v["ms"] / prof_steps, 3)}
+                                      for k, v in sorted(families.items(), key=lambda kv: -kv[1]["ms"])],
+                        "hot_path": hot_path_summary(args, cfg, model, tot_fl / prof_steps, tot_ms / prof_steps, attn, prof_steps),
                         "all_fusion_gemms": {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                              "ms_per_step": round(tot_ms / prof_steps, 3),
                                              "share_of_step": round(tot_ms / prof_steps / ms_per_step, 3)},
@@ -759,7 +838,7 @@ def main():
             "metric": "images/sec (fwd+bwd) flamingo-mini bs=32" if args.config == "B" else f"images/sec (fwd+bwd) config {args.config} bs={args.batch}",
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "tolerance": TOLERANCE, "data": "synthetic",
             "config": {"name": args.config,
                        "workload": f"{args.what}; {args.lm} + {args.clip}, {args.images} image(s)" + (f" x {args.frames} frames" if args.frames else "")
                                    + f" + {args.seq_len} tokens per sequence, xattn_every {args.xattn_every}, "
@@ -776,7 +855,7 @@ def main():
                        "loss_first": round(loss_first_val, 4), "loss_last": round(loss_last_val, 4), "loss": round(loss_val, 4),
                        "optimizer_steps_before_timed_region": args.warmup + (max(args.warmup, 1) if use_graph else 0),
                        "optimizer": "none" if args.no_optimizer else args.optimizer, "hip_graph": use_graph, "graph_mode": graph_mode, "collectives": bool(collectives), "rccl_channels": (args.rccl_channels or None), "segment_layers": (args.segment_layers if graph_mode == "piecewise" else None), **({"rehearsal": "all ranks share ONE GPU, gloo exchange: the value is not a measurement"} if args.shared_gpu_rehearsal else {}), "collective_pace": (args.pace if graph_mode == "piecewise" and collectives else None), "overlapped_optimizer": bool(graph_mode == "piecewise" and use_graph and overlap_opt), "host_issue_ms_per_step": round(host_issue_ms, 3), "piecewise_host_ms_per_step": piecewise_host,
-                       "hoisted_kv": bool(model.flamingo.hoist_kv), "sync_exchange": args.sync_exchange == "on", "resampler_layerwise": bool(model.flamingo.resampler.layerwise), "stock_gemm_tuning_file": stock_tuned,
+                       "hoisted_kv": bool(model.flamingo.hoist_kv), "sync_exchange": args.sync_exchange == "on", "sync_exchange_timeouts": sync_timeouts, "resampler_layerwise": bool(model.flamingo.resampler.layerwise), "stock_gemm_tuning_file": stock_tuned,
                        "backbone_tweaks": args.backbone_tweaks == "on"},
             "roofline": roofline,
         }
@@ -817,6 +896,10 @@ def main():
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if sync_timeouts:
+        print("bench.py: an in-launch hand-off of the fused cross-attention kernels timed out (config.sync_exchange_timeouts = 1): the run's "
+              "numbers are invalid", file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -12,6 +12,7 @@
 // bf16: operand tiles through the LDS-DMA ring of the GEMM family (ff_gemm_tiles.h), v_mfma_f32_16x16x32_bf16; each wave owns 16
 // rows of the tile for the projection AND the attention, so Q / d O reach the attention MFMAs through a 9 KiB LDS tile.
 // fp32 (verification precision): the projection reads its operands straight from global memory (v_mfma_f32_16x16x4_f32).
+#include <atomic>
 #include "ff_common.h"
 #include "ff_internal.h"
 #include "ff_gemm_tiles.h"
@@ -723,9 +724,17 @@ FF_DEV void res_work_item(const XaFusedArgs& a, int& h, int& b) {
 // activation rows were, its first three tiles requested while the attention is still running.
 // The counters are caller-owned (ff_xattn_desc.sync), zero when first handed over and never reset: every launch adds exactly `heads` to
 // each sample's counter, a workgroup's ticket tells it which multiple of `heads` to wait for, and the comparison is wrap-safe.
-// Co-residency: one workgroup per CU and `heads` consecutive workgroups per sample; workgroups are dispatched in order, so a sample's
-// group is never waiting for a workgroup that sits behind a group that cannot finish.  A bounded spin turns a violated assumption into
-// an error word (sync[kSyncStatus]) and garbage the parity tests catch, not into a hung GPU.
+// Co-residency.  A waiting workgroup holds its CU (one workgroup per CU: the LDS), so a sample's `heads` workgroups must all get a CU while
+// the first of them waits.  Workgroup b is dispatched to XCD b % 8 and every XCD dispatches its own workgroups in blockIdx order; res_work_item
+// (through xcd_remap) gives XCD x the work items [x * chunk, (x + 1) * chunk) in that order, head fastest - so an XCD works through its samples
+// one after the other, the oldest unfinished sample's remaining heads are always the next workgroups that XCD dispatches, and the launch makes
+// progress whenever EVERY XCD can hold `heads` (8) of these workgroups at a time.  (blockIdx-wise a sample's workgroups are b, b + 8, ...,
+// b + 56: on a device whose dispatcher did NOT spread consecutive workgroups over 8 XCDs - a partitioned (CPX) device, one XCD - the first 32
+// resident workgroups would be heads 0..3 of eight samples and nothing would ever complete.)  The host therefore takes this path only on a
+// device that reports 8 XCDs with at least kMinCusPerXcd CUs each (xa_exchange_device_ok); what it cannot see - a CU mask on the stream, another
+// process's persistent kernels holding most of an XCD - is caught by the bounded spin below: a violated assumption becomes an error word
+// (sync[kSyncStatus], ff_xattn_sync_status) that the Python layer checks after warm-up steps, every N graph replays, at every eager optimizer
+// step and at the end of bench.py, not a hung GPU and not silence.
 constexpr int kSyncSlots = FF_XATTN_SYNC_SLOTS;         // samples per counter bank: forward bank, backward bank, status word
 constexpr int kSyncStatus = 2 * kSyncSlots;
 constexpr int kOutNS = 4;                               // ring depth of the phase-2 weight stream
@@ -1552,9 +1561,27 @@ static int launch_bwd_res(const XaFusedArgs& a, const void* dy1, const void* Wo,
 // of 64 (the contraction is 8 k-steps, the operand of all heads 32 KiB), a head's column slice dim / 8 that is a whole number of 32-column
 // groups, and one counter per sample.
 size_t xa_ln3_part_bytes(int batch, int heads) { return (size_t)batch * heads * 32 * 2 * sizeof(float); }
+// The in-launch exchange needs the device described at "Co-residency" above: 8 XCDs (xcd_remap's constant) with room for a sample's 8
+// workgroups on each.  Asked once per device; a device that does not qualify keeps the separate launches.
+constexpr int kMinCusPerXcd = 16;
+static bool xa_exchange_device_ok() {
+    static std::atomic<int> cache[64];          // 0 = not asked, 1 = ok, 2 = no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int c = cache[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        int cus = 0, xccs = 0;
+        const bool have = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                          hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess;
+        c = (have && xccs == 8 && cus / 8 >= kMinCusPerXcd) ? 1 : 2;
+        cache[dev].store(c, std::memory_order_relaxed);
+    }
+    return c == 1;
+}
 bool xa_out_fusable(const XaFusedArgs& a, int dtype, int dim_head) {
     static const int on = dbg_switch("FF_XATTN_OUTFUSE", 1);
-    if (!on || a.heads != 8 || a.inner != 8 * kResDH || a.dim % 256 != 0 || a.dim / 8 > 32 * kOutMaxPer || a.batch > kSyncSlots) return false;
+    if (!on || !xa_exchange_device_ok()) return false;
+    if (a.heads != 8 || a.inner != 8 * kResDH || a.dim % 256 != 0 || a.dim / 8 > 32 * kOutMaxPer || a.batch > kSyncSlots) return false;
     return res_ring_depth(a, dtype, dim_head, false) != 0 && res_ring_depth(a, dtype, dim_head, true) != 0;
 }
 

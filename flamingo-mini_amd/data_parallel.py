@@ -517,6 +517,9 @@ class ShardedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            from . import functional as _F
+            _F.poll_sync_exchange("ShardedAdamW.step")      # non-blocking check of the fused cross-attention kernels' hand-off error word
         self.finish_step()
         return loss
 

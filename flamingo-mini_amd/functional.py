@@ -444,23 +444,51 @@ def resampler_layerwise(x_f: torch.Tensor, params: Sequence[torch.Tensor], cfg, 
 # GatedCrossAttentionBlock
 # ----------------------------------------------------------------------------------------------------
 # ff_xattn_desc.sync: the arrival counters through which the (sample, head) workgroups of the fused cross-attention kernels exchange their
-# tiles inside a launch (to_out / d LN(y) without a launch of their own).  One buffer per device, zeroed once, at allocation; only the
-# library writes it.  Calls that share it must be stream-ordered: every block of a model runs on the stream its step runs on, and this
-# process runs one step at a time.  (Two models stepping concurrently on two streams of one device need use_sync_exchange = False.)
-_sync_buffers: dict = {}
+# tiles inside a launch (to_out / d LN(y) without a launch of their own).  The counters are per sample, not per call, so every launch that
+# shares a buffer must be ordered behind the previous one: a buffer therefore belongs to ONE stream of one device - the stream that was
+# current when it was first asked for - and a call on any other stream gets its own (eval or decode beside training, a second model, a
+# side-stream experiment: no interleaved arrivals).  The zero fill is enqueued on the owning stream, i.e. ahead of the first launch that
+# counts on it.  A forward call records the buffer it used in its autograd context: the backward pass (the autograd engine restores the
+# forward's stream) and the deferred weight-gradient flush see the same decision the forward made, whatever the switch says by then.
+_sync_buffers: dict = {}        # (device index, stream handle) -> uint8 tensor of ff_xattn_sync_bytes()
+_sync_probes: dict = {}         # (device index, stream handle) -> (pinned int32 tensor, event) of the last non-blocking status probe
 use_sync_exchange = True        # False: every block keeps its separate to_out / d LN(y) launches (A/B timing, debugging)
+_STATUS_WORD = None             # element index of the status word in an int32 view of a sync buffer
 
 
-def ensure_sync_buffer(device) -> Optional[torch.Tensor]:
-    """Allocate (once) and return the device's sync buffer.  Call sites that capture HIP graphs call this BEFORE the capture begins: the
-    zero fill must not become a graph node, and the memory must be the process's, not a graph pool's."""
+class SyncExchangeTimeout(ffi.FusionLibraryError):
+    """An arrival wait inside a fused cross-attention launch gave up (a sample's workgroups were denied co-residency): the outputs of
+    that launch - and of everything computed from them - are invalid."""
+
+
+def _status_word() -> int:
+    global _STATUS_WORD
+    if _STATUS_WORD is None:
+        words = int(ffi.lib().ff_xattn_sync_bytes()) // 4          # include/flamingo_fusion.h: (4 * FF_XATTN_SYNC_SLOTS + 64) words,
+        _STATUS_WORD = 2 * ((words - 64) // 4)                      # the status word follows the first two counter banks
+    return _STATUS_WORD
+
+
+def _sync_key(device, stream=None):
     device = torch.device(device)
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(index) if stream is None else stream
+    return index, int(stream.cuda_stream)
+
+
+def ensure_sync_buffer(device, stream=None) -> Optional[torch.Tensor]:
+    """The sync buffer of (`device`, `stream`; default: the current stream), allocated and zeroed on first use.  Nothing can be allocated
+    while that stream is capturing (the zero fill must not become a graph node, the memory must not come from a graph pool): code that
+    captures HIP graphs calls this for its capture stream BEFORE the capture begins (graphs.GraphedTrainStep and
+    PiecewiseGraphedTrainStep do); a capture nobody prepared gets None and keeps the separate launches."""
+    index, handle = key = _sync_key(device, stream)
     buf = _sync_buffers.get(key)
     if buf is None:
         if torch.cuda.is_current_stream_capturing():
-            return None                     # a capture that nobody prepared: this call keeps its separate launches
-        buf = torch.zeros(int(ffi.lib().ff_xattn_sync_bytes()), dtype=torch.uint8, device=device)
+            return None
+        stream = torch.cuda.current_stream(index) if stream is None else stream
+        with torch.cuda.stream(stream):
+            buf = torch.zeros(int(ffi.lib().ff_xattn_sync_bytes()), dtype=torch.uint8, device=torch.device("cuda", index))
         _sync_buffers[key] = buf
     return buf
 
@@ -470,15 +498,59 @@ def _sync_buffer(device) -> Optional[torch.Tensor]:
 
 
 def sync_exchange_status(device=None) -> int:
-    """1 if an in-launch arrival wait of the fused cross-attention kernels ever timed out on `device` (that call's output was invalid), else 0."""
+    """1 if an in-launch arrival wait of the fused cross-attention kernels ever timed out on `device` (None: any device) - that launch's
+    output was invalid -, else 0.  Blocking: synchronises the streams that own sync buffers."""
     bad = 0
-    for dev, buf in list(_sync_buffers.items()):
-        if device is None or torch.device(device).index in (None, dev):
-            bad |= int(ffi.lib().ff_xattn_sync_status(buf.data_ptr(), ffi.stream_handle(buf.device)))
+    for (index, handle), buf in list(_sync_buffers.items()):
+        if device is None or torch.device(device).index in (None, index):
+            rc = int(ffi.lib().ff_xattn_sync_status(buf.data_ptr(), handle))
+            if rc < 0:
+                ffi.check(rc, "ff_xattn_sync_status")
+            bad |= rc
     return bad
 
 
-def _xattn_desc(y, n_media, n_visual, dim_visual, cfg, tt, tt_offset=0, ck=None, cv=None) -> ffi.XattnDesc:
+def check_sync_exchange(where: str = "", device=None) -> None:
+    """Blocking check; raises SyncExchangeTimeout if any in-launch hand-off ever timed out.  Called by the graph-replay steps (after the
+    warm-up, after the capture, every `check_every` replays, in close()) and by bench.py after its timed region."""
+    if _sync_buffers and sync_exchange_status(device):
+        raise SyncExchangeTimeout(
+            f"{where or 'check_sync_exchange'}: an in-launch hand-off of the fused cross-attention kernels timed out (ff_xattn_sync_status = 1): "
+            "a sample's eight workgroups were not resident together (CU mask, partitioned or shared GPU?). Results since the last clean check are "
+            "invalid; set flamingo_mini_amd.functional.use_sync_exchange = False to run the separate launches.")
+
+
+def poll_sync_exchange(where: str = "") -> None:
+    """Non-blocking form for eager training loops (FusedAdamW.step / ShardedAdamW.step call it): looks at the status word that the PREVIOUS
+    call copied to pinned memory - raising SyncExchangeTimeout if it was set - and enqueues the next copy behind the work issued so far.
+    Never synchronises; does nothing for a stream that is capturing (a captured step is checked by its graph-step object)."""
+    for key, buf in list(_sync_buffers.items()):
+        index, handle = key
+        probe = _sync_probes.get(key)
+        if probe is not None:
+            host, event = probe
+            if not event.query():
+                continue                                     # the previous probe is still in flight: look again next time
+            if int(host.item()):
+                raise SyncExchangeTimeout(f"{where or 'poll_sync_exchange'}: an in-launch hand-off of the fused cross-attention kernels timed out "
+                                          "(see functional.check_sync_exchange)")
+        stream = torch.cuda.ExternalStream(handle, device=torch.device("cuda", index)) if handle else torch.cuda.default_stream(index)
+        with torch.cuda.stream(stream):
+            if torch.cuda.is_current_stream_capturing():
+                continue
+            host = probe[0] if probe is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
+            host.copy_(buf.view(torch.int32)[_status_word(): _status_word() + 1], non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(stream)
+        _sync_probes[key] = (host, event)
+
+
+_AUTO = object()
+
+
+def _xattn_desc(y, n_media, n_visual, dim_visual, cfg, tt, tt_offset=0, ck=None, cv=None, sync=_AUTO) -> ffi.XattnDesc:
+    """sync: _AUTO = the current stream's buffer if the switch is on and the shape can use one (forward calls); a tensor or None = what the
+    forward call of this block decided (backward calls pass ctx.sync); the tensor is kept alive on the descriptor."""
     heads, dim_head, ff_mult, act = cfg
     b, L, d = y.shape
     desc = ffi.XattnDesc(ffi.dtype_code(y.dtype), b, L, d, dim_visual, n_media, n_visual, heads, dim_head, ff_mult, ffi.ACTS[act],
@@ -486,9 +558,10 @@ def _xattn_desc(y, n_media, n_visual, dim_visual, cfg, tt, tt_offset=0, ck=None,
     if ck is not None:
         desc.cached_k = ffi.Strides(ck.stride(0), ck.stride(2), ck.stride(1))   # (b, h, n, d) tensor -> (sb, sr, sh)
         desc.cached_v = ffi.Strides(cv.stride(0), cv.stride(2), cv.stride(1))
-    if y.is_cuda and y.dtype == torch.bfloat16 and heads == 8 and dim_head == 64 and L <= 32:
-        sync = _sync_buffer(y.device)
-        desc.sync = None if sync is None else sync.data_ptr()
+    if sync is _AUTO:
+        sync = _sync_buffer(y.device) if (y.is_cuda and y.dtype == torch.bfloat16 and heads == 8 and dim_head == 64 and L <= 32) else None
+    desc.sync = None if sync is None else sync.data_ptr()
+    desc.sync_tensor = sync
     return desc
 
 
@@ -507,7 +580,7 @@ class _XattnBlockFn(torch.autograd.Function):
         ffi.check(lib.ff_xattn_block_fwd(desc, y.data_ptr(), vf.data_ptr(), tt.data_ptr(), ffi.ptr_array(params), None, None,
                                          out.data_ptr(), saved.data_ptr(), saved.numel(), scratch.data_ptr(), scratch.numel(),
                                          ffi.stream_handle(dev)), "ff_xattn_block_fwd")
-        ctx.cfg, ctx.n_visual = cfg, n_visual
+        ctx.cfg, ctx.n_visual, ctx.sync = cfg, n_visual, desc.sync_tensor
         ctx.save_for_backward(y, vf, tt, saved, *params)
         ctx.mark_non_differentiable(saved)
         ctx.set_materialize_grads(False)     # no zero-filled "gradient" of the saved-activation buffer (a multi-MB uint8 fill per block)
@@ -517,7 +590,7 @@ class _XattnBlockFn(torch.autograd.Function):
     def backward(ctx, dout, _dsaved):
         lib = ffi.lib()
         y, vf, tt, saved, *params = ctx.saved_tensors
-        desc = _xattn_desc(y, vf.shape[1], ctx.n_visual, vf.shape[3], ctx.cfg, tt)
+        desc = _xattn_desc(y, vf.shape[1], ctx.n_visual, vf.shape[3], ctx.cfg, tt, sync=ctx.sync)
         dev = y.device
         dout = torch.zeros_like(y) if dout is None else dout.contiguous()
         flat, grads = _flat_grads(params)
@@ -583,9 +656,9 @@ class _XattnBlockKvFn(torch.autograd.Function):
     """Block forward / backward with externally projected K / V: consumes `kv` (b, n_kv, 2*inner), returns d kv."""
 
     @staticmethod
-    def _desc(y, kv, n_visual, dim_visual, cfg, tt):
+    def _desc(y, kv, n_visual, dim_visual, cfg, tt, sync=_AUTO):
         inner = cfg[0] * cfg[1]
-        desc = _xattn_desc(y, kv.shape[1] // n_visual, n_visual, dim_visual, cfg, tt)
+        desc = _xattn_desc(y, kv.shape[1] // n_visual, n_visual, dim_visual, cfg, tt, sync=sync)
         desc.cached_k = desc.cached_v = ffi.Strides(kv.shape[1] * 2 * inner, 2 * inner, cfg[1])   # (batch, row, head) strides
         return desc, inner
 
@@ -603,7 +676,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
         ffi.check(lib.ff_xattn_block_fwd(desc, y.data_ptr(), None, tt.data_ptr(), ffi.ptr_array(params), kv.data_ptr(),
                                          kv.data_ptr() + inner * kv.element_size(), out.data_ptr(), saved.data_ptr(), saved.numel(),
                                          scratch.data_ptr(), scratch.numel(), ffi.stream_handle(dev)), "ff_xattn_block_fwd(hoisted kv)")
-        ctx.cfg, ctx.n_visual = cfg, n_visual
+        ctx.cfg, ctx.n_visual, ctx.sync = cfg, n_visual, desc.sync_tensor
         defer, group = wgrad if wgrad is not None else (True, None)
         ctx.defer = bool(defer)
         ctx.group = max(1, min(ffi.WGRAD_GROUP_MAX, int(group if group else _wgrad_queue.group)))
@@ -614,7 +687,7 @@ class _XattnBlockKvFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = ffi.lib()
         y, kv, tt, saved, *params = ctx.saved_tensors
-        desc, inner = _XattnBlockKvFn._desc(y, kv, ctx.n_visual, params[_KV_PARAM].shape[1], ctx.cfg, tt)
+        desc, inner = _XattnBlockKvFn._desc(y, kv, ctx.n_visual, params[_KV_PARAM].shape[1], ctx.cfg, tt, sync=ctx.sync)
         dev = y.device
         dout = dout.contiguous()
         own = [p for i, p in enumerate(params) if i != _KV_PARAM]            # d to_kv.weight comes from _KvProjectFn

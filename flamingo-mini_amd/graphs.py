@@ -56,24 +56,62 @@ def _refuse_live_autograd_graphs(model: torch.nn.Module) -> None:
             "their gradient-accumulation nodes are bound to the stream of that forward and cannot take part in a stream capture.")
 
 
+_WATCHDOG_PERIOD_S = 0.1        # ProcessGroupNCCL.hpp: kWatchdogThreadSleepMillis = 100 (a compile-time constant of the torch build, no environment knob)
+
+
 def _let_the_watchdog_drain() -> None:
-    """Called between the eager warm-up steps (already synchronised) and a stream capture.  ProcessGroupNCCL's watchdog thread keeps every collective
-    of the warm-up in a list and polls its events (hipEventQuery) every ~100 ms until it has seen them complete; on ROCm such a query from that
-    thread while THIS thread captures has aborted the process now and then even in "thread_local" capture mode (round 5: the whole-step-capture row
-    of the round-end session, and one run of the piecewise capture test, died that way - no Python frame, no message).  Two of its periods later
-    the list is empty and nothing queries anything during the capture."""
-    import time
+    """Called between the eager warm-up steps and a stream capture.  ProcessGroupNCCL's watchdog thread keeps every collective of the warm-up in
+    a list and polls its events (hipEventQuery) once per period until it has seen them complete; on ROCm such a query from that thread while
+    THIS thread captures has aborted the process now and then even in "thread_local" capture mode (round 5: no Python frame, no message).
+    The list has no Python accessor (the process group exposes neither its length nor the watchdog's heartbeat), so the drain cannot be
+    observed - but it can be bounded: once the DEVICE is idle every listed collective is complete, each watchdog pass visits the whole list
+    and erases what is complete, and a pass starts at most one period after the previous one ended.  Device idle + three periods (one may be
+    in progress, one full pass, one of slack for a descheduled thread) therefore leaves nothing to query during the capture; collectives
+    issued INSIDE a capture are never listed (ProcessGroupNCCL skips workEnqueue while capturing)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-        time.sleep(0.3)
+        torch.cuda.synchronize()
+        deadline = time.monotonic() + 3 * _WATCHDOG_PERIOD_S + 0.05
+        while time.monotonic() < deadline:
+            time.sleep(_WATCHDOG_PERIOD_S / 2)
+
+
+def _model_device(model: torch.nn.Module) -> torch.device:
+    for p in model.parameters():
+        if p.is_cuda:
+            return p.device
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _prepared_capture_stream(model: torch.nn.Module) -> torch.cuda.Stream:
+    """The stream a step object captures on - its own, so that the arrival counters its fused cross-attention launches exchange through
+    (functional.ensure_sync_buffer: one buffer per device AND stream) are shared with nobody else's launches - with that buffer allocated
+    and zeroed NOW: inside a capture nothing can be allocated, and a capture nobody prepared silently keeps the separate launches."""
+    from . import functional as F
+    device = _model_device(model)
+    stream = torch.cuda.Stream(device=device)
+    stream.wait_stream(torch.cuda.current_stream(device))
+    if F.use_sync_exchange:
+        F.ensure_sync_buffer(device, stream)
+    return stream
+
+
+def _check_sync_exchange(where: str) -> None:
+    from . import functional as F
+    F.check_sync_exchange(where)
 
 
 class GraphedTrainStep:
+    """check_every: every that many replays (and after the warm-up, and in close()) the step reads the error word of the in-launch hand-offs
+    of the fused cross-attention kernels (functional.check_sync_exchange - one device synchronisation) and raises SyncExchangeTimeout if a
+    launch was ever denied co-residency: a replayed graph cannot train through a timed-out hand-off unnoticed.  0 = only at those two points."""
+
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
-                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None):
+                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, check_every: int = 128):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a GPU")
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
+        self.check_every, self._replays = int(check_every), 0
         _refuse_live_autograd_graphs(model)
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self._loss_fn = loss_fn or (lambda out: out.loss)
@@ -84,7 +122,9 @@ class GraphedTrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _check_sync_exchange("GraphedTrainStep: eager warm-up steps")
         self.graph = torch.cuda.CUDAGraph()
+        self._capture_stream = _prepared_capture_stream(model)
         model.zero_grad(set_to_none=True)
         # With collectives in the step the process group's watchdog THREAD is alive and polls the events of the warm-up steps' collectives
         # (hipEventQuery) whenever it wakes up; under the default "global" capture mode such a call from another thread during the capture
@@ -92,9 +132,23 @@ class GraphedTrainStep:
         import torch.distributed as dist
         mode = "thread_local" if reducer is not None or (dist.is_available() and dist.is_initialized()) else "global"
         _let_the_watchdog_drain()
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+        with torch.cuda.graph(self.graph, stream=self._capture_stream, capture_error_mode=mode):
             self.loss = self._eager().detach()
         torch.cuda.synchronize()
+
+    def close(self) -> None:
+        """Final check of the in-launch hand-offs (raises SyncExchangeTimeout); idempotent."""
+        if self._replays:
+            self._replays = 0
+            _check_sync_exchange("GraphedTrainStep.close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if exc[0] is None:
+            self.close()
+        return False
 
     def _eager(self) -> torch.Tensor:
         self.model.zero_grad(set_to_none=True)              # gradients are re-created (not accumulated) by every backward
@@ -115,6 +169,9 @@ class GraphedTrainStep:
                     self.static[k].copy_(v, non_blocking=True)
         if self.optimizer is not None and hasattr(self.optimizer, "sync_device_hyperparams"):
             self.optimizer.sync_device_hyperparams()        # an LR scheduler may have changed group["lr"] since the capture
+        if self.check_every > 0 and self._replays and self._replays % self.check_every == 0:
+            _check_sync_exchange(f"GraphedTrainStep: replays {self._replays - self.check_every + 1}..{self._replays}")
+        self._replays += 1
         self.graph.replay()
         return self.loss
 
@@ -231,7 +288,8 @@ class PiecewiseGraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
                  warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, segment_layers: int = 4, capture: bool = True,
-                 pace: str = "host", overlap_optimizer: bool = False, segment_arena: bool = True):
+                 pace: str = "host", overlap_optimizer: bool = False, segment_arena: bool = True, check_every: int = 128):
+        self.check_every, self._replays = int(check_every), 0          # see GraphedTrainStep
         if pace not in ("host", "stream"):
             raise ValueError("pace must be 'host' or 'stream'")
         if overlap_optimizer and (pace != "host" or not capture):
@@ -268,11 +326,15 @@ class PiecewiseGraphedTrainStep:
             raise
 
     def close(self) -> None:
-        """Take the cut points out of the model (idempotent).  The step cannot run afterwards."""
+        """Take the cut points out of the model (idempotent) and check the in-launch hand-offs of the steps that ran one last time (raises
+        SyncExchangeTimeout).  The step cannot run afterwards."""
         if getattr(self.model, "install_autograd_cuts", None) is not None:
             self.model.install_autograd_cuts(None)
         self.cuts.reset()
         self.graphs, self._opt_pieces, self._opt_graph = [], [], None
+        if self._replays and torch.cuda.is_available():
+            self._replays = 0
+            _check_sync_exchange("PiecewiseGraphedTrainStep.close")
 
     def __enter__(self):
         return self
@@ -292,15 +354,17 @@ class PiecewiseGraphedTrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _check_sync_exchange("PiecewiseGraphedTrainStep: eager warm-up steps")
         arena_sizes = self._size_arenas() if self.segment_arena else None
         import torch.distributed as dist
         mode = "thread_local" if reducer is not None or (dist.is_available() and dist.is_initialized()) else "global"
         _let_the_watchdog_drain()
         pool = torch.cuda.graph_pool_handle()
+        cap_stream = _prepared_capture_stream(model)        # every piece is captured on this one stream: one set of arrival counters
 
         def piece(fn):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+            with torch.cuda.graph(g, pool=pool, stream=cap_stream, capture_error_mode=mode):
                 out = fn()
             self.graphs.append(g)
             return out
@@ -421,6 +485,9 @@ class PiecewiseGraphedTrainStep:
             return self.loss
         if self.optimizer is not None and hasattr(self.optimizer, "sync_device_hyperparams"):
             self.optimizer.sync_device_hyperparams()
+        if self.check_every > 0 and self._replays and self._replays % self.check_every == 0:
+            _check_sync_exchange(f"PiecewiseGraphedTrainStep: replays {self._replays - self.check_every + 1}..{self._replays}")
+        self._replays += 1
         ht = self.host_timing                               # None, or a dict that accumulates the HOST seconds of each kind of call
         t0 = time.perf_counter() if ht is not None else 0.0
         if self.overlap_optimizer:

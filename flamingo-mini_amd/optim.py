@@ -44,6 +44,11 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = ffi.lib()
+        if advance and not torch.cuda.is_current_stream_capturing():
+            # an eager training loop cannot run through a timed-out in-launch hand-off of the fused cross-attention kernels unnoticed:
+            # looks at the status word the previous step copied to pinned memory, enqueues the next copy; never synchronises
+            from . import functional as _F
+            _F.poll_sync_exchange("FusedAdamW.step")
         if only is not None:
             only = frozenset(only)
             if not all(g.get("capturable", False) for g in self.param_groups):

@@ -269,7 +269,9 @@ int ff_resampler_prologue_bwd(const ff_resampler_desc* d, const void* dx0, const
  * then holds no K/V region (size queries and calls must use the same descriptor).
  * `sync` (ABI 4, optional): ff_xattn_sync_bytes() bytes of device memory that were ZERO when first handed to the library and that only the
  * library writes afterwards.  With it, and at the training / decode shape of the published configurations (bf16, 8 heads of 64, at most 32
- * tokens and 64 keys per sample, dim a multiple of 256 up to 1536, batch <= FF_XATTN_SYNC_SLOTS), `to_out` + tanh gate + residual
+ * tokens and 64 keys per sample, dim a multiple of 256 up to 1280 - at 1536 the backward kernel's resident rows + ring + tiles are 165 184 B
+ * of LDS, over the CU's 160 KiB, and the block keeps its separate launches -, batch <= FF_XATTN_SYNC_SLOTS, and a device that reports 8 XCDs
+ * of at least 16 CUs each: see "Co-residency" in csrc/ff_xattn_fused.hip), `to_out` + tanh gate + residual
  * (gated_cross_attention.py:124-126,180) run INSIDE the fused LayerNorm -> to_q -> attention launch, and d LN(y) = d q . Wq inside the fused
  * attention-backward launch: the eight (sample, head) workgroups of a sample exchange their tiles through per-sample arrival counters in
  * `sync` instead of through a kernel boundary (two 64 x 64-tile GEMM launches per block and step less).  At the training shape the
@@ -278,7 +280,8 @@ int ff_resampler_prologue_bwd(const ff_resampler_desc* d, const void* dx0, const
  * and step less).  Calls that share a `sync` buffer must be ordered on one stream (the counters are per sample, not per call); NULL keeps the
  * separate launches.  Results are the same either way up to the rounding of fp32 sums taken in another order; the word behind the first two
  * banks is an error flag (ff_xattn_sync_status; non-zero: an arrival wait timed out - a launch was denied co-residency of a sample's eight
- * workgroups - and that call's output is invalid).
+ * workgroups - and that call's output is invalid).  A caller MUST read that flag before trusting results computed with a `sync` buffer: the
+ * Python layer does so after warm-up steps, every N graph replays, at every eager optimizer step (non-blocking) and at the end of bench.py.
  * ------------------------------------------------------------------------------------------------------ */
 #define FF_XATTN_PARAMS 11
 #define FF_XATTN_SYNC_SLOTS 1024

@@ -365,6 +365,166 @@ def test_in_launch_exchange_equals_separate_launches_and_oracle(b, L, nv, dim):
     torch.cuda.synchronize()
 
 
+def _fused_tiles_of_one_block_step(m, yd, vfd, mlt, dyd):
+    """profile codes (ff_gemm_profile_record.tile) of the fused cross-attention launches of one forward + backward of block `m`"""
+    from flamingo_mini_amd import ffi
+    lib = ffi.lib()
+    lib.ff_gemm_profile_enable(256)
+    try:
+        out, _ = m(yd, vfd, mlt)
+        out.backward(dyd)
+        torch.cuda.synchronize()
+        recs = (ffi.GemmProfileRecord * 256)()
+        n = lib.ff_gemm_profile_read(recs, 256)
+    finally:
+        lib.ff_gemm_profile_enable(0)
+    return sorted(recs[i].tile for i in range(n) if recs[i].tile <= -4)
+
+
+@pytest.mark.parametrize("dim,want", [(1280, [-9, -8]), (1536, [-5, -4])], ids=["dim1280-in-launch", "dim1536-separate-launches"])
+def test_in_launch_exchange_engages_up_to_the_documented_width(dim, want):
+    """include/flamingo_fusion.h documents the widths at which `to_out` / d LN(y) (+ their LayerNorms) run INSIDE the fused launches: dim a
+    multiple of 256 up to 1280 (the header said 1536, where the backward kernel's LDS footprint is 165 184 B > 160 KiB and the
+    fusion silently never engaged).  At the documented maximum the launch log must show the phase-3 tiles (-8 forward, -9 backward); one
+    step beyond it the plain fused launches (-4 / -5) followed by the separate products - and the results are held to the oracle either way
+    by test_in_launch_exchange_equals_separate_launches_and_oracle."""
+    from flamingo_mini_amd import functional as F
+    dtype = torch.bfloat16
+    b, L, nv, dv = 8, 32, 64, 256
+    p = xattn_params(dim, dv, 8, 64, 2, tag=f"width{dim}")
+    m = build_block(p, dim, dv, 8, 64, nv, 2, "gelu", dtype)
+    ml = np.zeros((b, L), np.int64); ml[:, 0] = 1
+    yd = dev(det((b, L, dim), "w-y"), dtype).requires_grad_(True)
+    vfd = dev(det((b, 1, nv, dv), "w-vf"), dtype).requires_grad_(True)
+    dyd = dev(det((b, L, dim), "w-dy"), dtype)
+    assert F.use_sync_exchange
+    assert _fused_tiles_of_one_block_step(m, yd, vfd, torch.as_tensor(ml).cuda(), dyd) == want
+    assert F.sync_exchange_status() == 0
+
+
+@pytest.mark.parametrize("b", [64, 128], ids=["512-workgroups", "1024-workgroups"])
+def test_in_launch_exchange_beside_a_persistent_kernel(b):
+    """the RCCL-shaped case.  While a second stream HOLDS 32 CUs with a persistent kernel (tests/helpers/cu_hog.hip: one
+    64-thread workgroup with 128 KiB of LDS per CU, spinning for the whole test - nothing of the fused kernels fits beside it), the fused
+    cross-attention launches run their in-launch hand-offs at 512 and 1024 workgroups, i.e. in several dispatch rounds on the 224 CUs left.
+    Every sample's eight workgroups must still meet (status word 0), the results must be the bits of the undisturbed run, and within the
+    usual distance of the separate launches.  A third leg hands the SAME buffers to a run on another stream: it must get its own counters
+    (functional.ensure_sync_buffer is per device AND stream), not share the first stream's."""
+    from flamingo_mini_amd import functional as F
+    from util import cu_hog
+    dtype = torch.bfloat16
+    L, nv, dim, dv, heads, dh, ffm = 32, 64, 1280, 256, 8, 64, 2
+    p = xattn_params(dim, dv, heads, dh, ffm, tag="hog")
+    m = build_block(p, dim, dv, heads, dh, nv, ffm, "gelu", dtype)
+    ml = np.zeros((b, L), np.int64); ml[:, 0] = 1; ml[1, 0] = 0; ml[1, 3] = 1
+    yd = dev(det((b, L, dim), "hog-y"), dtype).requires_grad_(True)
+    vfd = dev(det((b, 1, nv, dv), "hog-vf"), dtype).requires_grad_(True)
+    dyd = dev(det((b, L, dim), "hog-dy"), dtype)
+    mlt = torch.as_tensor(ml).cuda()
+
+    def run():
+        for t_ in (yd, vfd, *m.parameters()):
+            t_.grad = None
+        out, _ = m(yd, vfd, mlt)
+        out.backward(dyd)
+        return [out.detach().clone(), yd.grad.clone(), vfd.grad.clone()] + [q.grad.clone() for q in m.parameters()]
+
+    names = ["out", "dy", "dvf"] + [k for k, _ in m.named_parameters()]
+    assert F.use_sync_exchange
+    quiet = run()
+    torch.cuda.synchronize()
+    assert F.sync_exchange_status() == 0
+    try:
+        F.use_sync_exchange = False
+        separate = run()
+        torch.cuda.synchronize()
+    finally:
+        F.use_sync_exchange = True
+    hog, side = cu_hog(), torch.cuda.Stream()
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    rc = hog.cu_hog_launch(32, 128 * 1024, 400.0, sink.data_ptr(), side.cuda_stream)      # 32 CUs held for 0.4 s
+    assert rc == 0, rc
+    import time
+    time.sleep(0.02)                                    # the persistent workgroups are resident before the first fused launch is issued
+    t0 = time.perf_counter()
+    for i in range(12):
+        crowded = run()
+        for k, x_, y_ in zip(names, crowded, quiet):
+            assert torch.equal(x_, y_), (i, k)
+    torch.cuda.current_stream().synchronize()
+    assert time.perf_counter() - t0 < 0.35, "the twelve steps were meant to run WHILE the persistent kernel holds its CUs"
+    assert not side.query(), "the persistent kernel ended before the fused launches did: the test did not test anything"
+    assert F.sync_exchange_status() == 0
+    for k, a_, b_ in zip(names, crowded, separate):
+        if a_.numel() > 1:
+            assert rel(a_, b_) < 3e-3, k
+    # another stream gets its own counters, and interleaving the two streams' launches disturbs neither
+    other = torch.cuda.Stream()
+    n_bufs = len(F._sync_buffers)
+    other.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(other):
+        elsewhere = run()
+    again = run()
+    torch.cuda.synchronize()
+    assert len(F._sync_buffers) == n_bufs + 1
+    for k, x_, y_, z_ in zip(names, elsewhere, again, quiet):
+        assert torch.equal(x_, z_) and torch.equal(y_, z_), k
+    assert F.sync_exchange_status() == 0
+    torch.cuda.synchronize()
+
+
+def test_sync_exchange_timeout_is_raised_not_ignored():
+    """The error word cannot be ignored: with the status word of a stream's sync buffer set (what a timed-out arrival wait leaves behind),
+    check_sync_exchange raises, the non-blocking poll of the eager optimizers raises on its second call, and a graph-replay step raises at
+    its next checkpoint."""
+    from flamingo_mini_amd import functional as F
+    from flamingo_mini_amd.graphs import GraphedTrainStep
+    dtype = torch.bfloat16
+    p = xattn_params(256, 128, 8, 64, 2, tag="timeout")
+    m = build_block(p, 256, 128, 8, 64, 16, 2, "gelu", dtype)
+    ml = torch.zeros((2, 8), dtype=torch.long, device="cuda"); ml[:, 0] = 1
+    y = dev(det((2, 8, 256), "to-y"), dtype)
+    vf = dev(det((2, 1, 16, 128), "to-vf"), dtype)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blk = m
+
+        def forward(self, y, vf, ml):
+            out, _ = self.blk(y, vf, ml)
+
+            class R:
+                loss = out.float().square().mean()
+            return R
+
+    model = Wrap()
+    with GraphedTrainStep(model, None, dict(y=y, vf=vf, ml=ml), warmup=1, check_every=2) as step:
+        step(); step()
+        torch.cuda.synchronize()
+        F.check_sync_exchange("clean")                                  # nothing timed out
+        F.poll_sync_exchange("clean"); torch.cuda.synchronize(); F.poll_sync_exchange("clean")
+        buf = next(iter(F._sync_buffers.values()))
+        word = F._status_word()
+        try:
+            buf.view(torch.int32)[word] = 1                             # what res_await leaves behind when it gives up
+            torch.cuda.synchronize()
+            with pytest.raises(F.SyncExchangeTimeout):
+                F.check_sync_exchange("test")
+            F.poll_sync_exchange("test")                                # enqueues the probe that sees the word ...
+            torch.cuda.synchronize()
+            with pytest.raises(F.SyncExchangeTimeout):
+                F.poll_sync_exchange("test")                            # ... and the next call reports it
+            with pytest.raises(F.SyncExchangeTimeout):
+                step()                                                  # replay 2 is a checkpoint of check_every = 2
+        finally:
+            buf.view(torch.int32)[word] = 0
+            F._sync_probes.clear()
+            torch.cuda.synchronize()
+    assert F.sync_exchange_status() == 0
+
+
 @pytest.mark.parametrize("b,L,dim,ffm,act", [(32, 1, 1280, 4, "gelu"), (4, 8, 1280, 4, "gelu"), (16, 2, 2048, 4, "gelu"), (3, 5, 256, 1, "sqrelu"),
                                              (2, 7, 768, 4, "gelu"), (8, 4, 1024, 2, "gelu"), (16, 2, 384, 4, "gelu"), (32, 1, 128, 4, "gelu"),
                                              (5, 6, 640, 2, "sqrelu")],

@@ -56,3 +56,25 @@ def rnd(shape, seed, scale=1.0):
 def as64(t):
     """what the kernel actually saw (after rounding to its dtype), as float64 numpy"""
     return t.detach().double().cpu().numpy()
+
+
+def build_cu_hog() -> str:
+    """Compile tests/helpers/cu_hog.hip -> libcu_hog.so if stale (hipcc cross-compiles without a GPU; __graft_entry__.build() calls this so
+    that the helper travels to the GPU box prebuilt)."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers")
+    src, so = os.path.join(here, "cu_hog.hip"), os.path.join(here, "libcu_hog.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        hipcc = next(c for c in ("/opt/rocm/bin/hipcc", "hipcc") if c == "hipcc" or os.path.exists(c))
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, src], check=True, capture_output=True)
+    return so
+
+
+def cu_hog():
+    """ctypes handle of tests/helpers/libcu_hog.so (a kernel that holds CUs for a given time - a test helper, not part of the product
+    library).  `lib.cu_hog_launch(blocks, lds_bytes, milliseconds, sink_ptr, stream)` returns a hipError_t."""
+    import ctypes
+    lib = ctypes.CDLL(build_cu_hog())
+    lib.cu_hog_launch.restype = ctypes.c_int
+    lib.cu_hog_launch.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    return lib

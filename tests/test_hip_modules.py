@@ -461,13 +461,14 @@ def test_in_launch_exchange_beside_a_persistent_kernel(b):
             assert rel(a_, b_) < 3e-3, k
     # another stream gets its own counters, and interleaving the two streams' launches disturbs neither
     other = torch.cuda.Stream()
-    n_bufs = len(F._sync_buffers)
+    assert other.cuda_stream != torch.cuda.current_stream().cuda_stream
     other.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(other):
         elsewhere = run()
     again = run()
     torch.cuda.synchronize()
-    assert len(F._sync_buffers) == n_bufs + 1
+    mine, theirs = F._sync_buffers[F._sync_key(yd.device)], F._sync_buffers[F._sync_key(yd.device, other)]     # (torch hands out streams from a pool:
+    assert mine.data_ptr() != theirs.data_ptr()                                                                   # `other` may have had its buffer already)
     for k, x_, y_, z_ in zip(names, elsewhere, again, quiet):
         assert torch.equal(x_, z_) and torch.equal(y_, z_), k
     assert F.sync_exchange_status() == 0

@@ -262,7 +262,9 @@ def gemm_profile_summary(lib, ffi, max_records):
             a = attn.setdefault({-1: "fwd", -2: "bwd_dq", -3: "bwd_dkv"}[r.tile], dict(ms=0.0, bytes=0.0, launches=0))
             a["ms"] += r.ms; a["bytes"] += nbytes; a["launches"] += 1
             continue
-        key = (r.dtype, r.tile, r.a_layout, r.b_layout)
+        # one group per kernel INSTANTIATION: split-K launches of the 128 x 160 tile run the 8-wave workgroup with a 3-deep ring, the others the
+        # 12-wave one with a 4-deep ring (ff_gemm.hip run_bf16_dma) - two kernels in the rocprofv3 trace, two groups here
+        key = (r.dtype, r.tile, r.a_layout, r.b_layout, 1 if (r.tile == 128160 and r.split_k > 1) else 0)
         for table, k in ((groups, key), (shapes, (r.M, r.N, r.K, r.nz, r.a_layout, r.b_layout, r.tile, r.split_k)), (families, (r.dtype, r.tile))):
             g = table.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
             g["ms"] += r.ms
@@ -783,10 +785,8 @@ def main():
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             tm, tn = (64, 128) if key[1] == 6412 else (key[1], key[1])
             name = (f"ff::gemm_bf16_dma_kernel<{tm}, {tn}, {key[2]}, {key[3]}, 2>" if is_bf16 else f"ff::gemm_f32_kernel<{key[2]}, {key[3]}>")
-            if key[1] == 128160:      # the producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU, DMA waves, MFMA waves>; split-K launches
-                # of this tile run the 8-wave workgroup with a 3-deep ring (ff_gemm.hip run_bf16_dma): name the instantiation most launches used
-                n_split = sum(v["launches"] for k, v in shapes.items() if k[6] == 128160 and k[4] == key[2] and k[5] == key[3] and k[7] > 1)
-                name = (f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 3, 1, 4, 4>" if 2 * n_split > g["launches"]
+            if key[1] == 128160:      # the producer / consumer kernels: <BM, BN, AL, BL, stages, workgroups per CU, DMA waves, MFMA waves>
+                name = (f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 3, 1, 4, 4>" if key[4]
                         else f"ff::gemm_bf16_pc_kernel<128, 160, {key[2]}, {key[3]}, 4, 1, 8, 4>")
             elif key[1] == 64002:
                 name = f"ff::gemm_bf16_pc_kernel<64, 64, {key[2]}, {key[3]}, 3, 2, 4, 4>"

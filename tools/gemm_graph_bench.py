@@ -22,7 +22,8 @@ As = [torch.randn((M, K) if al == 0 else (K, M), device="cuda", dtype=dt) for _ 
 
 
 EPI = os.environ.get("EPI", "")      # "": plain; "act": gelu + aux_out (FFW up-projection); "act_bwd": gelu' from aux_in, gated (its data gradient)
-H = torch.randn(M, N, device="cuda", dtype=dt) if EPI.startswith("act_bwd") else None
+# COLD_H=1 (round 6): one pre-activation buffer per launch, as in the model (each block's H was written a forward pass ago: it comes from HBM)
+Hs = [torch.randn(M, N, device="cuda", dtype=dt) for _ in range(nb if os.environ.get("COLD_H", "0") == "1" else 1)] if EPI.startswith("act_bwd") else None
 gate = torch.tensor([0.5], device="cuda", dtype=dt)
 R = torch.randn(M, N, device="cuda", dtype=dt) if EPI == "res" else None
 
@@ -33,7 +34,7 @@ def run():
         if EPI in ("act", "act_sqrelu"):
             F.gemm(As[i % na], B, act="gelu" if EPI == "act" else "sqrelu", want_aux_out=True, **kw)
         elif EPI in ("act_bwd", "act_bwd_sqrelu"):
-            F.gemm(As[i % na], B, act_bwd="gelu" if EPI == "act_bwd" else "sqrelu", aux_in=H, gate=gate, **kw)
+            F.gemm(As[i % na], B, act_bwd="gelu" if EPI == "act_bwd" else "sqrelu", aux_in=Hs[i % len(Hs)], gate=gate, **kw)
         elif EPI == "res":
             F.gemm(As[i % na], B, residual=R, gate=gate, **kw)
         else:
@@ -59,5 +60,5 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / (reps * nb)
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FF_") or k == "EPI")
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FF_") or k in ("EPI", "COLD_H", "COLD_A"))
 print(f"{M}x{N}x{K} a{al} b{bl} tile {tile or 'auto'} [{tag}]: {us:7.2f} us   {2.0 * M * N * K / us / 1e6:6.0f} TFLOP/s   ({nb} B buffers, {na} A)", flush=True)

@@ -2,6 +2,7 @@
 tools/build_timeline.sh, -DFF_XA_TIMELINE; 100 MHz clock, 16 slots per workgroup).
 forward : 0 entry | 1 rows / K / V / first weight tiles landed | 2 LayerNorm done | 3 q projection done | 4 attention done, O stored (+ drained)
           | 5 every head of the sample has arrived | 6 O of all heads staged in LDS (+ first Wo tiles) | 7 out-projection done, tile parked | 8 epilogue stored
+          | 9 phase 3 (LayerNorm behind the product: statistics exchanged through the second counter bank, normalised rows stored)
 backward: 0 entry | 1 operands landed | 2 dO projection done | 3 dQ done (+ published) | 4 dK / dV stored | 5 every head has arrived
           | 6 dQ of all heads staged | 7 d LN(y) product done, tile parked | 8 stored
     tools/build_timeline.sh && python tools/xattn_res_timeline.py
@@ -41,7 +42,7 @@ def show(tag, last):
 
 for exchange in (False, True, False, True):
     F.use_sync_exchange = exchange
-    last = 8 if exchange else 4
+    last = 9 if exchange else 4          # 8 -> 9: phase 3 (the LayerNorm behind the product, second counter bank) done and stored
     for it in range(3):
         kv = F.kv_project(vf, [blk.attn.to_kv.weight])[0]
         out, _ = blk(y, vf, ml, hoisted_kv=kv)

@@ -16,7 +16,11 @@ tile = args[5] if len(args) >= 6 else 0
 stages = args[6] if len(args) >= 7 else 0
 dt = torch.bfloat16
 nb = max(4, min(48, int(400e6 / (N * K * 2))))
-Bs = [torch.randn((N, K) if bl == 0 else (K, N), device="cuda", dtype=dt) * 0.05 for _ in range(nb)]
+uniq = int(os.environ.get("UNIQUE", "0"))     # round 6: UNIQUE=1 = the SAME weight buffer in every one of the nb launches of the graph (warm: L2 / Infinity
+                                              # Cache), UNIQUE=4 = four buffers in rotation, ...: separates operand latency from request rate (0 = all different: cold)
+Bs = [torch.randn((N, K) if bl == 0 else (K, N), device="cuda", dtype=dt) * 0.05 for _ in range(uniq if uniq > 0 else nb)]
+if uniq > 0:
+    Bs = [Bs[i % uniq] for i in range(nb)]
 na = nb if os.environ.get("COLD_A", "0") == "1" else 1
 As = [torch.randn((M, K) if al == 0 else (K, M), device="cuda", dtype=dt) for _ in range(na)]
 
@@ -60,5 +64,5 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / (reps * nb)
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FF_") or k in ("EPI", "COLD_H", "COLD_A"))
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FF_") or k in ("EPI", "COLD_H", "COLD_A", "UNIQUE"))
 print(f"{M}x{N}x{K} a{al} b{bl} tile {tile or 'auto'} [{tag}]: {us:7.2f} us   {2.0 * M * N * K / us / 1e6:6.0f} TFLOP/s   ({nb} B buffers, {na} A)", flush=True)

@@ -499,8 +499,14 @@ __global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_
     }
     FF_GEMM_ARGS(Q, pr, P);             // epilogue arguments: the round trip overlaps the first operand tiles
     if (tc.z > 0) pr = P.p[tc.z];
+#ifdef FF_GEMM_PCMODE    // timing builds (tools/build_pcmodes.sh: one library per mode, -DFF_GEMM_PCMODE=n; results are WRONG, timing only) -
+    constexpr int pcmode = FF_GEMM_PCMODE;      // 1: no fragment reads / MFMA (the DMA side alone), 2: no DMA (the consumers alone),
+#else                                           // 3: fragment reads only, 4: MFMA only.  A compile-time constant: a run-time switch cost the
+    constexpr int pcmode = 0;                   // kernel its register budget (r6s7: 427 us instead of 63)
+#endif
     if (producer) {
         for (int kt = 0; kt < nk; kt++) {
+            if (pcmode == 2) { __builtin_amdgcn_s_barrier(); continue; }
             const int younger = min(nk - 1 - kt, NS - 2);
             if (NS >= 4 && younger == 2) wait_vmcnt<2 * PER_TILE>();
             else if (NS >= 3 && younger >= 1) wait_vmcnt<PER_TILE>();
@@ -511,15 +517,31 @@ __global__ __launch_bounds__((NCW + NPW) * 64, WPC * (NCW + NPW) / 4) void gemm_
     } else {
         for (int kt = 0; kt < nk; kt++) {
             __builtin_amdgcn_s_barrier();
+            if (pcmode == 1) continue;
             const bf16* sA = smem + (kt % NS) * STAGE;
             const bf16* sB = sA + A_ELEMS;
 #pragma unroll
             for (int ks = 0; ks < kBK / 32; ks++) {
                 bf16x8 fa[MT], fb[NT];
+                if (pcmode != 4) {
 #pragma unroll
-                for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
+                    for (int i = 0; i < MT; i++) fa[i] = frag_read2<BM, AL>(sA, wm * WM + i * 16, ks);
 #pragma unroll
-                for (int j = 0; j < NT; j++) fb[j] = BS::frag(sB, wn * WN + j * 16, ks);
+                    for (int j = 0; j < NT; j++) fb[j] = BS::frag(sB, wn * WN + j * 16, ks);
+                } else {
+                    const bf16x8 fixed = __builtin_bit_cast(bf16x8, f32x4{(float)l, 1.f, 2.f, (float)kt});
+#pragma unroll
+                    for (int i = 0; i < MT; i++) fa[i] = fixed;
+#pragma unroll
+                    for (int j = 0; j < NT; j++) fb[j] = fixed;
+                }
+                if (pcmode == 3) {      // keep the reads alive without the MFMAs
+#pragma unroll
+                    for (int i = 0; i < MT; i++) acc[i][0] += __builtin_bit_cast(f32x4, fa[i]);
+#pragma unroll
+                    for (int j = 0; j < NT; j++) acc[0][j] += __builtin_bit_cast(f32x4, fb[j]);
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll

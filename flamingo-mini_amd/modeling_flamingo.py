@@ -198,6 +198,10 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
             raise NotImplementedError("activation checkpointing of the language model is not supported by the fused cross-attention hooks: "
                                       "their conditioning (visual features, hoisted K / V) is released when forward() returns. "
                                       "Disable gradient checkpointing (the frozen LM keeps few activations: only the trainable blocks save theirs).")
+        if self.training and device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            # whatever optimizer drives an eager training loop: the error word of the fused cross-attention kernels' in-launch hand-offs is looked
+            # at once per forward (non-blocking: the value the previous call copied to pinned memory) - raises SyncExchangeTimeout
+            F.poll_sync_exchange("FlamingoBaseModel.forward")
         cuts = getattr(self, "_autograd_cuts", None)
         if cuts is not None and xattn_past is None:
             visual_features = cuts.cut(visual_features)      # (PiecewiseGraphedTrainStep: the resampler's backward becomes its own segment)

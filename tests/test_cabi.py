@@ -215,3 +215,18 @@ def test_reference_parameter_counts():
     assert sum(p.numel() for p in rs.parameters()) == 63023104
     assert sum(p.numel() for p in xa.parameters()) == 15471618
     assert len(rs.fused_params()) == len(list(rs.parameters())) and len(xa.fused_params()) == len(list(xa.parameters()))
+
+
+def test_sync_status_word_position_follows_the_header():
+    """functional._status_word() (where the Python layer's non-blocking probe reads the in-launch hand-offs' error word) must be the word
+    the header documents: behind the first two banks of FF_XATTN_SYNC_SLOTS counters; and with no sync buffer allocated the checks are no-ops."""
+    import re
+    from flamingo_mini_amd import ffi, functional as F
+    header = open(os.path.join(ROOT, "include", "flamingo_fusion.h")).read()
+    slots = int(re.search(r"#define FF_XATTN_SYNC_SLOTS (\d+)", header).group(1))
+    assert int(ffi.lib().ff_xattn_sync_bytes()) == (4 * slots + 64) * 4
+    assert F._status_word() == 2 * slots
+    if not F._sync_buffers:
+        F.check_sync_exchange("cpu")
+        F.poll_sync_exchange("cpu")
+        assert F.sync_exchange_status() == 0

@@ -443,7 +443,7 @@ def test_in_launch_exchange_beside_a_persistent_kernel(b):
     hog, side = cu_hog(), torch.cuda.Stream()
     sink = torch.zeros(4, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    rc = hog.cu_hog_launch(32, 128 * 1024, 400.0, sink.data_ptr(), side.cuda_stream)      # 32 CUs held for 0.4 s
+    rc = hog.cu_hog_launch(32, 128 * 1024, 1500.0, sink.data_ptr(), side.cuda_stream)     # 32 CUs held for 1.5 s
     assert rc == 0, rc
     import time
     time.sleep(0.02)                                    # the persistent workgroups are resident before the first fused launch is issued
@@ -453,8 +453,7 @@ def test_in_launch_exchange_beside_a_persistent_kernel(b):
         for k, x_, y_ in zip(names, crowded, quiet):
             assert torch.equal(x_, y_), (i, k)
     torch.cuda.current_stream().synchronize()
-    assert time.perf_counter() - t0 < 0.35, "the twelve steps were meant to run WHILE the persistent kernel holds its CUs"
-    assert not side.query(), "the persistent kernel ended before the fused launches did: the test did not test anything"
+    assert not side.query(), f"the persistent kernel ended before the fused launches did ({time.perf_counter() - t0:.2f} s): the test did not test anything"
     assert F.sync_exchange_status() == 0
     for k, a_, b_ in zip(names, crowded, separate):
         if a_.numel() > 1:
@@ -473,6 +472,66 @@ def test_in_launch_exchange_beside_a_persistent_kernel(b):
         assert torch.equal(x_, z_) and torch.equal(y_, z_), k
     assert F.sync_exchange_status() == 0
     torch.cuda.synchronize()
+
+
+def test_denied_co_residency_is_detected_not_silent():
+    """The failure itself, not a poked word: a persistent kernel holds 208 of the 256 CUs (26 of every XCD's 32: six left, fewer than a sample's
+    eight heads) while a fused forward + backward of 32 samples runs.  A sample's workgroups can no longer be resident together, the arrival waits
+    give up after 50 ms each (csrc kSpinTicks: bounded in TIME on the constant 100 MHz clock - round 6 found the former poll-count bound had
+    not expired after 6 s), and the launches compute on incomplete exchanges.  That must surface, and promptly: the call returns while the
+    other kernel still holds its CUs, the status word is 1, check_sync_exchange raises - and once the CUs are free again and the word is cleared
+    the same call gives the right answer.  (tools/sessions/r6/denial_probe.py: which hog sizes deny what; with >= 232 CUs held the launches
+    BEFORE the fused one already wait for the other kernel to end - slow, but correct: status 0.)"""
+    import time
+    from flamingo_mini_amd import functional as F
+    from util import cu_hog
+    dtype = torch.bfloat16
+    b, L, nv, dim, dv = 32, 32, 64, 1280, 256
+    p = xattn_params(dim, dv, 8, 64, 2, tag="denied")
+    m = build_block(p, dim, dv, 8, 64, nv, 2, "gelu", dtype)
+    ml = np.zeros((b, L), np.int64); ml[:, 0] = 1
+    yd = dev(det((b, L, dim), "den-y"), dtype).requires_grad_(True)
+    vfd = dev(det((b, 1, nv, dv), "den-vf"), dtype).requires_grad_(True)
+    dyd = dev(det((b, L, dim), "den-dy"), dtype)
+    mlt = torch.as_tensor(ml).cuda()
+
+    def run():
+        for t_ in (yd, vfd, *m.parameters()):
+            t_.grad = None
+        out, _ = m(yd, vfd, mlt)
+        out.backward(dyd)
+        torch.cuda.current_stream().synchronize()
+        return out.detach().clone(), yd.grad.clone()
+
+    good = run()
+    assert F.sync_exchange_status() == 0
+    props = torch.cuda.get_device_properties(0)
+    if props.multi_processor_count != 256:
+        pytest.skip("the scenario is laid out for 8 XCDs of 32 CUs")
+    hog, side = cu_hog(), torch.cuda.Stream()
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert hog.cu_hog_launch(208, 128 * 1024, 3000.0, sink.data_ptr(), side.cuda_stream) == 0      # 26 CUs of every XCD, for 3 s
+    time.sleep(0.05)
+    t0 = time.perf_counter()
+    try:
+        run()                                           # finishes (bounded waits), on garbage
+        took = time.perf_counter() - t0
+        assert not side.query(), "the other kernel ended first: nothing was denied"
+        assert took < 2.5, f"abandoned waits are bounded at 50 ms each; the call took {took:.2f} s"
+        assert F.sync_exchange_status() == 1, f"no hand-off timed out in {took:.2f} s although 208 CUs were held"
+        with pytest.raises(F.SyncExchangeTimeout):
+            F.check_sync_exchange("test")
+    finally:
+        side.synchronize()                              # the CUs are free again
+        word = F._status_word()
+        for buf in F._sync_buffers.values():
+            buf.view(torch.int32)[word] = 0
+        F._sync_probes.clear()
+        torch.cuda.synchronize()
+    again = run()
+    assert F.sync_exchange_status() == 0
+    assert torch.equal(again[0], good[0]) and torch.equal(again[1], good[1])
 
 
 def test_sync_exchange_timeout_is_raised_not_ignored():

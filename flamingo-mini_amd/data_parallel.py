@@ -101,6 +101,7 @@ class GradientAllReducer:
         self._sync = True
         fused = {id(p) for m in model.modules() if hasattr(m, "fused_params") for p in m.fused_params()}
         self._fused_ids = fused
+        self._fused_params = [p for p in model.parameters() if p.requires_grad and id(p) in fused]
         self._names = dict(model.named_parameters())
         self.loose = [p for p in model.parameters() if p.requires_grad and id(p) not in fused]
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_param) for p in self.loose]
@@ -266,6 +267,12 @@ class GradientAllReducer:
                 continue
             seen.add(id(p))
             self._mean_in_place(p.grad)
+        if self.active and self._sync and self._collect is None:
+            # fused parameters whose gradient did not arrive as a bucket of this model (torch.autocast over fp32 parameters: the fused modules ran
+            # on CASTS of them, whose buckets are not ours; the gradients reached the parameters through the casts' backward): exchanged here
+            for p in self._fused_params:
+                if p.grad is not None and id(p) not in self._early and id(p) not in seen:
+                    self._mean_in_place(p.grad)
         self.late.clear()
         self._early.clear()
 
@@ -487,6 +494,13 @@ class ShardedAdamW(torch.optim.Optimizer):
         for ev in self._work:
             torch.cuda.current_stream().wait_event(ev)
         self._work.clear()
+        covered = {id(p) for st in self.buckets.values() for p in st["params"]}
+        stray = [self._names.get(id(p), "?") for p in self._model.parameters()
+                 if p.requires_grad and p.grad is not None and id(p) in self._fused_ids and id(p) not in covered]
+        if stray:       # (torch.autocast over fp32 parameters: the fused modules ran on casts, no bucket of THIS model ever arrived)
+            raise RuntimeError(f"ShardedAdamW: {len(stray)} fused parameter(s) (e.g. {stray[0]}) have a gradient that did not arrive as a gradient bucket "
+                               "of their module - under torch.autocast the fused modules run on casts of fp32 parameters. Use bf16 parameters with "
+                               "master_dtype=torch.float32 here, or GradientAllReducer + FusedAdamW under autocast.")
         for st in self._late:                    # accumulated gradients: gather .grad into the bucket layout, then the same pipeline
             flat = torch.zeros_like(st["pflat"])
             for p, off, cnt in st["owners"]:

@@ -219,6 +219,26 @@ def _empty_bytes(n: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
 
 
+def autocast_compute_dtype(ref: torch.Tensor) -> Optional[torch.dtype]:
+    """Mixed-precision training the way the reference's recipe does it (`training/train.sh:24`: HF Trainer --fp16 = torch.autocast over fp32
+    parameters): inside a CUDA autocast region the drop-in modules hand the library copies of their parameters in the dtype its kernels
+    compute in - bfloat16 under bf16 autocast; float32 under fp16 autocast (the library has no fp16 kernels: that region runs its exact
+    fp32 kernels, correct and slow) - through differentiable casts, so the gradients reach the fp32 parameters.  None outside autocast."""
+    if not ref.is_cuda:
+        return None
+    try:                                    # torch >= 2.4 spells it per device type
+        on, adt = torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda")
+    except TypeError:
+        on, adt = torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype()
+    if not on:
+        return None
+    return torch.bfloat16 if adt == torch.bfloat16 else torch.float32
+
+
+def autocast_params(params: Sequence[torch.Tensor], dtype: torch.dtype):
+    return [p if p.dtype == dtype else p.to(dtype) for p in params]
+
+
 def _same_dtype(ref: torch.Tensor, tensors: Sequence[torch.Tensor], what: str) -> None:
     for t in tensors:
         if t.dtype != ref.dtype:

@@ -69,10 +69,23 @@ class GatedCrossAttentionBlock(nn.Module):
         if previous_kv is None:
             assert text_time.shape == y.shape[:2]
         shape_before = y.shape
-        extra = {} if hoisted_kv is None else {"hoisted_kv": hoisted_kv, "wgrad": (self.defer_wgrad, self.wgrad_group)}
-        out, kv = F.xattn_block(y, visual_features, text_time, self.fused_params(), self.cfg, self.n_visual,
+        params, defer = self.fused_params(), self.defer_wgrad
+        cdt = F.autocast_compute_dtype(y)
+        if cdt is not None:
+            # torch.autocast over fp32 parameters (the reference's --fp16 / --bf16 recipe): the kernels get casts of the parameters in their own
+            # dtype and the output goes back in the dtype it came in.  The casts' backward READS the gradients the moment this block's backward
+            # returns them, so the weight gradients cannot be deferred into a later grouped launch.
+            in_dtype, defer = y.dtype, False
+            params = F.autocast_params(params, cdt)
+            y = y.to(cdt)
+            visual_features = None if visual_features is None else visual_features.to(cdt)
+            hoisted_kv = None if hoisted_kv is None else hoisted_kv.to(cdt)
+        extra = {} if hoisted_kv is None else {"hoisted_kv": hoisted_kv, "wgrad": (defer, self.wgrad_group)}
+        out, kv = F.xattn_block(y, visual_features, text_time, params, self.cfg, self.n_visual,
                                 previous_kv=previous_kv, output_kv=bool(output_kv), **extra)
         assert out.shape == shape_before
+        if cdt is not None and out.dtype != in_dtype:
+            out = out.to(in_dtype)
         return out, kv
 
 

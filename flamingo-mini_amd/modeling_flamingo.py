@@ -216,6 +216,9 @@ class FlamingoBaseModel(ABC, PreTrainedModel):
         if xattn_past is None and self.hoist_kv:
             # every layer's to_kv sees the same visual features: project for all layers in grouped launches (functional.kv_project)
             weights = [h.xattn_block.attn.to_kv.weight for h in hooks]
+            cdt = F.autocast_compute_dtype(visual_features)
+            if cdt is not None:              # torch.autocast over fp32 parameters: casts in the kernels' dtype (functional.autocast_compute_dtype)
+                weights = F.autocast_params(weights, cdt)
             vf_cast = visual_features.to(weights[0].dtype)
             step = self.kv_project_group if self.kv_project_group > 0 else len(weights)
             hoisted = [kv for g in range(0, len(weights), step) for kv in F.kv_project(vf_cast, weights[g:g + step])]

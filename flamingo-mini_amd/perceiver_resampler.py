@@ -73,11 +73,15 @@ class PerceiverResampler(nn.Module):
         if x_f.shape[1] > self.num_time_embeds:
             raise RuntimeError(f"{x_f.shape[1]} frames but only {self.num_time_embeds} time embeddings")
         cfg = (self.depth, self.heads, self.dim_head, self.n_queries, self.num_time_embeds, self.ff_mult, self.act)
-        if x_f.dtype != self.latents.dtype:
-            x_f = x_f.to(self.latents.dtype)
+        params = self.fused_params()
+        cdt = F.autocast_compute_dtype(x_f)
+        if cdt is not None:                      # torch.autocast over fp32 parameters: see functional.autocast_compute_dtype
+            params = F.autocast_params(params, cdt)
+        if x_f.dtype != params[0].dtype:
+            x_f = x_f.to(params[0].dtype)
         if self.layerwise:
-            out = F.resampler_layerwise(x_f, self.fused_params(), cfg, cut=self.autograd_cut)
+            out = F.resampler_layerwise(x_f, params, cfg, cut=self.autograd_cut)
         else:
-            out = F.resampler(x_f, self.fused_params(), cfg)
+            out = F.resampler(x_f, params, cfg)
         assert out.shape == (x_f.shape[0], self.n_queries, self.dim)
         return out

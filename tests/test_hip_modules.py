@@ -365,6 +365,53 @@ def test_in_launch_exchange_equals_separate_launches_and_oracle(b, L, nv, dim):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16], ids=["bf16-autocast", "fp16-autocast"])
+def test_modules_with_fp32_parameters_under_autocast(amp):
+    """torch.autocast over fp32 parameters (the reference's mixed-precision recipe): a gated block at gpt2-large geometry and a resampler,
+    parameters in fp32, activations arriving in the autocast dtype.  bf16 autocast = the bf16 kernels on casts of the parameters (tolerances of
+    the bf16 path against the oracle on what the kernels saw); fp16 autocast = the fp32 kernels (the only error is the fp16 rounding of the
+    inputs, which the oracle is fed).  Outputs come back in the dtype the activations came in; gradients arrive on the fp32 parameters."""
+    dim, dv, heads, dh, ffm, nv, b, L = 1280, 1024, 8, 64, 4, 64, 4, 32
+    p = xattn_params(dim, dv, heads, dh, ffm, tag="amp")
+    m = build_block(p, dim, dv, heads, dh, nv, ffm, "gelu", torch.float32)
+    ml = np.zeros((b, L), np.int64); ml[:, 0] = 1; ml[1, 0] = 0; ml[1, 3] = 1
+    yd = dev(det((b, L, dim), "amp-y"), amp).requires_grad_(True)
+    vfd = dev(det((b, 1, nv, dv), "amp-vf"), amp).requires_grad_(True)
+    dyd = dev(det((b, L, dim), "amp-dy"), amp)
+    with torch.autocast("cuda", dtype=amp):
+        out, _ = m(yd, vfd, torch.as_tensor(ml).cuda())
+    assert out.dtype == amp
+    out.backward(dyd)
+    cdt = torch.bfloat16 if amp == torch.bfloat16 else torch.float32
+    p64 = {k: as64(v.detach().to(cdt)) for k, v in m.state_dict().items()}                 # what the kernels saw
+    outr, _, cache = O.gated_xattn_block_fwd(as64(yd.detach().to(cdt)), as64(vfd.detach().to(cdt)), ml, p64, n_visual=nv)
+    dyr, dvfr, gr = O.gated_xattn_block_bwd(as64(dyd.to(cdt)), cache, p64)
+    t = dict(TOL[torch.bfloat16]) if amp == torch.bfloat16 else dict(out=2e-3, grad=2e-3)    # fp16: the stored output / gradients are rounded to fp16 once
+    assert rel(out.float() - yd.detach().float(), outr - as64(yd.detach().to(cdt))) < max(t["out"], 8e-3 if amp == torch.float16 else 0)
+    assert rel(yd.grad, dyr) < t["grad"] and rel(vfd.grad, dvfr) < t["grad"]
+    for k, prm in m.named_parameters():
+        assert prm.grad is not None and prm.grad.dtype == torch.float32, k
+        if gr[k].size > 1:
+            assert rel(prm.grad, gr[k]) < t["grad"], k
+    # the resampler: fp32 parameters, CLIP features in the autocast dtype
+    rp = resampler_params(256, 2, 8, 64, 64, 4, 4, tag="amp-rs")
+    rs = build_resampler(rp, 256, 2, 8, 64, 64, 4, 4, "gelu", torch.float32)
+    x = dev(det((2, 2, 50, 256), "amp-x"), amp).requires_grad_(True)
+    dz = dev(det((2, 64, 256), "amp-dz"), cdt)
+    with torch.autocast("cuda", dtype=amp):
+        z_ = rs(x)
+    assert z_.dtype == cdt                                             # (the dtype the kernels computed in)
+    z_.backward(dz)
+    rp64 = {k: as64(v.detach().to(cdt)) for k, v in rs.state_dict().items()}
+    zr, rc = O.resampler_fwd(as64(x.detach().to(cdt)), rp64)
+    dxr, rg = O.resampler_bwd(as64(dz), rc, rp64)
+    tr = TOL[torch.bfloat16] if amp == torch.bfloat16 else dict(out=2e-3, grad=2e-3)
+    assert rel(z_, zr) < tr["out"] and rel(x.grad, dxr) < tr["grad"]
+    for k, prm in rs.named_parameters():
+        assert prm.grad is not None and prm.grad.dtype == torch.float32, k
+        assert rel(prm.grad, rg[k]) < tr["grad"], k
+
+
 def _fused_tiles_of_one_block_step(m, yd, vfd, mlt, dyd):
     """profile codes (ff_gemm_profile_record.tile) of the fused cross-attention launches of one forward + backward of block `m`"""
     from flamingo_mini_amd import ffi

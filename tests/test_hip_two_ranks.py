@@ -33,12 +33,13 @@ def _paths():
 def _train(model, batch, mode, reducer, adamw):
     from flamingo_mini_amd import FusedAdamW
     from flamingo_mini_amd.graphs import PiecewiseGraphedTrainStep
-    opt = FusedAdamW([p for p in model.parameters_trainable()], capturable=mode != "eager", **adamw)
+    opt = FusedAdamW([p for p in model.parameters_trainable()], capturable=mode not in ("eager", "eager-autocast"), **adamw)
     losses = []
-    if mode == "eager":
+    if mode in ("eager", "eager-autocast"):
         for _ in range(N_STEPS):
             model.zero_grad(set_to_none=True)
-            loss = model(**batch).loss
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "eager-autocast"):
+                loss = model(**batch).loss
             loss.backward()
             if reducer is not None:
                 reducer.finish()
@@ -72,18 +73,20 @@ def _worker(rank, world, port, out_dir, mode, dtype_name):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
-@pytest.mark.parametrize("mode", ["eager", "piecewise", "overlapped"])
+@pytest.mark.parametrize("mode,dtype_name", [(m, d) for d in ("float32", "bfloat16") for m in ("eager", "piecewise", "overlapped")] + [("eager-autocast", "float32")],
+                         ids=lambda v: str(v))
 def test_two_ranks_on_the_real_kernels_equal_one_process_on_the_whole_batch(tmp_path, mode, dtype_name):
+    """(eager-autocast, round 6: fp32 parameters under torch.autocast(bf16) - the fused modules run on casts of the parameters, no gradient bucket
+    of theirs arrives, and the reducer exchanges those parameters' gradients in finish().)"""
     _paths()
     from test_model_plumbing import H64, build_h64
     from util import rel
     mp.start_processes(_worker, args=(2, _free_port(), str(tmp_path), mode, dtype_name), nprocs=2, join=True, start_method="spawn")
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     model, z, batch = build_h64(getattr(torch, dtype_name), "cuda")
-    ref_losses = _train(model, batch, "eager", None, H64["adamw"])
-    f32 = dtype_name == "float32"
-    for i in range(1 if mode != "eager" else 0, N_STEPS):      # the whole-batch loss is the mean of the two ranks' losses (equal token counts)
+    ref_losses = _train(model, batch, "eager-autocast" if mode == "eager-autocast" else "eager", None, H64["adamw"])
+    f32 = dtype_name == "float32" and mode != "eager-autocast"
+    for i in range(1 if mode not in ("eager", "eager-autocast") else 0, N_STEPS):      # the whole-batch loss is the mean of the two ranks' losses (equal token counts)
         both = 0.5 * (float(r0["losses"][i]) + float(r1["losses"][i]))
         assert abs(both - ref_losses[i]) <= (2e-5 if f32 else 3e-2) * max(1.0, abs(ref_losses[i])), (i, both, ref_losses)
     for k, p in model.named_parameters():

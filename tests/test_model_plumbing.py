@@ -165,6 +165,37 @@ def test_full_gpt2_model_bf16_on_hip():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16], ids=["bf16-autocast", "fp16-autocast"])
+def test_full_gpt2_model_fp32_parameters_under_autocast(amp):
+    """The reference's own training recipe is mixed precision through torch.autocast over fp32 parameters (HF Trainer --fp16,
+    training/train.sh:24; --bf16 on newer hardware), which its plain nn.Modules support for free.  The drop-in must too: inside an autocast
+    region the fused modules run on differentiable casts of their fp32 parameters - bf16 kernels under bf16 autocast, the exact fp32 kernels
+    under fp16 autocast (the library has no fp16 kernels) - and the gradients arrive on the fp32 parameters.  Held to the reference's float64
+    vectors at the whole-model bf16 tolerance (the stock backbones run in the autocast dtype either way)."""
+    model, z = build(torch.float32, "cuda", "gpt2")
+    px = torch.from_numpy(z["px"]).to(device="cuda", dtype=torch.float32)
+    ids, ml = torch.from_numpy(z["ids"]).cuda(), torch.from_numpy(z["ml"]).cuda()
+    model.train()
+    with torch.autocast("cuda", dtype=amp):
+        out = model(input_ids=ids, attention_mask=torch.ones_like(ids), media_locations=ml, pixel_values=px, labels=ids)
+    assert rel(out.logits.float(), z["logits"]) < TOL_FULL_BF16["out"]
+    assert abs(float(out.loss) - float(z["loss"])) < TOL_FULL_BF16["loss"]
+    out.loss.backward()
+    named = dict(model.named_parameters())
+    worst = {}
+    for k in [k[2:] for k in z["files"] if k.startswith("g.")]:
+        ref = z["g." + k]
+        g = named[k].grad
+        assert g is not None and g.dtype == torch.float32, k          # the gradient reached the fp32 parameter
+        if ref.size == 1:
+            assert gate_grad_ok(g.cpu().numpy(), ref, TOL_FULL_BF16["grad"], z["gs." + k]), (k, float(g), float(ref.reshape(-1)[0]))
+        else:
+            worst[k] = rel(g, ref)
+    bad = {k: v for k, v in worst.items() if not v < TOL_FULL_BF16["grad"]}
+    assert not bad, bad
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("family", ["opt", "gpt2"])
 def test_greedy_generate_cached_equals_uncached(family):
     model, z = build(torch.float32, "cuda", family)

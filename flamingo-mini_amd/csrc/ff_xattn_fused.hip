@@ -739,7 +739,8 @@ constexpr int kSyncSlots = FF_XATTN_SYNC_SLOTS;         // samples per counter b
 constexpr int kSyncStatus = 2 * kSyncSlots;
 constexpr int kOutNS = 4;                               // ring depth of the phase-2 weight stream
 constexpr int kOutMaxPer = 6;                           // 32-column groups per head slice: dim / heads <= 192
-constexpr unsigned long long kSpinTicks = 5000000ull;     // 50 ms of the 100 MHz wall clock: the bound of an arrival wait (res_await)
+constexpr unsigned long long kSpinTicks = 5000000ull;     // 50 ms of the 100 MHz wall clock and ...
+constexpr int kSpinPolls = 1 << 14;                      // ... this many polls of its own: the bound of an arrival wait (res_await)
 
 // one accumulator row -> global, write-through (sc1): the line leaves this XCD's L2, every other CU's sc1 load sees it.
 // 16-byte stores: lane (c, g) holds columns g*4 .. g*4+3 of every 16-column tile; the lanes g and g ^ 1 swap halves so that the even one
@@ -774,17 +775,23 @@ FF_DEV unsigned res_arrive(unsigned* cnt, unsigned group) {
     const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (ticket / group + 1u) * group;
 }
-// The wait is bounded in TIME (the constant 100 MHz clock), not in polls: round 6 measured the poll loop at ~23 us per iteration when most of
-// the chip is held by another kernel (r6s9: 2^18 polls had not expired after 6 s), which is a hang for all practical purposes.  50 ms is three
-// orders of magnitude beyond a legitimate wait (a sample's heads are dispatched back to back; the launch itself lasts ~30 us) and short enough
-// that a launch denied co-residency fails within a fraction of a second.
+// The wait is bounded in polls AND in time.  A poll (s_sleep + one sc1 load) takes ~0.2 us when a launch is denied co-residency (r6s18: 233 000 -
+// 266 000 polls in 50 ms), but its duration follows the memory system's load, so a poll count alone is an uncalibrated bound (rounds 5's 2^18
+// polls were ~55 ms there); the constant 100 MHz clock alone is no bound either: it keeps running while a queue is preempted (two processes
+// time-slicing one GPU), and a workgroup that comes back from a long slice must not give up on partners that were suspended with it.  So a wait
+// gives up after 50 ms of wall time during which it also completed 2^14 polls of its own - three orders of magnitude beyond a legitimate wait (a
+// sample's heads are dispatched back to back; the launch itself lasts ~30 us) - and a launch denied co-residency fails within a fraction of a second.
+// (s_memrealtime, not wall_clock64(): the latter was hoisted out of the loop when it sat behind the poll-count test - r6s17 - and never fired.)
 FF_DEV void res_await(unsigned* cnt, unsigned target, unsigned* status) {
-    const unsigned long long t0 = wall_clock64();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int polls = 0;
     while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > kSpinTicks) {
-            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+        if (++polls > kSpinPolls) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) {
+                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
         }
     }
 }

@@ -524,8 +524,8 @@ def test_in_launch_exchange_beside_a_persistent_kernel(b):
 def test_denied_co_residency_is_detected_not_silent():
     """The failure itself, not a poked word: a persistent kernel holds 208 of the 256 CUs (26 of every XCD's 32: six left, fewer than a sample's
     eight heads) while a fused forward + backward of 32 samples runs.  A sample's workgroups can no longer be resident together, the arrival waits
-    give up after 50 ms each (csrc kSpinTicks: bounded in TIME on the constant 100 MHz clock - round 6 found the former poll-count bound had
-    not expired after 6 s), and the launches compute on incomplete exchanges.  That must surface, and promptly: the call returns while the
+    give up after 50 ms each (csrc kSpinTicks / kSpinPolls: 50 ms of the constant 100 MHz clock AND 2^14 polls of their own - a poll takes ~0.2 us
+    there, r6s18), and the launches compute on incomplete exchanges.  That must surface, and promptly: the call returns while the
     other kernel still holds its CUs, the status word is 1, check_sync_exchange raises - and once the CUs are free again and the word is cleared
     the same call gives the right answer.  (tools/sessions/r6/denial_probe.py: which hog sizes deny what; with >= 232 CUs held the launches
     BEFORE the fused one already wait for the other kernel to end - slow, but correct: status 0.)"""

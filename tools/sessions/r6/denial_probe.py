@@ -15,7 +15,7 @@ m = GatedCrossAttentionBlock(dim=1280, dim_visual=256, dim_head=64, heads=8, ff_
 m.load_state_dict({k: torch.as_tensor(np.asarray(v, np.float64)).float() for k, v in p.items()})
 m = m.to(dtype).cuda()
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
-for held, b in [(0, 32), (208, 32), (224, 32), (232, 32), (240, 32), (248, 2), (248, 32), (200, 64)]:
+for held, b in [(0, 32), (208, 32), (224, 32), (200, 64), (128, 64)]:
     ml = torch.zeros((b, 32), dtype=torch.long, device="cuda"); ml[:, 0] = 1
     y = dev(det((b, 32, 1280), "pr-y"), dtype).requires_grad_(True)
     vf = dev(det((b, 1, 64, 256), "pr-vf"), dtype)
@@ -38,6 +38,8 @@ for held, b in [(0, 32), (208, 32), (224, 32), (232, 32), (240, 32), (248, 2), (
     st = F.sync_exchange_status()
     side.synchronize()
     w = F._status_word()
+    raw = [int(buf.view(torch.int32)[w]) for buf in F._sync_buffers.values()]
+    st = f"{st} (raw words {raw})"
     for buf in F._sync_buffers.values():
         buf.view(torch.int32)[w] = 0
     torch.cuda.synchronize()

@@ -76,6 +76,10 @@ def _let_the_watchdog_drain() -> None:
             time.sleep(_WATCHDOG_PERIOD_S / 2)
 
 
+def _autocast(dtype: Optional[torch.dtype]):
+    return torch.autocast("cuda", dtype=dtype) if dtype is not None else contextlib.nullcontext()
+
+
 def _model_device(model: torch.nn.Module) -> torch.device:
     for p in model.parameters():
         if p.is_cuda:
@@ -107,11 +111,13 @@ class GraphedTrainStep:
     launch was ever denied co-residency: a replayed graph cannot train through a timed-out hand-off unnoticed.  0 = only at those two points."""
 
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
-                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, check_every: int = 128):
+                 warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, check_every: int = 128,
+                 autocast: Optional[torch.dtype] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a GPU")
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
         self.check_every, self._replays = int(check_every), 0
+        self.autocast = autocast        # torch.bfloat16 / torch.float16: the forward runs under torch.autocast (fp32 parameters, the reference's recipe)
         _refuse_live_autograd_graphs(model)
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self._loss_fn = loss_fn or (lambda out: out.loss)
@@ -152,7 +158,8 @@ class GraphedTrainStep:
 
     def _eager(self) -> torch.Tensor:
         self.model.zero_grad(set_to_none=True)              # gradients are re-created (not accumulated) by every backward
-        loss = self._loss_fn(self.model(**self.static))
+        with _autocast(self.autocast):
+            loss = self._loss_fn(self.model(**self.static))
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()                           # the capturing stream waits for the collectives before the optimizer reads .grad
@@ -288,8 +295,10 @@ class PiecewiseGraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer], example_batch: Dict[str, torch.Tensor],
                  warmup: int = 3, loss_fn: Optional[Callable] = None, reducer=None, segment_layers: int = 4, capture: bool = True,
-                 pace: str = "host", overlap_optimizer: bool = False, segment_arena: bool = True, check_every: int = 128):
+                 pace: str = "host", overlap_optimizer: bool = False, segment_arena: bool = True, check_every: int = 128,
+                 autocast: Optional[torch.dtype] = None):
         self.check_every, self._replays = int(check_every), 0          # see GraphedTrainStep
+        self.autocast = autocast
         if pace not in ("host", "stream"):
             raise ValueError("pace must be 'host' or 'stream'")
         if overlap_optimizer and (pace != "host" or not capture):
@@ -371,8 +380,12 @@ class PiecewiseGraphedTrainStep:
 
         model.zero_grad(set_to_none=True)
         self.cuts.reset()
+        def fwd():
+            with _autocast(self.autocast):
+                return self._loss_fn(self.model(**self.static))
+
         with self.cuts.arm():
-            loss = piece(lambda: self._loss_fn(self.model(**self.static)))
+            loss = piece(fwd)
         self.loss = loss.detach()
         trainable = [p for p in model.parameters() if p.requires_grad]
         last_touched, seen = {}, {}
@@ -438,7 +451,7 @@ class PiecewiseGraphedTrainStep:
         rng = torch.cuda.get_rng_state()                    # (the pass must not shift the dropout stream of the steps that follow)
         ctx = self.reducer.no_sync() if self.reducer is not None and hasattr(self.reducer, "no_sync") else contextlib.nullcontext()
         with ctx:
-            with self.cuts.arm():
+            with self.cuts.arm(), _autocast(self.autocast):
                 loss = self._loss_fn(self.model(**self.static))
             for seg in self.cuts.segments(loss):
                 arena = F.GradArena()
@@ -459,7 +472,7 @@ class PiecewiseGraphedTrainStep:
         that un-fused parameters, whose gradient is accumulated by two segments, are exchanged after the last one (reducer.finish())."""
         self.model.zero_grad(set_to_none=True)
         self.cuts.reset()
-        with self.cuts.arm():
+        with self.cuts.arm(), _autocast(self.autocast):
             loss = self._loss_fn(self.model(**self.static))
         if self.reducer is not None:
             self.reducer.defer_loose = True

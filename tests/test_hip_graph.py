@@ -60,6 +60,34 @@ def test_graph_replay_equals_eager_steps(dtype):
     assert {float(s["step"]) for s in opt_g.state_dict()["state"].values()} == {6.0}
 
 
+def test_graph_replay_under_autocast_equals_eager_steps_under_autocast():
+    """fp32 parameters, torch.autocast(bf16) around the forward (the reference's mixed-precision recipe): GraphedTrainStep(autocast=...) captures the
+    casts of the parameters with the step; replays equal eager autocast steps."""
+    from flamingo_mini_amd import FusedAdamW, GraphedTrainStep
+    torch.manual_seed(0)
+    eager = _Toy().cuda()
+    graphed = copy.deepcopy(eager)
+    ml = torch.zeros(2, 16, dtype=torch.int64, device="cuda")
+    ml[:, 0] = 1
+    batches = [dict(x_f=dev(rnd((2, 1, 24, 64), 10 + i)), y=dev(rnd((2, 16, 64), 20 + i)), media_locations=ml) for i in range(5)]
+    opt_e = FusedAdamW(eager.parameters(), lr=1e-2)
+    losses_e = []
+    for b in batches:
+        eager.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = eager(**b)
+        loss.backward()
+        opt_e.step()
+        losses_e.append(float(loss))
+    opt_g = FusedAdamW(graphed.parameters(), lr=1e-2, capturable=True)
+    with GraphedTrainStep(graphed, opt_g, batches[0], warmup=1, loss_fn=lambda out: out, autocast=torch.bfloat16) as step:
+        losses_g = [None] + [float(step(b)) for b in batches[1:]]
+    for le, lg in zip(losses_e[1:], losses_g[1:]):
+        assert abs(le - lg) <= 3e-2 * max(1.0, abs(le)), (losses_e, losses_g)
+    for (n, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert pg.dtype == torch.float32 and rel(pg, pe) < 3e-2, n
+
+
 class _ToyHoisted(torch.nn.Module):
     """Resampler + two gated blocks on K / V projected up front (the training layout of FlamingoModel): exercises the deferred,
     grouped weight gradients and every kind of gradient bucket the reducer sees."""

@@ -216,6 +216,35 @@ def test_sharded_adamw_on_one_rccl_rank_equals_fused_adamw(one_rank_rccl, master
         assert rel(pb, pa) < 1e-2, n
 
 
+def test_sharded_adamw_refuses_autocast_over_fp32_parameters(one_rank_rccl):
+    """Under torch.autocast the fused modules run on casts of their fp32 parameters, so no gradient bucket of THIS model ever reaches
+    ShardedAdamW - whose update is per bucket.  It must say so instead of silently not updating those parameters."""
+    from flamingo_mini_amd.data_parallel import ShardedAdamW
+    torch.manual_seed(0)
+
+    class ToyLoose(_Toy):                   # ... plus one un-fused trainable parameter (the token embedding's role)
+        def __init__(self):
+            super().__init__()
+            self.loose = torch.nn.Parameter(torch.ones(64))
+
+        def forward(self, x_f, y, media_locations):
+            return super().forward(x_f, y * self.loose, media_locations)
+
+    model = ToyLoose().cuda()
+    ml = torch.zeros(2, 16, dtype=torch.int64, device="cuda"); ml[:, 0] = 1
+    batch = dict(x_f=dev(rnd((2, 1, 24, 64), 70)), y=dev(rnd((2, 16, 64), 71)), media_locations=ml)
+    opt = ShardedAdamW(model, lr=1e-2, force_collectives=True)
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(**batch)
+        loss.backward()
+        with pytest.raises(RuntimeError, match="did not arrive as a gradient bucket"):
+            opt.finish_step()
+        torch.cuda.synchronize()
+    finally:
+        opt.close()
+
+
 @pytest.mark.parametrize("mode,expect", [("drop", 0), ("nograd", 0), ("keep", 3)])
 def test_capture_after_an_eager_forward_of_the_same_model(mode, expect):
     """tools/capture_after_eager.py in a child process (the failure this guards against was a segmentation fault inside the runtime):
